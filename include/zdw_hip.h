@@ -1,0 +1,157 @@
+/*
+ * zdw_hip.h — C ABI of libzdw_hip.so: the MI355X (gfx950) implementation of adobe/zdw's
+ * two-pass TSV -> ZDW block encode.
+ *
+ * The reference has no FFI for this path; its seam is four private calls that
+ * ConvertToZDW::processFile makes once per block (cplusplus/ConvertToZDW.cpp:805,848,851,872):
+ *
+ *     parseInput(FILE*)                -> zdw_block_pass1
+ *     uniques.write(FILE*)             -> zdw_block_dict
+ *     writeLookupColumnStats(FILE*,n)  -> zdw_block_stats
+ *     writeBlockRows(FILE*,FILE*,n,u)  -> zdw_block_pass2
+ *     uniques.clear()                  -> zdw_block_next
+ *
+ * They stream through FILE*; this ABI is buffer based (plain pointers and sizes, no C++ or
+ * torch types).  The host shim (zdw_amd/csrc/ConvertToZDW.cpp, the convertDWfile CLI) keeps
+ * everything else: .desc.sql parsing, file header, block header, compressor child, rename.
+ *
+ * Return values are the reference's ERR_CODE numbers (cplusplus/ConvertToZDW.h:44-70):
+ * 0 OK, 7 OUT_OF_MEMORY, 15 WRONG_NUM_OF_COLUMNS_ON_A_ROW, 20 UNKNOWN_ERROR (HIP failures,
+ * unsupported input); zdw_last_error() has the text.  No exception crosses this boundary.
+ *
+ * Threading: one context per input file; calls on one context must be serialised.
+ * Ownership: the library owns all device memory and every buffer it returns (valid until the
+ * next zdw_block_next / zdw_set_input_* / zdw_ctx_destroy on that context); the caller owns
+ * what it passes in.
+ */
+#ifndef ZDW_HIP_H
+#define ZDW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZDW_ABI_VERSION 1
+
+/* ERR_CODE values used by this library (cplusplus/ConvertToZDW.h:44-70) */
+#define ZDW_OK 0
+#define ZDW_OUT_OF_MEMORY 7
+#define ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW 15
+#define ZDW_UNKNOWN_ERROR 20
+
+/* column type ids stored in the file (cplusplus/zdw_column_type_constants.h:17-35) */
+enum {
+    ZDW_VARCHAR = 0, ZDW_TEXT = 1, ZDW_DATETIME = 2, ZDW_CHAR_2 = 3, ZDW_CHAR = 6,
+    ZDW_TINY = 7, ZDW_SHORT = 8, ZDW_LONG = 9, ZDW_LONGLONG = 10, ZDW_DECIMAL = 11,
+    ZDW_TINY_SIGNED = 12, ZDW_SHORT_SIGNED = 13, ZDW_LONG_SIGNED = 14, ZDW_LONGLONG_SIGNED = 15,
+    ZDW_TINYTEXT = 16, ZDW_MEDIUMTEXT = 17, ZDW_LONGTEXT = 18
+};
+
+typedef struct zdw_ctx zdw_ctx;
+
+typedef struct zdw_opts {
+    uint32_t struct_size;          /* sizeof(zdw_opts), for forward compatibility */
+    int32_t device;                /* HIP device ordinal; -1 = the calling thread's current device */
+    uint32_t trim_trailing_spaces; /* convertDWfile -t (ConvertToZDW.cpp:295-313) */
+    uint32_t first_row_capacity;   /* initial m_LongestLine; 0 = 16384 (ConvertToZDW.cpp:965) */
+    uint64_t dict_slots;           /* initial hash-table slots for the string dictionary; 0 = automatic */
+    uint64_t reserved[4];
+} zdw_opts;
+
+/* Where a block must end when it cannot hold the whole remaining input (reference: memory-driven,
+ * StringHeap/Memory).  max_rows = rows in this block; partial_fields = how many
+ * leading fields of the following row pass 1 had already visited when the limit tripped (they stay
+ * in this block's dictionary and ranges, the row itself moves to the next block). */
+typedef struct zdw_split_hint {
+    uint32_t max_rows;        /* 0xFFFFFFFF = no limit */
+    uint32_t partial_fields;
+} zdw_split_hint;
+
+typedef struct zdw_pass1_result {
+    uint32_t num_rows;        /* rows in this block (block header field 1) */
+    uint32_t longest_line;    /* emulated m_LongestLine after this block's pass 1 (block header field 2) */
+    uint32_t is_last_block;   /* block header field 3 ('done') */
+    uint32_t bad_row;         /* 1-based row within the block when the call returns 15, else 0 */
+    uint64_t bytes_consumed;  /* input bytes covered by blocks so far (start of the next block) */
+    uint64_t dict_entries;    /* unique strings this block's pass 1 found (Dictionary::getNumEntries) */
+    uint64_t table_slots;     /* hash-table size that was sufficient */
+} zdw_pass1_result;
+
+/* Per-kernel device times of the last block, milliseconds, measured with HIP events on the
+ * context's stream when timing is enabled (zdw_ctx_enable_timing). */
+#define ZDW_NUM_STAGES 12
+typedef struct zdw_stage_times {
+    float ms[ZDW_NUM_STAGES];
+    uint32_t launches[ZDW_NUM_STAGES];
+} zdw_stage_times;
+enum {
+    ZDW_STAGE_SCAN_ROWS = 0,   /* row-start count per span + exclusive scan            */
+    ZDW_STAGE_PASS1 = 1,       /* tokenise + hash/dedupe + integer parse + column ranges */
+    ZDW_STAGE_DICT_COMPACT = 2,
+    ZDW_STAGE_DICT_SORT = 3,
+    ZDW_STAGE_DICT_EMIT = 4,   /* offsets + dictionary blob */
+    ZDW_STAGE_PASS2_SIZE = 5,  /* per-row encoded length + exclusive scan */
+    ZDW_STAGE_PASS2_EMIT = 6,
+    ZDW_STAGE_H2D = 7,
+    ZDW_STAGE_D2H = 8
+};
+
+uint32_t zdw_abi_version(void);
+
+/* col_types: ncols type ids as stored in the file header (after ReadDescFile, ConvertToZDW.cpp:91-162). */
+int zdw_ctx_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opts, zdw_ctx **out);
+void zdw_ctx_destroy(zdw_ctx *ctx);
+const char *zdw_last_error(const zdw_ctx *ctx);   /* ctx may be NULL: last zdw_ctx_create error */
+int zdw_ctx_enable_timing(zdw_ctx *ctx, int enable);
+int zdw_ctx_stage_times(const zdw_ctx *ctx, zdw_stage_times *out);
+
+/* The whole TSV image of one input file.  Host variant copies to HBM (pinned staging);
+ * the device variant borrows an HBM-resident buffer (16-byte aligned) and never writes to it. */
+int zdw_set_input_host(zdw_ctx *ctx, const uint8_t *tsv, uint64_t len);
+int zdw_set_input_device(zdw_ctx *ctx, const void *d_tsv, uint64_t len);
+
+/* parseInput(): consumes rows from the current position up to the end of input or the split hint
+ * (NULL = no limit).  Returns 0, 15 (res->bad_row set), 7 (a block of zero rows was forced) or 20. */
+int zdw_block_pass1(zdw_ctx *ctx, const zdw_split_hint *hint, zdw_pass1_result *res);
+
+/* Dictionary::write(): the dictionary section exactly as it appears in the file
+ * (dictionary.cpp:76-111): 00 for an empty dictionary, else index_size, size (index_size bytes LE),
+ * 00, then every string + NUL in strcmp order. */
+int zdw_block_dict(zdw_ctx *ctx, const uint8_t **section, uint64_t *section_len, uint8_t *index_size);
+
+/* writeLookupColumnStats(): col_size[ncols]; col_base[used] for used columns in column order
+ * (ConvertToZDW.cpp:417-483).  col_base must have room for ncols entries. */
+int zdw_block_stats(zdw_ctx *ctx, uint8_t *col_size, uint64_t *col_base, uint32_t *used);
+
+/* writeBlockRows(): the encoded rows of the block (ConvertToZDW.cpp:486-606). */
+int zdw_block_pass2(zdw_ctx *ctx, const uint8_t **rows, uint64_t *rows_len);
+
+/* Device-resident forms of the two bulk outputs (no D2H copy): for callers that keep the block in HBM. */
+int zdw_block_dict_device(zdw_ctx *ctx, const void **d_section, uint64_t *section_len, uint8_t *index_size);
+int zdw_block_pass2_device(zdw_ctx *ctx, const void **d_rows, uint64_t *rows_len);
+
+/* uniques.clear(): drop the block's state; the next zdw_block_pass1 continues at bytes_consumed. */
+int zdw_block_next(zdw_ctx *ctx);
+
+/* ---- multi-GPU: one ZDW block row-sharded over several contexts ----------------
+ * After zdw_block_pass1 on every shard:
+ *   zdw_shard_export_ranges / zdw_shard_import_ranges  : per-column min / max / seen (all-reduce)
+ *   zdw_shard_export_uniques                           : this shard's unique strings (len-prefixed)
+ *   zdw_shard_import_uniques                           : the union of all shards' strings; every
+ *                                                        shard then sorts the same set -> same offsets
+ *   zdw_shard_set_prev_row / zdw_shard_last_row        : stored values of the row before this shard
+ */
+int zdw_shard_export_ranges(zdw_ctx *ctx, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen);
+int zdw_shard_import_ranges(zdw_ctx *ctx, const uint64_t *col_min, const uint64_t *col_max, const uint8_t *col_seen);
+int zdw_shard_export_uniques(zdw_ctx *ctx, const void **d_lens, const void **d_bytes, uint64_t *count, uint64_t *nbytes);
+int zdw_shard_import_uniques(zdw_ctx *ctx, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes);
+int zdw_shard_last_row(zdw_ctx *ctx, uint64_t *stored /* ncols */);
+int zdw_shard_set_prev_row(zdw_ctx *ctx, const uint64_t *stored /* ncols, NULL = zeros */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZDW_HIP_H */

@@ -1,0 +1,25 @@
+"""In-tree build of the native code (hipcc --offload-arch=gfx950; g++ for the host shim)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB_HIP = os.path.join(LIBDIR, "libzdw_hip.so")
+LIB_CLI = os.path.join(LIBDIR, "libzdw_cli.so")
+CLI_EXE = os.path.join(LIBDIR, "convertDWfile")
+LIB_SYNTH = os.path.join(LIBDIR, "libzdw_synth.so")
+
+
+def build(jobs=4, quiet=True):
+    """(Re)build libzdw_hip.so, libzdw_cli.so and convertDWfile.  make decides what is stale."""
+    cmd = ["make", "-C", CSRC, "-j%d" % jobs, "all"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL if quiet else None)
+    for p in (LIB_HIP, LIB_CLI, CLI_EXE, LIB_SYNTH):
+        if not os.path.exists(p):
+            raise RuntimeError("native build did not produce " + p)
+    return LIB_HIP
+
+
+def have_sources():
+    return os.path.exists(os.path.join(CSRC, "Makefile"))

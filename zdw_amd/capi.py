@@ -1,0 +1,218 @@
+"""ctypes binding of include/zdw_hip.h.  Fails loudly when libzdw_hip.so is missing: there is no
+CPU fallback for the encode path."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK, OUT_OF_MEMORY, WRONG_NUM_OF_COLUMNS_ON_A_ROW, UNKNOWN_ERROR = 0, 7, 15, 20
+NUM_STAGES = 12
+STAGE_NAMES = ["scan_rows", "pass1", "dict_compact", "dict_sort", "dict_emit", "pass2_size", "pass2_emit", "h2d", "d2h"]
+
+
+class Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("trim_trailing_spaces", C.c_uint32),
+                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+
+class SplitHint(C.Structure):
+    _fields_ = [("max_rows", C.c_uint32), ("partial_fields", C.c_uint32)]
+
+
+class Pass1Result(C.Structure):
+    _fields_ = [("num_rows", C.c_uint32), ("longest_line", C.c_uint32), ("is_last_block", C.c_uint32), ("bad_row", C.c_uint32),
+                ("bytes_consumed", C.c_uint64), ("dict_entries", C.c_uint64), ("table_slots", C.c_uint64)]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [("ms", C.c_float * NUM_STAGES), ("launches", C.c_uint32 * NUM_STAGES)]
+
+
+class ZdwError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("zdw error %d: %s" % (code, text))
+        self.code = code
+        self.text = text
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_build.LIB_HIP):
+            raise RuntimeError("libzdw_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`"
+                               % _build.LIB_HIP)
+        L = C.CDLL(_build.LIB_HIP, mode=C.RTLD_GLOBAL)
+        vp, u8p, u64p, u32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        L.zdw_abi_version.restype = C.c_uint32
+        L.zdw_ctx_create.argtypes = [u8p, C.c_uint32, C.POINTER(Opts), C.POINTER(vp)]
+        L.zdw_ctx_destroy.argtypes = [vp]
+        L.zdw_ctx_destroy.restype = None
+        L.zdw_last_error.argtypes = [vp]
+        L.zdw_last_error.restype = C.c_char_p
+        L.zdw_ctx_enable_timing.argtypes = [vp, C.c_int]
+        L.zdw_ctx_stage_times.argtypes = [vp, C.POINTER(StageTimes)]
+        L.zdw_set_input_host.argtypes = [vp, vp, C.c_uint64]
+        L.zdw_set_input_device.argtypes = [vp, vp, C.c_uint64]
+        L.zdw_block_pass1.argtypes = [vp, C.POINTER(SplitHint), C.POINTER(Pass1Result)]
+        L.zdw_block_dict.argtypes = [vp, C.POINTER(vp), u64p, u8p]
+        L.zdw_block_dict_device.argtypes = [vp, C.POINTER(vp), u64p, u8p]
+        L.zdw_block_stats.argtypes = [vp, u8p, u64p, u32p]
+        L.zdw_block_pass2.argtypes = [vp, C.POINTER(vp), u64p]
+        L.zdw_block_pass2_device.argtypes = [vp, C.POINTER(vp), u64p]
+        L.zdw_block_next.argtypes = [vp]
+        L.zdw_shard_export_ranges.argtypes = [vp, u64p, u64p, u8p]
+        L.zdw_shard_import_ranges.argtypes = [vp, u64p, u64p, u8p]
+        L.zdw_shard_export_uniques.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, u64p]
+        L.zdw_shard_import_uniques.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
+        L.zdw_shard_last_row.argtypes = [vp, u64p]
+        L.zdw_shard_set_prev_row.argtypes = [vp, u64p]
+        _lib = L
+    return _lib
+
+
+class Block:
+    """Host copies of one encoded block's sections (what the reference writes between two block headers)."""
+
+    def __init__(self, num_rows, longest_line, is_last, dict_section, col_size, col_base, rows, p1):
+        self.num_rows, self.longest_line, self.is_last = num_rows, longest_line, is_last
+        self.dict_section, self.col_size, self.col_base, self.rows, self.p1 = dict_section, col_size, col_base, rows, p1
+
+    def tobytes(self):
+        import struct
+        return (struct.pack("<IIB", self.num_rows, self.longest_line, 1 if self.is_last else 0) + self.dict_section
+                + self.col_size + struct.pack("<%dQ" % len(self.col_base), *self.col_base) + self.rows)
+
+
+class Encoder:
+    """One zdw_ctx: the per-block seam of ConvertToZDW::processFile (cplusplus/ConvertToZDW.cpp:805-872)."""
+
+    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0):
+        self.L = lib()
+        self.ncols = len(col_types)
+        types = (C.c_uint8 * max(1, self.ncols))(*col_types)
+        o = Opts()
+        o.struct_size = C.sizeof(Opts)
+        o.device = device
+        o.trim_trailing_spaces = 1 if trim else 0
+        o.first_row_capacity = first_row_capacity
+        o.dict_slots = dict_slots
+        h = C.c_void_p()
+        rc = self.L.zdw_ctx_create(types, self.ncols, C.byref(o), C.byref(h))
+        if rc:
+            raise ZdwError(rc, self.L.zdw_last_error(None).decode())
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zdw_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise ZdwError(rc, self.L.zdw_last_error(self.h).decode())
+
+    def enable_timing(self, on=True):
+        self._chk(self.L.zdw_ctx_enable_timing(self.h, 1 if on else 0))
+
+    def stage_times(self):
+        t = StageTimes()
+        self._chk(self.L.zdw_ctx_stage_times(self.h, C.byref(t)))
+        return {STAGE_NAMES[i]: (t.ms[i], t.launches[i]) for i in range(len(STAGE_NAMES))}
+
+    def set_input_host(self, data):
+        """bytes / bytearray / C-contiguous uint8 numpy array"""
+        if isinstance(data, (bytes, bytearray)):
+            buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else None
+            self._keep = buf
+            self._chk(self.L.zdw_set_input_host(self.h, C.cast(buf, C.c_void_p) if buf is not None else None, len(data)))
+        else:
+            self._keep = data
+            self._chk(self.L.zdw_set_input_host(self.h, C.c_void_p(data.ctypes.data), data.size))
+
+    def set_input_device(self, ptr, nbytes, keepalive=None):
+        self._keep = keepalive
+        self._chk(self.L.zdw_set_input_device(self.h, C.c_void_p(ptr), nbytes))
+
+    def pass1(self, max_rows=None, partial_fields=0):
+        res = Pass1Result()
+        hint = None
+        if max_rows is not None:
+            hint = C.byref(SplitHint(max_rows, partial_fields))
+        rc = self.L.zdw_block_pass1(self.h, hint, C.byref(res))
+        return rc, res
+
+    def dict_section(self):
+        p, n, w = C.c_void_p(), C.c_uint64(), C.c_uint8()
+        self._chk(self.L.zdw_block_dict(self.h, C.byref(p), C.byref(n), C.byref(w)))
+        return C.string_at(p, n.value), w.value
+
+    def dict_section_device(self):
+        p, n, w = C.c_void_p(), C.c_uint64(), C.c_uint8()
+        self._chk(self.L.zdw_block_dict_device(self.h, C.byref(p), C.byref(n), C.byref(w)))
+        return p.value, n.value, w.value
+
+    def stats(self):
+        cs = (C.c_uint8 * max(1, self.ncols))()
+        cb = (C.c_uint64 * max(1, self.ncols))()
+        used = C.c_uint32()
+        self._chk(self.L.zdw_block_stats(self.h, cs, cb, C.byref(used)))
+        return bytes(cs)[:self.ncols], list(cb)[:used.value]
+
+    def pass2(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.L.zdw_block_pass2(self.h, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def pass2_device(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.L.zdw_block_pass2_device(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def next_block(self):
+        self._chk(self.L.zdw_block_next(self.h))
+
+    def encode_block(self, max_rows=None, partial_fields=0):
+        """pass 1 .. pass 2 for the next block; returns (rc, Block or None, Pass1Result)."""
+        rc, p1 = self.pass1(max_rows, partial_fields)
+        if rc or p1.num_rows == 0:
+            return rc, None, p1
+        sec, _ = self.dict_section()
+        cs, cb = self.stats()
+        rows = self.pass2()
+        return 0, Block(p1.num_rows, p1.longest_line, bool(p1.is_last_block), sec, cs, cb, rows, p1), p1
+
+    # ---- shard exchange (multi-GPU) ----
+    def export_ranges(self):
+        n = max(1, self.ncols)
+        mn, mx, seen = (C.c_uint64 * n)(), (C.c_uint64 * n)(), (C.c_uint8 * n)()
+        self._chk(self.L.zdw_shard_export_ranges(self.h, mn, mx, seen))
+        return list(mn)[:self.ncols], list(mx)[:self.ncols], list(seen)[:self.ncols]
+
+    def import_ranges(self, mn, mx, seen):
+        n = max(1, self.ncols)
+        self._chk(self.L.zdw_shard_import_ranges(self.h, (C.c_uint64 * n)(*mn), (C.c_uint64 * n)(*mx), (C.c_uint8 * n)(*seen)))
+
+    def export_uniques(self):
+        lens, byts, cnt, nb = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.zdw_shard_export_uniques(self.h, C.byref(lens), C.byref(byts), C.byref(cnt), C.byref(nb)))
+        return lens.value, byts.value, cnt.value, nb.value
+
+    def import_uniques(self, d_lens, d_bytes, count, nbytes):
+        self._chk(self.L.zdw_shard_import_uniques(self.h, C.c_void_p(d_lens), C.c_void_p(d_bytes), count, nbytes))
+
+    def last_row(self):
+        out = (C.c_uint64 * max(1, self.ncols))()
+        self._chk(self.L.zdw_shard_last_row(self.h, out))
+        return list(out)[:self.ncols]
+
+    def set_prev_row(self, stored):
+        if stored is None:
+            self._chk(self.L.zdw_shard_set_prev_row(self.h, None))
+        else:
+            self._chk(self.L.zdw_shard_set_prev_row(self.h, (C.c_uint64 * max(1, self.ncols))(*stored)))

@@ -1,0 +1,469 @@
+// ConvertToZDW.cpp — host shim of the MI355X encoder: the reference's file-level behaviour
+// (cplusplus/ConvertToZDW.cpp) around GPU block encoding through include/zdw_hip.h.
+//
+// What stays here, with its reference anchor:
+//   schema parsing ............. ReadDescFile        ConvertToZDW.cpp:91-162
+//   metadata sidecar / checks .. loadMetadataFile    :240-262, validateMetadata :226-237
+//   file header ................ processFile         :673-737
+//   block header ............... processFile         :839-842
+//   compressor child, temp name, rename ............ :647-671, :926-944
+//   validation shell-out ....... validate            :166-223
+// What moved to the GPU: parseInput, Dictionary, writeLookupColumnStats' inputs, writeBlockRows.
+#include "ConvertToZDW.h"
+
+#include "zdw_hip.h"
+
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <strings.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+namespace adobe {
+namespace zdw {
+
+void defaultStatusOutputCallback(const StatusOutputLevel level, const char *format, ...)
+{
+    FILE *to = level == ERROR ? stderr : stdout;
+    va_list ap;
+    va_start(ap, format);
+    vfprintf(to, format, ap);
+    va_end(ap);
+    fflush(to);
+}
+
+void stdErrStatusOutputCallback(const StatusOutputLevel, const char *format, ...)
+{
+    va_list ap;
+    va_start(ap, format);
+    vfprintf(stderr, format, ap);
+    va_end(ap);
+    fflush(stderr);
+}
+
+const int ConvertToZDW::CONVERT_ZDW_CURRENT_VERSION = 11;
+const char ConvertToZDW::CONVERT_ZDW_VERSION_TAIL[3] = "b";
+
+const char ConvertToZDW::ERR_CODE_TEXTS[ERR_CODE_COUNT][30] = {
+    "OK", "NO_ARGS", "CONVERSION_FAILED", "UNTAR_FAILED", "MISSING_DESC_FILE", "MISSING_SQL_FILE",
+    "FILE_CREATION_ERR", "OUT_OF_MEMORY", "UNCONVERT_FAILED", "FILE_SIZES_DIFFER",
+    "FILES_DIFFER", "MISSING_ARGUMENT", "GZIP_FAILED", "BZIP2_FAILED",
+    "DESC_FILE_MISSING_TYPE_INFO", "WRONG_NUM_OF_COLUMNS_ON_A_ROW",
+    "BAD_PARAMETER", "TOO_MANY_INPUT_FILES", "NO_INPUT_FILES", "CANT_OPEN_TEMP_FILE",
+    "Unknown error",
+    "BAD_METADATA_PARAMETER", "BAD_METADATA_FILE"};
+
+ConvertToZDW::ConvertToZDW(const bool quiet, const bool streaming)
+    : compressor(GZIP), statusOutput(defaultStatusOutputCallback), bQuiet(quiet), bTrimTrailingSpaces(false),
+      bStreamingInput(streaming), device(-1)
+{
+}
+
+ConvertToZDW::~ConvertToZDW() {}
+
+void ConvertToZDW::setBlockSplits(const std::vector<uint32_t> &rows, const std::vector<uint32_t> &fields)
+{
+    splitRows = rows;
+    splitFields = fields;
+    splitFields.resize(splitRows.size(), 0);
+}
+
+const char *ConvertToZDW::compressorExtension() const
+{
+    switch (compressor) {
+    case GZIP: return ".gz";
+    case BZIP2: return ".bz2";
+    case XZ: case FXZ: return ".xz";
+    case ZSTD: return ".zst";
+    }
+    return "";
+}
+
+const char *ConvertToZDW::compressorCommand() const
+{
+    switch (compressor) {
+    case GZIP: return "gzip";
+    case BZIP2: return "bzip2";
+    case XZ: return "xz";
+    case FXZ: return "fxz";
+    case ZSTD: return "zstd";
+    }
+    return "";
+}
+
+static bool startsWith(const char *s, const char *prefix) { return strncmp(s, prefix, strlen(prefix)) == 0; }
+
+// One schema line is "<name>\t<sql type ...>"; lines are consumed in 1023-byte pieces like the
+// reference's fgets buffer, so over-long lines split the same way.
+unsigned ConvertToZDW::readDescFile(FILE *f, Schema &s) const
+{
+    enum : unsigned char { VARCHAR = 0, TEXT = 1, DATETIME = 2, CHAR_2 = 3, CHAR = 6, TINY = 7, SHORT = 8, LONG = 9, LONGLONG = 10,
+                           DECIMAL = 11, TINY_SIGNED = 12, SHORT_SIGNED = 13, LONG_SIGNED = 14, LONGLONG_SIGNED = 15,
+                           TINYTEXT = 16, MEDIUMTEXT = 17, LONGTEXT = 18 };
+    s.names.clear(); s.types.clear(); s.charSizes.clear();
+    char line[1024];
+    while (fgets(line, sizeof line, f)) {
+        if (strncasecmp(line, "Field", 5) == 0) continue;
+        char *type = strchr(line, '\t');
+        if (!type) return BAD_FIELD;
+        *type++ = '\0';
+        s.names.push_back(line);
+        int charSize = 0;
+        unsigned char id;
+        if (startsWith(type, "varchar")) { id = VARCHAR; charSize = atoi(type + 8); }
+        else if (startsWith(type, "char")) {
+            charSize = atoi(type + 5);
+            id = charSize == 1 ? CHAR : charSize == 2 ? CHAR_2 : VARCHAR;
+        }
+        else if (startsWith(type, "text")) id = TEXT;
+        else if (startsWith(type, "tinytext")) id = TINYTEXT;
+        else if (startsWith(type, "mediumtext")) id = MEDIUMTEXT;
+        else if (startsWith(type, "longtext")) id = LONGTEXT;
+        else if (startsWith(type, "datetime")) id = DATETIME;
+        else if (startsWith(type, "decimal") || (type[0] && startsWith(type + 1, "decimal"))) id = DECIMAL;
+        else {
+            const bool isSigned = strstr(type, "unsigned") == NULL;
+            if (startsWith(type, "tinyint")) id = isSigned ? TINY_SIGNED : TINY;
+            else if (startsWith(type, "smallint")) id = isSigned ? SHORT_SIGNED : SHORT;
+            else if (startsWith(type, "bigint")) id = isSigned ? LONGLONG_SIGNED : LONGLONG;
+            else id = isSigned ? LONG_SIGNED : LONG;
+        }
+        s.types.push_back(id);
+        s.charSizes.push_back(charSize);
+    }
+    return static_cast<unsigned>(s.names.size());
+}
+
+bool ConvertToZDW::validateMetadata(const std::map<std::string, std::string> &metadata) const
+{
+    for (const auto &kv : metadata) {
+        if (kv.first.find_first_of("=\n") != std::string::npos) return false;
+        if (kv.second.find('\n') != std::string::npos) return false;
+    }
+    return true;
+}
+
+int ConvertToZDW::loadMetadataFile(const char *filepath, std::map<std::string, std::string> &metadata)
+{
+    std::ifstream in(filepath);
+    if (!in) return -1;
+    std::string line;
+    int lineNo = 0;
+    while (std::getline(in, line)) {
+        ++lineNo;
+        if (line.empty()) continue;
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) return lineNo;
+        metadata[line.substr(0, eq)] = line.substr(eq + 1);
+    }
+    return 0;
+}
+
+ConvertToZDW::ERR_CODE ConvertToZDW::validate(const char *zdwFile, const std::vector<std::string> &srcFiles, const char *exeName,
+                                              const char *outputDir)
+{
+    if (!bQuiet) statusOutput(INFO, "Unconverting %s back for validation...\n", zdwFile);
+    // the decoder is expected next to this executable, as in the reference
+    std::string dir(exeName);
+    const size_t slash = dir.rfind('/');
+    dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+    std::string unconvert = dir + "unconvertDWfile -q - ";
+    if (outputDir) { unconvert += "-d "; unconvert += outputDir; unconvert += " "; }
+    unconvert += zdwFile;
+    std::string cmd;
+    if (bStreamingInput) {
+        std::string zcat = "zcat ";
+        for (const std::string &f : srcFiles) { zcat += f; zcat += " "; }
+        cmd = "/bin/bash -c \"cmp <(" + unconvert + ") <(" + zcat + ")\"";
+    } else if (bTrimTrailingSpaces) {
+        cmd = "/bin/bash -c \"cmp <(" + unconvert + ") <(" + dir + "trim_spaces " + srcFiles[0] + ")\"";
+    } else {
+        cmd = unconvert + " | cmp " + srcFiles[0];
+    }
+    if (!bQuiet) statusOutput(INFO, "VALIDATION COMMAND: %s\n", cmd.c_str());
+    return system(cmd.c_str()) == 0 ? OK : FILES_DIFFER;
+}
+
+namespace {
+
+struct OutPipe {
+    FILE *f = nullptr;
+    bool put(const void *p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; }
+    bool le(uint64_t v, unsigned bytes)
+    {
+        unsigned char b[8];
+        for (unsigned i = 0; i < 8; ++i) b[i] = static_cast<unsigned char>(v >> (8 * i));
+        return put(b, bytes);
+    }
+};
+
+struct CtxGuard {
+    zdw_ctx *ctx = nullptr;
+    ~CtxGuard() { if (ctx) zdw_ctx_destroy(ctx); }
+};
+
+}  // namespace
+
+ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char> *hostImage, const char *mappedImage, uint64_t imageLen,
+                                                 const Schema &schema, const char *filestub, bool bValidate, const char *exeName,
+                                                 const char *outputDir, const char *zArgs,
+                                                 const std::map<std::string, std::string> &metadata)
+{
+    if (!validateMetadata(metadata)) {
+        statusOutput(ERROR, "Invalid metadata parameter\n");
+        return BAD_METADATA_PARAM;
+    }
+    const size_t numColumns = schema.names.size();
+
+    // ---- output names: <dir>/<base>.zdw<ext>, written as <base>.creating.zdw<ext> first ----
+    std::string base;
+    if (!outputDir) base = filestub;
+    else {
+        const char *leaf = strrchr(filestub, '/');
+        base = std::string(outputDir) + "/" + (leaf ? leaf + 1 : filestub);
+    }
+    const std::string finalName = base + ".zdw" + compressorExtension();
+    const std::string tempName = base + ".creating.zdw" + compressorExtension();
+
+    // ---- GPU context first: nothing is created on disk when no device is usable ----
+    CtxGuard guard;
+    {
+        zdw_opts opts;
+        memset(&opts, 0, sizeof opts);
+        opts.struct_size = sizeof opts;
+        opts.device = device;
+        opts.trim_trailing_spaces = bTrimTrailingSpaces ? 1u : 0u;
+        if (const char *e = getenv("ZDW_DICT_SLOTS")) opts.dict_slots = strtoull(e, NULL, 10);
+        const int rc = zdw_ctx_create(schema.types.data(), static_cast<uint32_t>(numColumns), &opts, &guard.ctx);
+        if (rc != ZDW_OK) {
+            libError = zdw_last_error(NULL);
+            statusOutput(ERROR, "GPU encoder unavailable: %s\n", libError.c_str());
+            return static_cast<ERR_CODE>(rc);
+        }
+    }
+    zdw_ctx *ctx = guard.ctx;
+    const unsigned char *image = hostImage ? hostImage->data() : reinterpret_cast<const unsigned char *>(mappedImage);
+    {
+        const int rc = zdw_set_input_host(ctx, image, imageLen);
+        if (rc != ZDW_OK) {
+            libError = zdw_last_error(ctx);
+            statusOutput(ERROR, "%s\n", libError.c_str());
+            return static_cast<ERR_CODE>(rc);
+        }
+    }
+
+    std::string cmd = compressorCommand();
+    if (zArgs) { cmd += " "; cmd += zArgs; }
+    cmd += " > ";
+    cmd += tempName;
+    OutPipe out;
+    out.f = popen(cmd.c_str(), "w");
+    if (!out.f) {
+        statusOutput(ERROR, "Could not open the process '%s' for writing!\n", cmd.c_str());
+        return FILE_CREATION_ERR;
+    }
+
+    // ---- file header ----
+    bool ok = out.le(CONVERT_ZDW_CURRENT_VERSION, 2);
+    {
+        uint64_t metaLen = 0;
+        for (const auto &kv : metadata) metaLen += kv.first.size() + kv.second.size() + 2;
+        ok = ok && out.le(metaLen, 4);
+        for (const auto &kv : metadata)
+            ok = ok && out.put(kv.first.c_str(), kv.first.size() + 1) && out.put(kv.second.c_str(), kv.second.size() + 1);
+    }
+    for (size_t c = 0; c < numColumns; ++c) ok = ok && out.put(schema.names[c].c_str(), schema.names[c].size() + 1);
+    ok = ok && out.le(0, 1);
+    ok = ok && out.put(schema.types.data(), numColumns);
+    for (size_t c = 0; c < numColumns; ++c) ok = ok && out.le(static_cast<uint16_t>(schema.charSizes[c]), 2);
+
+    // ---- blocks ----
+    ERR_CODE res = OK;
+    uint32_t totalRows = 0;
+    int blocks = 0;
+    bool more = true;
+    std::vector<unsigned char> colSize(numColumns ? numColumns : 1);
+    std::vector<uint64_t> colBase(numColumns ? numColumns : 1);
+    while (more && res == OK) {
+        ++blocks;
+        if (!bQuiet) {
+            if (blocks == 1) statusOutput(INFO, "\nProcessing %s\n", filestub);
+            else statusOutput(INFO, "\nProcessing block %d of %s (%llu rows so far)\n", blocks, filestub, (unsigned long long)totalRows);
+            statusOutput(INFO, "Compiling unique values\n");
+        }
+        zdw_split_hint hint = {0xFFFFFFFFu, 0};
+        const bool forced = static_cast<size_t>(blocks - 1) < splitRows.size();
+        if (forced) { hint.max_rows = splitRows[blocks - 1]; hint.partial_fields = splitFields[blocks - 1]; }
+        zdw_pass1_result p1;
+        int rc = zdw_block_pass1(ctx, forced ? &hint : NULL, &p1);
+        if (rc == ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW) {
+            statusOutput(ERROR, "\nRow %u had the problem\n", p1.bad_row);
+            res = WRONG_NUM_OF_COLUMNS_ON_A_ROW;
+            break;
+        }
+        if (rc != ZDW_OK) {
+            libError = zdw_last_error(ctx);
+            if (rc == ZDW_OUT_OF_MEMORY && p1.num_rows == 0) statusOutput(ERROR, "Not enough memory to run %s\n", exeName);
+            else statusOutput(ERROR, "%s\n", libError.c_str());
+            res = static_cast<ERR_CODE>(rc);
+            break;
+        }
+        if (!bQuiet) statusOutput(INFO, "\r%u rows\n", p1.num_rows);
+        if (p1.num_rows == 0) {
+            // nothing (more) to encode; for a first block this is the empty-file case: header only
+            if (blocks == 1) statusOutput(ERROR, "Empty data file -- nothing to process\n");
+            break;
+        }
+        ok = ok && out.le(p1.num_rows, 4) && out.le(p1.longest_line, 4) && out.le(p1.is_last_block ? 1 : 0, 1);
+
+        const uint8_t *section = NULL; uint64_t sectionLen = 0; uint8_t indexSize = 0;
+        rc = zdw_block_dict(ctx, &section, &sectionLen, &indexSize);
+        if (rc == ZDW_OK) {
+            if (!bQuiet) {
+                const uint64_t dictSize = indexSize ? sectionLen - 1 - indexSize : 1;
+                statusOutput(INFO, "\nWriting dictionary:\n%u bytes being stored for %u unique entries.  Generating %d-byte offsets...\n",
+                             static_cast<unsigned>(dictSize), static_cast<unsigned>(p1.dict_entries), indexSize ? indexSize : 1);
+            }
+            ok = ok && out.put(section, sectionLen);
+            uint32_t used = 0;
+            rc = zdw_block_stats(ctx, colSize.data(), colBase.data(), &used);
+            if (rc == ZDW_OK) {
+                ok = ok && out.put(colSize.data(), numColumns);
+                for (uint32_t u = 0; u < used; ++u) ok = ok && out.le(colBase[u], 8);
+                if (!bQuiet) statusOutput(INFO, "\nWriting rows\n");
+                const uint8_t *rowBytes = NULL; uint64_t rowLen = 0;
+                rc = zdw_block_pass2(ctx, &rowBytes, &rowLen);
+                if (rc == ZDW_OK) ok = ok && out.put(rowBytes, rowLen);
+            }
+        }
+        if (rc != ZDW_OK) {
+            libError = zdw_last_error(ctx);
+            statusOutput(ERROR, "%s\n", libError.c_str());
+            res = static_cast<ERR_CODE>(rc);
+            break;
+        }
+        totalRows += p1.num_rows;
+        if (!bQuiet) statusOutput(INFO, "\r%u\nDone with block %d -- cleaning up...\n", p1.num_rows, blocks);
+        more = !p1.is_last_block;
+        zdw_block_next(ctx);
+    }
+
+    const int childStatus = pclose(out.f);
+    out.f = NULL;
+    if (res == OK && (!ok || childStatus != 0)) {
+        statusOutput(ERROR, "Writing through '%s' failed\n", cmd.c_str());
+        res = FILE_CREATION_ERR;
+    }
+
+    // ---- optional validation against the source text (needs the reference's unconvertDWfile beside us) ----
+    if (res == OK && bValidate) {
+        std::vector<std::string> src;
+        std::string tmpGz;
+        if (bStreamingInput) {
+            tmpGz = base + ".tmp.1.gz";
+            FILE *gz = popen(("gzip > " + tmpGz).c_str(), "w");
+            if (!gz) res = CANT_OPEN_TEMP_FILE;
+            else {
+                if (imageLen && fwrite(image, 1, imageLen, gz) != imageLen) res = CANT_OPEN_TEMP_FILE;
+                pclose(gz);
+                src.push_back(tmpGz);
+            }
+        } else {
+            src.push_back(std::string(filestub) + "." + getInputFileExtension());
+        }
+        if (res == OK) {
+            const ERR_CODE v = validate(tempName.c_str(), src, exeName, outputDir);
+            if (v == OK) { if (!bQuiet) statusOutput(INFO, "%s GOOD\n", finalName.c_str()); }
+            else { statusOutput(INFO, "%s BAD\n", finalName.c_str()); res = v; }
+        }
+        if (!tmpGz.empty()) unlink(tmpGz.c_str());
+    }
+
+    if (res == OK) {
+        if (!bQuiet) statusOutput(INFO, "Rows=%u\n", totalRows);    // parsed by callers of the reference CLI
+        if (rename(tempName.c_str(), finalName.c_str()) == 0) {
+            if (!bQuiet) statusOutput(INFO, "Done\n");
+        } else {
+            res = FILE_CREATION_ERR;
+            statusOutput(INFO, "Final create file failed -- you can use %s instead.\n", tempName.c_str());
+        }
+    } else {
+        unlink(tempName.c_str());
+    }
+    return res;
+}
+
+ConvertToZDW::ERR_CODE ConvertToZDW::convertFile(const char *infile, const char *exeName, const bool bValidate, char *filestub,
+                                                 const char *outputDir, const char *zArgs,
+                                                 const std::map<std::string, std::string> &metadata)
+{
+    // the stub is the input path cut at the first ".sql" 
+    strcpy(filestub, infile);
+    char *ext = strstr(filestub, ".sql");
+    if (!ext) return MISSING_SQL_FILE;
+    *ext = '\0';
+
+    Schema schema;
+    {
+        const std::string descName = std::string(filestub) + ".desc." + getInputFileExtension();
+        FILE *desc = fopen(descName.c_str(), "r");
+        if (!desc) return MISSING_DESC_FILE;
+        const unsigned n = readDescFile(desc, schema);
+        fclose(desc);
+        if (n == BAD_FIELD) return DESC_FILE_MISSING_TYPE_INFO;
+    }
+
+    std::map<std::string, std::string> meta = metadata;
+    if (meta.empty()) {
+        const std::string sidecar = std::string(filestub) + ".metadata";
+        if (loadMetadataFile(sidecar.c_str(), meta) > 0) return BAD_METADATA_FILE;   // a missing sidecar is fine
+    }
+
+    if (const char *e = getenv("ZDW_SPLIT_ROWS")) {   // parity runs: force the block boundaries a reference run took
+        std::vector<uint32_t> rows, fields;
+        std::stringstream rs(e);
+        std::string tok;
+        while (std::getline(rs, tok, ',')) if (!tok.empty()) rows.push_back(static_cast<uint32_t>(strtoul(tok.c_str(), NULL, 10)));
+        if (const char *f = getenv("ZDW_SPLIT_FIELDS")) {
+            std::stringstream fs(f);
+            while (std::getline(fs, tok, ',')) if (!tok.empty()) fields.push_back(static_cast<uint32_t>(strtoul(tok.c_str(), NULL, 10)));
+        }
+        setBlockSplits(rows, fields);
+    }
+
+    try {
+        if (bStreamingInput) {
+            std::vector<unsigned char> image;
+            unsigned char buf[1 << 16];
+            size_t got;
+            while ((got = fread(buf, 1, sizeof buf, stdin)) > 0) image.insert(image.end(), buf, buf + got);
+            return processFile(&image, NULL, image.size(), schema, filestub, bValidate, exeName, outputDir, zArgs, meta);
+        }
+        const std::string sqlName = std::string(filestub) + "." + getInputFileExtension();
+        const int fd = open(sqlName.c_str(), O_RDONLY);
+        if (fd < 0) return MISSING_SQL_FILE;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); return MISSING_SQL_FILE; }
+        const uint64_t len = static_cast<uint64_t>(st.st_size);
+        const char *map = NULL;
+        if (len) {
+            void *m = mmap(NULL, len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); return MISSING_SQL_FILE; }
+            map = static_cast<const char *>(m);
+        }
+        const ERR_CODE r = processFile(NULL, map, len, schema, filestub, bValidate, exeName, outputDir, zArgs, meta);
+        if (map) munmap(const_cast<char *>(map), len);
+        close(fd);
+        return r;
+    } catch (const std::bad_alloc &) {
+        return OUT_OF_MEMORY;
+    }
+}
+
+}  // namespace zdw
+}  // namespace adobe

@@ -1,0 +1,95 @@
+// ConvertToZDW.h — host shim with the public face of the reference encoder class
+// (adobe::zdw::ConvertToZDW, cplusplus/ConvertToZDW.h:28-103) on top of libzdw_hip.so.
+//
+// Same constructor, convertFile() signature, ERR_CODE values, `compressor` member,
+// trimTrailingSpaces(), setStatusOutputCallback(), loadMetadataFile() and
+// getInputFileExtension(), so that code written against the reference class compiles
+// against this one.  Everything block-related happens on the GPU through include/zdw_hip.h;
+// this class keeps what the reference keeps on the host: schema parsing, file and block
+// headers, the compressor child process, temp name + rename, validation shell-out.
+#ifndef ZDW_AMD_CONVERTTOZDW_H
+#define ZDW_AMD_CONVERTTOZDW_H
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace adobe {
+namespace zdw {
+
+enum StatusOutputLevel { INFO, ERROR };   // zdw/status_output.h:22-26
+typedef void (*StatusOutputCallback)(const StatusOutputLevel, const char *, ...);
+void defaultStatusOutputCallback(const StatusOutputLevel level, const char *format, ...);   // INFO->stdout, ERROR->stderr
+void stdErrStatusOutputCallback(const StatusOutputLevel level, const char *format, ...);
+
+class ConvertToZDW {
+public:
+    static const int CONVERT_ZDW_CURRENT_VERSION;   // 11
+    static const char CONVERT_ZDW_VERSION_TAIL[3];  // "b"
+
+    enum Compressor { GZIP = 0, BZIP2 = 1, XZ = 2, FXZ = 3, ZSTD = 4 };
+
+    enum ERR_CODE {   // values are API (cplusplus/ConvertToZDW.h:44-70)
+        OK = 0, NO_ARGS = 1, CONVERSION_FAILED = 2, UNTAR_FAILED = 3, MISSING_DESC_FILE = 4, MISSING_SQL_FILE = 5,
+        FILE_CREATION_ERR = 6, OUT_OF_MEMORY = 7, UNCONVERT_FAILED = 8, FILE_SIZES_DIFFER = 9, FILES_DIFFER = 10,
+        MISSING_ARGUMENT = 11, GZIP_FAILED = 12, BZIP2_FAILED = 13, DESC_FILE_MISSING_TYPE_INFO = 14,
+        WRONG_NUM_OF_COLUMNS_ON_A_ROW = 15, BAD_PARAMETER = 16, TOO_MANY_INPUT_FILES = 17, NO_INPUT_FILES = 18,
+        CANT_OPEN_TEMP_FILE = 19, UNKNOWN_ERROR = 20, BAD_METADATA_PARAM = 21, BAD_METADATA_FILE = 22, ERR_CODE_COUNT
+    };
+    static const char ERR_CODE_TEXTS[ERR_CODE_COUNT][30];
+
+    explicit ConvertToZDW(const bool bQuiet = false, const bool bStreamingInput = false);
+    ~ConvertToZDW();
+
+    void setStatusOutputCallback(StatusOutputCallback cb) { statusOutput = cb; }
+    void trimTrailingSpaces(bool val = true) { bTrimTrailingSpaces = val; }
+    const char *getInputFileExtension() const { return "sql"; }
+
+    // Returns 0 on success, -1 when the file cannot be opened, else the number of the first bad line.
+    static int loadMetadataFile(const char *filepath, std::map<std::string, std::string> &metadata);
+
+    ERR_CODE convertFile(const char *infile, const char *exeName, const bool bValidate, char *filestub,
+                         const char *outputDir = NULL, const char *zArgs = NULL,
+                         const std::map<std::string, std::string> &metadata = std::map<std::string, std::string>());
+
+    Compressor compressor;
+
+    // ---- additions of this build (not in the reference class) ----
+    // Forced block boundaries, for byte parity with a reference run whose memory limit tripped
+    // (SURVEY.md Q9): block i holds rows[i] rows and had visited fields[i] fields of the next row.
+    void setBlockSplits(const std::vector<uint32_t> &rows, const std::vector<uint32_t> &fields);
+    void setDevice(int hipDevice) { device = hipDevice; }
+    // last GPU/library error text (empty when none)
+    const std::string &lastLibraryError() const { return libError; }
+
+private:
+    struct Schema {
+        std::vector<std::string> names;
+        std::vector<unsigned char> types;
+        std::vector<int> charSizes;
+    };
+    static const unsigned BAD_FIELD = static_cast<unsigned>(-1);
+    unsigned readDescFile(FILE *f, Schema &s) const;
+    bool validateMetadata(const std::map<std::string, std::string> &metadata) const;
+    ERR_CODE processFile(const std::vector<unsigned char> *hostImage, const char *mappedImage, uint64_t imageLen, const Schema &schema,
+                         const char *filestub, bool bValidate, const char *exeName, const char *outputDir, const char *zArgs,
+                         const std::map<std::string, std::string> &metadata);
+    ERR_CODE validate(const char *zdwFile, const std::vector<std::string> &srcFiles, const char *exeName, const char *outputDir);
+    const char *compressorExtension() const;
+    const char *compressorCommand() const;
+
+    StatusOutputCallback statusOutput;
+    const bool bQuiet;
+    bool bTrimTrailingSpaces;
+    const bool bStreamingInput;
+    int device;
+    std::vector<uint32_t> splitRows, splitFields;
+    std::string libError;
+};
+
+}  // namespace zdw
+}  // namespace adobe
+
+#endif

@@ -1,0 +1,352 @@
+// k_dict.hip — the block dictionary after pass 1: compaction of the hash table into a list of
+// unique strings, an exact string sort into strcmp order (unsigned bytes, shorter prefix first:
+// cplusplus/dictionary.h:30-35), offset assignment and the dictionary blob
+// (Dictionary::write, cplusplus/dictionary.cpp:76-111).
+//
+// The sort is an MSD-by-8-bytes refinement: round d sorts the still-tied strings by
+// (tie group, big-endian bytes [8d, 8d+8)) with a stable LSD radix sort (8-bit digits; histogram,
+// scan, wave-ballot ranked scatter), then splits groups where keys differ.  Strings leave the
+// working set as soon as they are distinguished, so the later rounds touch only long shared
+// prefixes.  All integer work; bound by HBM traffic on (key,value) pairs.
+#include "zdw_dev.h"
+#include "zdw_kernels.h"
+#include "zdw_dict_dev.h"
+
+namespace zdw {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// ------------------------------------------------------------------------------------------
+// table -> list of uniques (order is arbitrary; the sort makes it canonical)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dict_compact(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ slot_len,
+                                                       uint64_t nslots, uint64_t *__restrict__ uniq_pos,
+                                                       uint32_t *__restrict__ uniq_len, uint32_t *__restrict__ uniq_slot,
+                                                       uint32_t *count)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (nslots + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t w = i < nslots ? slots[i] : 0ull;
+        const uint64_t m = __ballot(w != 0);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == (uint32_t)lowest_bit(m)) base = atomicAdd(count, popc64(m));
+            base = bcast32(base, lowest_bit(m));
+            if (w != 0) {
+                const uint32_t k = base + mbcnt64(m);
+                uniq_pos[k] = (w & POS_MASK) - 1;
+                uniq_len[k] = slot_len[i];
+                uniq_slot[k] = (uint32_t)i;
+            }
+            // count[1] = longest string (bounds the number of sort rounds)
+            uint32_t ml = w != 0 ? slot_len[i] : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)ml, d, 64); ml = o > ml ? o : ml; }
+            if (lane == 0 && ml) atomicMax(count + 1, ml);
+        }
+    }
+}
+
+void launch_dict_compact(const uint64_t *slots, const uint32_t *slot_len, uint64_t nslots, uint64_t *uniq_pos, uint32_t *uniq_len,
+                         uint32_t *uniq_slot, uint32_t *count, hipStream_t s)
+{
+    const uint64_t blocks = (nslots + 255) / 256;
+    const uint32_t grid = blocks < 4096 ? (uint32_t)blocks : 4096u;
+    hipLaunchKernelGGL(k_dict_compact, dim3(grid), dim3(256), 0, s, slots, slot_len, nslots, uniq_pos, uniq_len, uniq_slot, count);
+}
+
+// ------------------------------------------------------------------------------------------
+// LSD radix sort of (u64 key, u32 value) pairs, 8-bit digits.  One wave per 2048-element chunk.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t SORT_CHUNK = 2048;
+
+uint32_t sort_blocks(uint64_t n) { return (uint32_t)((n + SORT_CHUNK - 1) / SORT_CHUNK); }
+
+__global__ __launch_bounds__(64) void k_radix_hist(const uint64_t *__restrict__ keys, uint32_t n, uint32_t shift,
+                                                    uint32_t *__restrict__ hist, uint32_t nblocks)
+{
+    __shared__ uint32_t h[256];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += 64) h[i] = 0;
+    __syncthreads();
+    const uint32_t beg = blockIdx.x * SORT_CHUNK;
+    const uint32_t end = beg + SORT_CHUNK < n ? beg + SORT_CHUNK : n;
+    for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    for (uint32_t d = lane; d < 256; d += 64) hist[d * nblocks + blockIdx.x] = h[d];
+}
+
+__global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                       uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                       uint32_t n, uint32_t shift, const uint32_t *__restrict__ offsets,
+                                                       uint32_t nblocks)
+{
+    __shared__ uint32_t offs[256];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t d = lane; d < 256; d += 64) offs[d] = offsets[d * nblocks + blockIdx.x];
+    __syncthreads();
+    const uint32_t beg = blockIdx.x * SORT_CHUNK;
+    const uint32_t end = beg + SORT_CHUNK < n ? beg + SORT_CHUNK : n;
+    for (uint32_t b = beg; b < end; b += 64) {
+        const uint32_t i = b + lane;
+        const bool valid = i < end;
+        const uint64_t key = valid ? keys_in[i] : 0ull;
+        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t digit = (uint32_t)(key >> shift) & 255u;
+        uint64_t mm = __ballot(valid);                 // lanes holding the same digit as this lane
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool one = (digit >> bit) & 1u;
+            const uint64_t vote = __ballot(one);
+            mm &= one ? vote : ~vote;
+        }
+        uint32_t dst = 0;
+        if (valid) dst = offs[digit] + popc64(mm & mask_lt((int)lane));
+        __syncthreads();
+        if (valid && lane == (uint32_t)highest_bit(mm)) offs[digit] += popc64(mm);
+        __syncthreads();
+        if (valid) { keys_out[dst] = key; vals_out[dst] = val; }
+    }
+}
+
+// sorts by bits [bit_lo, bit_hi) of the key; result lands in (*keys, *vals) (pointers are swapped as needed)
+static void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **keys_alt, uint32_t **vals_alt, uint32_t n,
+                             uint32_t bit_lo, uint32_t bit_hi, uint32_t *hist, void *scan_tmp, hipStream_t s)
+{
+    const uint32_t nb = sort_blocks(n);
+    for (uint32_t shift = bit_lo; shift < bit_hi; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(64), 0, s, *keys, n, shift, hist, nb);
+        // exclusive scan in place is not used: scan into the second half of the histogram buffer
+        uint32_t *offsets = hist + (size_t)256 * nb + 1;
+        launch_scan_u32_to_u32(hist, offsets, (uint64_t)256 * nb, scan_tmp, nullptr, s);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(64), 0, s, *keys, *vals, *keys_alt, *vals_alt, n, shift, offsets, nb);
+        uint64_t *tk = *keys; *keys = *keys_alt; *keys_alt = tk;
+        uint32_t *tv = *vals; *vals = *vals_alt; *vals_alt = tv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// refinement rounds
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sort_init(uint32_t *order, uint32_t *active, uint32_t *group, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { order[i] = i; active[i] = i; group[i] = 0; }
+}
+
+// keys[j] = 8 bytes at depth d of the string now at position active[j]; vals[j] = j
+__global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
+                                                    const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
+                                                    const uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
+                                                    uint32_t m, uint32_t depth, uint64_t *__restrict__ keys,
+                                                    uint32_t *__restrict__ vals)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t u = order[active[j]];
+    keys[j] = sort_key8(string_at(in, extra, uniq_pos[u]), uniq_len[u], depth);
+    vals[j] = j;
+}
+
+__global__ __launch_bounds__(256) void k_sort_group_keys(const uint32_t *__restrict__ group, const uint32_t *__restrict__ vals,
+                                                          uint32_t m, uint64_t *__restrict__ keys)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) keys[j] = group[vals[j]];
+}
+
+// tmp[j] = the unique that belongs at the j-th tied position after this round
+__global__ __launch_bounds__(256) void k_sort_gather(const uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
+                                                      const uint32_t *__restrict__ vals, uint32_t m, uint32_t *__restrict__ tmp)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) tmp[j] = order[active[vals[j]]];
+}
+
+// writes the round's result back and flags what is still tied:
+//   head[j]   = 1 when position j starts a run of two or more equal (group, key)
+//   still[j]  = 1 when position j is tied with a neighbour (needs another round)
+__global__ __launch_bounds__(256) void k_sort_ties(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
+                                                    const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
+                                                    uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
+                                                    const uint32_t *__restrict__ group, const uint32_t *__restrict__ tmp,
+                                                    uint32_t m, uint32_t depth, uint32_t *__restrict__ head,
+                                                    uint32_t *__restrict__ still)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t u = tmp[j];
+    order[active[j]] = u;
+    const uint64_t k = sort_key8(string_at(in, extra, uniq_pos[u]), uniq_len[u], depth);
+    bool tie_prev = false, tie_next = false;
+    if (j > 0 && group[j - 1] == group[j]) {
+        const uint32_t v = tmp[j - 1];
+        tie_prev = sort_key8(string_at(in, extra, uniq_pos[v]), uniq_len[v], depth) == k;
+    }
+    if (j + 1 < m && group[j + 1] == group[j]) {
+        const uint32_t v = tmp[j + 1];
+        tie_next = sort_key8(string_at(in, extra, uniq_pos[v]), uniq_len[v], depth) == k;
+    }
+    // run labels must stay dense (1..#runs) because the next round radix-sorts them on as few bits
+    // as the number of still-tied strings needs: count a head only for runs that stay in the working set
+    head[j] = (!tie_prev && tie_next) ? 1u : 0u;
+    still[j] = (tie_prev || tie_next) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_sort_compact(const uint32_t *__restrict__ active, const uint32_t *__restrict__ head,
+                                                       const uint32_t *__restrict__ still, const uint32_t *__restrict__ head_scan,
+                                                       const uint32_t *__restrict__ still_scan, uint32_t m,
+                                                       uint32_t *__restrict__ active_out, uint32_t *__restrict__ group_out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m || !still[j]) return;
+    const uint32_t k = still_scan[j];
+    active_out[k] = active[j];
+    group_out[k] = head_scan[j] + head[j];      // run label: grows with position, equal inside a run
+}
+
+// Sort n unique strings.  Buffers: see SortBuffers.  Returns 0 or a hipError_t.
+int dict_sort(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n64,
+              SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len)
+{
+    const uint32_t n = (uint32_t)n64;
+    uint32_t rounds = 0;
+    if (n == 0) { if (rounds_out) *rounds_out = 0; return 0; }
+    const uint32_t nb256 = (n + 255) / 256;
+    hipLaunchKernelGGL(k_sort_init, dim3(nb256), dim3(256), 0, s, b.order, b.active_a, b.group, n);
+    uint32_t *active = b.active_a, *active_alt = b.active_b;
+    // group labels per active index live in val-sized scratch: group (current) and flags-derived next
+    uint32_t *group = b.group;
+    uint32_t m = n;
+    // scratch carved from flags: head[m], still[m], head_scan[m+1], still_scan[m+1], tmp[m], group_next[m]
+    uint32_t *head = b.flags;
+    uint32_t *still = head + n;
+    uint32_t *head_scan = still + n;
+    uint32_t *still_scan = head_scan + n + 1;
+    uint32_t *tmp = still_scan + n + 1;
+    uint32_t *group_next = tmp + n;
+    for (uint32_t depth = 0; m > 1; ++depth) {
+        ++rounds;
+        const uint32_t gb = (m + 255) / 256;
+        uint64_t *keys = b.key_a, *keys_alt = b.key_b;
+        uint32_t *vals = b.val_a, *vals_alt = b.val_b;
+        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, b.order, active, m, depth, keys, vals);
+        radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, m, 0, 64, b.hist, b.scan_tmp, s);
+        if (depth > 0) {
+            // stable second key: the tie group (labels are < m + 1)
+            hipLaunchKernelGGL(k_sort_group_keys, dim3(gb), dim3(256), 0, s, group, vals, m, keys);
+            uint32_t bits = 1;
+            while (bits < 32 && (1ull << bits) <= (uint64_t)m + 1) ++bits;
+            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
+        }
+        hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, b.order, active, vals, m, tmp);
+        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, b.order, active, group, tmp, m, depth,
+                           head, still);
+        launch_scan_u32_to_u32(head, head_scan, m, b.scan_tmp, nullptr, s);
+        launch_scan_u32_to_u32(still, still_scan, m, b.scan_tmp, nullptr, s);
+        hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active, head, still, head_scan, still_scan, m, active_alt,
+                           group_next);
+        uint32_t m_next = 0;
+        HIPCHK(hipMemcpyAsync(&m_next, still_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        uint32_t *t = active; active = active_alt; active_alt = t;
+        t = group; group = group_next; group_next = t;
+        m = m_next;
+        if (depth > max_len / 8 + 2) return (int)hipErrorUnknown;   // cannot happen: two distinct strings differ within max_len bytes
+    }
+    if (rounds_out) *rounds_out = rounds;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// offsets + blob
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dict_lengths(const uint32_t *__restrict__ order, const uint32_t *__restrict__ uniq_len,
+                                                       uint32_t n, uint32_t *__restrict__ len_plus1)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) len_plus1[r] = uniq_len[order[r]] + 1;
+}
+
+void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_dict_lengths, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, order, uniq_len, (uint32_t)n, len_plus1);
+}
+
+// one string per thread: copy into the blob (offset 1 + exclusive sum of len+1), NUL terminate,
+// publish the offset for its table slot
+__global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
+                                                    const uint32_t *__restrict__ order, const uint64_t *__restrict__ uniq_pos,
+                                                    const uint32_t *__restrict__ uniq_len, const uint32_t *__restrict__ uniq_slot,
+                                                    const uint64_t *__restrict__ off_excl, uint32_t n, uint8_t *__restrict__ blob,
+                                                    uint32_t *__restrict__ slot_off)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) blob[0] = 0;                                     // origin byte (dictionary.cpp:96)
+    if (r >= n) return;
+    const uint32_t u = order[r];
+    const uint64_t off = 1 + off_excl[r];
+    const uint32_t len = uniq_len[u];
+    const uint8_t *p = string_at(in, extra, uniq_pos[u]);
+    uint8_t *q = blob + off;
+    for (uint32_t i = 0; i < len; ++i) q[i] = p[i];
+    q[len] = 0;
+    slot_off[uniq_slot[u]] = (uint32_t)off;
+}
+
+void launch_dict_emit(const uint8_t *in, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                      const uint32_t *uniq_slot, const uint64_t *off_excl, uint64_t n, uint8_t *blob, uint32_t *slot_off, hipStream_t s)
+{
+    const uint32_t grid = n ? (uint32_t)((n + 255) / 256) : 1u;
+    hipLaunchKernelGGL(k_dict_emit, dim3(grid), dim3(256), 0, s, in, extra, order, uniq_pos, uniq_len, uniq_slot, off_excl, (uint32_t)n,
+                       blob, slot_off);
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU merge: strings travel as NUL-terminated bytes + u32 lengths
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_export_strings(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
+                                                         const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
+                                                         const uint64_t *__restrict__ off_excl, uint32_t n, uint8_t *__restrict__ bytes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = string_at(in, extra, uniq_pos[i]);
+    uint8_t *q = bytes + off_excl[i];
+    const uint32_t len = uniq_len[i];
+    for (uint32_t k = 0; k < len; ++k) q[k] = p[k];
+    q[len] = 0;
+}
+
+void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                           const uint64_t *off_excl, uint64_t n, uint8_t *bytes, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_export_strings, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, off_excl,
+                       (uint32_t)n, bytes);
+}
+
+__global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, const uint8_t *extra, const uint32_t *__restrict__ lens,
+                                                         const uint64_t *__restrict__ offs, uint64_t count, uint64_t *slots,
+                                                         uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim,
+                                                         uint64_t hi, P1Status *st)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    dict_insert(in, extra, hi, slots, slot_len, slot_mask, max_entries, st, EXTRA_BASE + offs[i], lens[i], trim != 0);
+}
+
+void launch_import_strings(const uint8_t *in, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
+                           uint64_t *slots, uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim, uint64_t hi,
+                           P1Status *st, hipStream_t s)
+{
+    if (!count) return;
+    hipLaunchKernelGGL(k_import_strings, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, in, extra, lens, offs, count, slots,
+                       slot_len, slot_mask, max_entries, trim, hi, st);
+}
+
+}  // namespace zdw

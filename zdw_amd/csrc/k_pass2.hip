@@ -1,0 +1,103 @@
+// k_pass2.hip — pass 2 of the ZDW block encode on gfx950 (ConvertToZDW::writeBlockRows,
+// cplusplus/ConvertToZDW.cpp:486-606).
+//
+// Input is the fixed-width record matrix rec[row][column] that pass 1 left in HBM (u32 dictionary
+// table slot id per text field, u64 parsed value per numeric field), so this pass is pure
+// fixed-stride integer work: stored value = dictionary offset | value - base, flag = stored value
+// differs from the previous row's, row bytes = ceil(used/8) flag bytes followed by the low
+// `size` bytes of every flagged value in column order.
+//
+// A row is handled by G = min(64, pow2 >= used columns) adjacent lanes (64/G rows per wave):
+// flag bits come from one wave ballot, the byte position of each value from a G-lane prefix sum.
+// Two launches: row lengths (then an exclusive scan gives each row's output offset), then emit.
+#include "zdw_dev.h"
+#include "zdw_kernels.h"
+
+namespace zdw {
+
+__device__ __forceinline__ uint64_t stored_value(const Pass2Args &a, uint32_t row, uint32_t u)
+{
+    const uint8_t *p = a.rec + (uint64_t)row * a.rec_stride + a.used_recoff[u];
+    if (a.used_kind[u] == K_TEXT) {
+        const uint32_t id = *reinterpret_cast<const uint32_t *>(p);
+        return id ? (uint64_t)a.slot_off[id - 1] : 0ull;            // ConvertToZDW.cpp:528-531
+    }
+    const uint64_t v = *reinterpret_cast<const uint64_t *>(p);
+    return v ? v - a.used_base[u] : 0ull;                           // :543-547, :564-566
+}
+
+template <uint32_t G, bool EMIT>
+__global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
+{
+    constexpr uint32_t ROWS_PER_WAVE = 64 / G;
+    const uint32_t lane = lane_id();
+    const uint32_t sub = lane & (G - 1), grp = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t row64 = wave * ROWS_PER_WAVE + grp;
+    const bool row_ok = row64 < a.nrows;
+    const uint32_t row = (uint32_t)row64;
+    const uint32_t nflag = (a.nused + 7) >> 3;
+    const uint64_t out_row = (EMIT && row_ok) ? a.row_off[row] : 0ull;
+    uint32_t running = 0;      // value bytes of this row emitted so far (uniform inside the group)
+
+    for (uint32_t u0 = 0; u0 < a.nused; u0 += G) {
+        const uint32_t u = u0 + sub;
+        const bool ok = row_ok && u < a.nused;
+        uint64_t cur = 0, prev = 0;
+        uint32_t sz = 0;
+        if (ok) {
+            cur = stored_value(a, row, u);
+            prev = row ? stored_value(a, row - 1, u) : a.prev0[u];
+            sz = a.used_size[u];
+        }
+        const bool flag = ok && cur != prev;
+        const uint32_t mine = flag ? sz : 0u;
+        // inclusive prefix over the G lanes of the group
+        uint32_t inc = mine;
+#pragma unroll
+        for (uint32_t d = 1; d < G; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, d, G);
+            if (sub >= d) inc += t;
+        }
+        const uint32_t tot = (uint32_t)__shfl((int)inc, G - 1, G);
+        if (EMIT) {
+            const uint64_t bal = __ballot(flag);
+            uint64_t bits = bal;
+            if constexpr (G < 64) bits = (bal >> (grp * G)) & ((1ull << G) - 1ull);
+            constexpr uint32_t FB = G >= 8 ? G / 8 : 1;                  // flag bytes this chunk can produce
+            if (row_ok && sub < FB && u0 + 8 * sub < a.nused)
+                a.out[out_row + (u0 >> 3) + sub] = (uint8_t)(bits >> (8 * sub));
+            if (flag) {
+                uint8_t *q = a.out + out_row + nflag + running + (inc - mine);
+                for (uint32_t j = 0; j < sz; ++j) q[j] = (uint8_t)(cur >> (8 * j));   // little-endian truncating store
+            }
+            if (ok && a.last_stored && row == a.nrows - 1) a.last_stored[u] = cur;
+        }
+        running += tot;
+    }
+    if (!EMIT && row_ok && sub == 0) a.row_len[row] = nflag + running;
+}
+
+template <bool EMIT>
+static void launch_pass2(const Pass2Args &a, hipStream_t s)
+{
+    if (!a.nrows) return;
+    uint32_t g = 1;
+    while (g < 64 && g < a.nused) g <<= 1;
+    const uint64_t rows_per_block = (256 / 64) * (64 / g);
+    const uint32_t grid = (uint32_t)((a.nrows + rows_per_block - 1) / rows_per_block);
+    switch (g) {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<1, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<2, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<4, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+    case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<8, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<16, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<32, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<64, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+}
+
+void launch_pass2_size(const Pass2Args &a, hipStream_t s) { launch_pass2<false>(a, s); }
+void launch_pass2_emit(const Pass2Args &a, hipStream_t s) { launch_pass2<true>(a, s); }
+
+}  // namespace zdw

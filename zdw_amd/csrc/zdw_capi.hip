@@ -1,0 +1,868 @@
+// zdw_capi.hip — the C ABI of libzdw_hip.so (include/zdw_hip.h): host orchestration of the
+// gfx950 kernels for one ZDW block at a time.  Mirrors the per-block seam of
+// ConvertToZDW::processFile (cplusplus/ConvertToZDW.cpp:765-894).
+#include "../../include/zdw_hip.h"
+#include "zdw_dev.h"
+#include "zdw_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace zdw;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct HostBuf {   // pinned
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+unsigned bytes_for(uint64_t v)   // dictionary.cpp:62-73 and ConvertToZDW.cpp:458-464
+{
+    unsigned n = 1;
+    while (v >= 256) { ++n; v /= 256; }
+    return n;
+}
+
+struct TimedSpan { hipEvent_t a, b; int stage; };
+
+}  // namespace
+
+struct zdw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // schema
+    uint32_t ncols = 0, nnum = 0, rec_stride = 0;
+    std::vector<uint8_t> types, kind;
+    std::vector<uint32_t> recoff;
+    std::vector<int32_t> numidx;
+    DevBuf d_kind, d_recoff, d_numidx;
+    bool trim = false;
+    uint32_t row_cap = FIRST_ROW_CAP;      // emulated m_LongestLine, persists across blocks
+    uint64_t slots_opt = 0;
+    // input image
+    const uint8_t *d_in = nullptr;
+    uint64_t n = 0;
+    DevBuf in_owned;
+    bool have_input = false;
+    uint64_t hi = 0;                       // effective end: last row terminator + 1
+    uint64_t lo = 0;                       // start of the current block
+    uint64_t next_lo = 0;                  // start of the next block (set by pass 1)
+    // block state
+    bool p1_done = false, dict_done = false, stats_done = false, p2_done = false, is_last = true;
+    uint32_t nrows = 0;
+    uint64_t nslots = 0;
+    DevBuf span_starts, span_rowbase, scan_tmp, rec, slots, slot_len, col_min, col_max, col_seen, status, long_rows, d_scalar;
+    std::vector<uint64_t> h_min, h_max;
+    std::vector<uint8_t> h_seen;
+    // dictionary
+    DevBuf uniq_pos, uniq_len, uniq_slot, key_a, key_b, val_a, val_b, order, group, active_a, active_b, flags, hist, lenp1, off_excl,
+        slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
+    uint64_t nuniq = 0, dict_size = 0, extra_bytes = 0;
+    uint8_t index_size = 0;
+    uint64_t dict_sec_off = 0, dict_sec_len = 0;
+    uint32_t sort_rounds = 0;
+    // stats
+    std::vector<uint8_t> col_size;
+    std::vector<uint64_t> col_base;
+    std::vector<uint32_t> used;
+    // pass 2
+    DevBuf d_used_recoff, d_used_kind, d_used_size, d_used_base, d_prev0, d_last, row_len, row_off, rows_out;
+    std::vector<uint64_t> prev_row;        // per column, for a shard that does not start the block
+    bool have_prev = false;
+    uint64_t rows_len = 0;
+    HostBuf h_dict, h_rows;
+    // timing
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    zdw_stage_times times{};
+};
+
+namespace {
+
+int fail(zdw_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail((c), e_ == hipErrorOutOfMemory ? ZDW_OUT_OF_MEMORY : ZDW_UNKNOWN_ERROR, "%s: %s", #call, \
+                        hipGetErrorString(e_));                                                            \
+    } while (0)
+
+struct StageScope {
+    zdw_ctx *c; int stage; hipEvent_t a = nullptr;
+    StageScope(zdw_ctx *ctx, int st) : c(ctx), stage(st)
+    {
+        if (c->timing && hipEventCreate(&a) == hipSuccess) (void)hipEventRecord(a, c->stream);
+    }
+    ~StageScope()
+    {
+        if (!a) return;
+        hipEvent_t b = nullptr;
+        if (hipEventCreate(&b) == hipSuccess) {
+            (void)hipEventRecord(b, c->stream);
+            c->spans.push_back({a, b, stage});
+        }
+    }
+};
+
+void collect_times(zdw_ctx *c)
+{
+    for (auto &s : c->spans) {
+        float ms = 0;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            c->times.ms[s.stage] += ms;
+            c->times.launches[s.stage] += 1;
+        }
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    c->spans.clear();
+}
+
+void reset_block(zdw_ctx *c)
+{
+    c->p1_done = c->dict_done = c->stats_done = c->p2_done = false;
+    c->nrows = 0; c->nuniq = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
+    c->have_prev = false;
+}
+
+// Replays the reference's fgets() chunking on one logical row (getnextrow.cpp:26-84) to learn how
+// far the row buffer would have grown.  `terminated` = the row ends with its unescaped newline.
+void replay_row_reads(const uint8_t *row, uint64_t len, bool terminated, uint32_t *cap)
+{
+    auto chunk = [&](uint64_t from, uint64_t size) {   // bytes one fgets(.., size, ..) delivers
+        uint64_t m = 0;
+        while (m + 1 < size && from + m < len) { if (row[from + m++] == '\n') break; }
+        return m;
+    };
+    auto ends_row = [&](uint64_t l) {
+        if (row[l - 1] != '\n') return false;
+        uint64_t k = 0;
+        while (k + 2 <= l && row[l - 2 - k] == '\\') ++k;
+        return (k & 1) == 0;
+    };
+    uint64_t l = chunk(0, *cap);
+    if (l < 2) return;
+    while (!ends_row(l)) {
+        if (l == (uint64_t)*cap - 1) *cap *= 2;
+        if (l >= len) return;                        // fgets hits EOF (only for an unterminated tail)
+        l += chunk(l, (uint64_t)*cap - l);
+    }
+    (void)terminated;
+}
+
+int upload_schema(zdw_ctx *c)
+{
+    HIP_TRY(c, c->d_kind.ensure(c->ncols));
+    HIP_TRY(c, c->d_recoff.ensure(c->ncols * sizeof(uint32_t)));
+    HIP_TRY(c, c->d_numidx.ensure(c->ncols * sizeof(int32_t)));
+    if (c->ncols) {
+        HIP_TRY(c, hipMemcpy(c->d_kind.p, c->kind.data(), c->ncols, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_recoff.p, c->recoff.data(), c->ncols * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_numidx.p, c->numidx.data(), c->ncols * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return ZDW_OK;
+}
+
+int after_input(zdw_ctx *c)
+{
+    reset_block(c);
+    c->lo = c->next_lo = 0;
+    c->row_cap = c->row_cap ? c->row_cap : FIRST_ROW_CAP;
+    c->hi = 0;
+    if (c->n) {
+        HIP_TRY(c, c->d_scalar.ensure(64));
+        launch_find_effective_end(c->d_in, c->n, 0, c->d_scalar.as<uint64_t>(), c->stream);
+        HIP_TRY(c, hipMemcpyAsync(&c->hi, c->d_scalar.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_input = true;
+    return ZDW_OK;
+}
+
+// ---- dictionary: table -> sorted blob + slot offsets -----------------------------------------
+int ensure_dict(zdw_ctx *c)
+{
+    if (c->dict_done) return ZDW_OK;
+    if (!c->p1_done) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_block_pass1 has not run for this block");
+    hipStream_t s = c->stream;
+    uint32_t count = 0, max_len = 0;
+    {
+        StageScope ts(c, ZDW_STAGE_DICT_COMPACT);
+        const uint64_t cap = c->nslots;   // upper bound on uniques; the table holds at most max_entries
+        const P1Status *st = c->status.as<P1Status>();
+        uint32_t entries = 0;
+        HIP_TRY(c, hipMemcpyAsync(&entries, &st->entries, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        (void)cap;
+        const uint64_t u = entries;
+        HIP_TRY(c, c->uniq_pos.ensure((u + 1) * 8));
+        HIP_TRY(c, c->uniq_len.ensure((u + 1) * 4));
+        HIP_TRY(c, c->uniq_slot.ensure((u + 1) * 4));
+        HIP_TRY(c, hipMemsetAsync(c->d_scalar.p, 0, 64, s));
+        launch_dict_compact(c->slots.as<uint64_t>(), c->slot_len.as<uint32_t>(), c->nslots, c->uniq_pos.as<uint64_t>(),
+                            c->uniq_len.as<uint32_t>(), c->uniq_slot.as<uint32_t>(), c->d_scalar.as<uint32_t>(), s);
+        uint32_t cm[2] = {0, 0};
+        HIP_TRY(c, hipMemcpyAsync(cm, c->d_scalar.p, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        count = cm[0]; max_len = cm[1];
+        if (count != entries) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary table count mismatch (%u vs %u)", count, entries);
+    }
+    c->nuniq = count;
+    const uint64_t u = count;
+    {
+        StageScope ts(c, ZDW_STAGE_DICT_SORT);
+        const size_t nb = sort_blocks(u ? u : 1);
+        HIP_TRY(c, c->key_a.ensure((u + 1) * 8)); HIP_TRY(c, c->key_b.ensure((u + 1) * 8));
+        HIP_TRY(c, c->val_a.ensure((u + 1) * 4)); HIP_TRY(c, c->val_b.ensure((u + 1) * 4));
+        HIP_TRY(c, c->order.ensure((u + 1) * 4)); HIP_TRY(c, c->group.ensure((u + 1) * 4));
+        HIP_TRY(c, c->active_a.ensure((u + 1) * 4)); HIP_TRY(c, c->active_b.ensure((u + 1) * 4));
+        HIP_TRY(c, c->flags.ensure((6 * u + 8) * 4));
+        HIP_TRY(c, c->hist.ensure((2 * (256 * nb + 1) + 8) * 4));
+        HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(std::max<uint64_t>(256 * nb + 1, std::max<uint64_t>(u + 1, c->nrows + 1ull)))));
+        SortBuffers b{};
+        b.key_a = c->key_a.as<uint64_t>(); b.key_b = c->key_b.as<uint64_t>();
+        b.val_a = c->val_a.as<uint32_t>(); b.val_b = c->val_b.as<uint32_t>();
+        b.order = c->order.as<uint32_t>(); b.group = c->group.as<uint32_t>();
+        b.active_a = c->active_a.as<uint32_t>(); b.active_b = c->active_b.as<uint32_t>();
+        b.flags = c->flags.as<uint32_t>(); b.hist = c->hist.as<uint32_t>();
+        b.scan_tmp = c->scan_tmp.p; b.counter = c->d_scalar.as<uint32_t>();
+        const int e = dict_sort(c->d_in, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, b, s,
+                                &c->sort_rounds, max_len);
+        if (e) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary sort: %s", hipGetErrorString((hipError_t)e));
+    }
+    {
+        StageScope ts(c, ZDW_STAGE_DICT_EMIT);
+        HIP_TRY(c, c->lenp1.ensure((u + 1) * 4));
+        HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
+        launch_dict_lengths(c->order.as<uint32_t>(), c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
+        launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+        uint64_t total = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        c->dict_size = total + 1;                       // Dictionary::getSize(): origin byte included
+        if (c->dict_size >= (1ull << 32))
+            return fail(c, ZDW_OUT_OF_MEMORY, "dictionary of %llu bytes exceeds the format's 32-bit offsets; split the block",
+                        (unsigned long long)c->dict_size);
+        c->index_size = (uint8_t)bytes_for(c->dict_size);
+        HIP_TRY(c, c->dict_sec.ensure(16 + c->dict_size));
+        HIP_TRY(c, c->slot_off.ensure(c->nslots * 4));
+        uint8_t *blob = c->dict_sec.as<uint8_t>() + 8;
+        launch_dict_emit(c->d_in, c->extra.as<uint8_t>(), c->order.as<uint32_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(),
+                         c->uniq_slot.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, blob, c->slot_off.as<uint32_t>(), s);
+        if (u == 0) {                                   // empty set: a single 00 (dictionary.cpp:80-84)
+            c->dict_sec_off = 8; c->dict_sec_len = 1;
+        } else {
+            uint8_t hdr[8];
+            hdr[0] = c->index_size;
+            for (unsigned i = 0; i < c->index_size; ++i) hdr[1 + i] = (uint8_t)(c->dict_size >> (8 * i));
+            c->dict_sec_off = 8 - 1 - c->index_size;
+            c->dict_sec_len = 1 + c->index_size + c->dict_size;
+            HIP_TRY(c, hipMemcpyAsync(c->dict_sec.as<uint8_t>() + c->dict_sec_off, hdr, 1 + c->index_size, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+        }
+    }
+    c->dict_done = true;
+    return ZDW_OK;
+}
+
+// ---- column widths and bases (writeLookupColumnStats, ConvertToZDW.cpp:417-483) ----------------
+int ensure_stats(zdw_ctx *c)
+{
+    if (c->stats_done) return ZDW_OK;
+    int rc = ensure_dict(c);
+    if (rc) return rc;
+    c->col_size.assign(c->ncols, 0);
+    c->col_base.assign(c->ncols, 0);
+    c->used.clear();
+    for (uint32_t k = 0; k < c->ncols; ++k) {
+        if (c->kind[k] == K_TEXT) {
+            if (!c->h_seen[k]) continue;
+            c->col_size[k] = c->index_size; c->col_base[k] = 0;
+        } else {
+            if (c->h_max[k] == 0) continue;                       // no value > 0 seen: column unused
+            const uint64_t base = c->h_min[k] - 1;
+            c->col_base[k] = base;
+            c->col_size[k] = (uint8_t)bytes_for(c->h_max[k] - base);
+        }
+        c->used.push_back(k);
+    }
+    c->stats_done = true;
+    return ZDW_OK;
+}
+
+int run_pass2(zdw_ctx *c)
+{
+    if (c->p2_done) return ZDW_OK;
+    int rc = ensure_stats(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const uint32_t nu = (uint32_t)c->used.size();
+    c->rows_len = 0;
+    if (nu == 0 || c->nrows == 0) { c->p2_done = true; HIP_TRY(c, c->rows_out.ensure(16)); return ZDW_OK; }
+    std::vector<uint32_t> uo(nu); std::vector<uint8_t> uk(nu), us(nu); std::vector<uint64_t> ub(nu), up(nu, 0);
+    for (uint32_t u = 0; u < nu; ++u) {
+        const uint32_t k = c->used[u];
+        uo[u] = c->recoff[k]; uk[u] = c->kind[k]; us[u] = c->col_size[k]; ub[u] = c->col_base[k];
+        if (c->have_prev) up[u] = c->prev_row[k];
+    }
+    HIP_TRY(c, c->d_used_recoff.ensure(nu * 4)); HIP_TRY(c, c->d_used_kind.ensure(nu)); HIP_TRY(c, c->d_used_size.ensure(nu));
+    HIP_TRY(c, c->d_used_base.ensure(nu * 8)); HIP_TRY(c, c->d_prev0.ensure(nu * 8)); HIP_TRY(c, c->d_last.ensure(nu * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->d_used_recoff.p, uo.data(), nu * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_used_kind.p, uk.data(), nu, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_used_size.p, us.data(), nu, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_used_base.p, ub.data(), nu * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->d_prev0.p, up.data(), nu * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));      // the host vectors above go out of scope
+    HIP_TRY(c, c->row_len.ensure((c->nrows + 1ull) * 4));
+    HIP_TRY(c, c->row_off.ensure((c->nrows + 2ull) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(c->nrows + 1ull)));
+    Pass2Args a{};
+    a.rec = c->rec.as<uint8_t>(); a.rec_stride = c->rec_stride; a.nrows = c->nrows; a.nused = nu;
+    a.used_recoff = c->d_used_recoff.as<uint32_t>(); a.used_kind = c->d_used_kind.as<uint8_t>();
+    a.used_size = c->d_used_size.as<uint8_t>(); a.used_base = c->d_used_base.as<uint64_t>();
+    a.slot_off = c->slot_off.as<uint32_t>(); a.prev0 = c->d_prev0.as<uint64_t>();
+    a.row_len = c->row_len.as<uint32_t>(); a.row_off = c->row_off.as<uint64_t>(); a.out = nullptr;
+    a.last_stored = c->d_last.as<uint64_t>();
+    {
+        StageScope ts(c, ZDW_STAGE_PASS2_SIZE);
+        launch_pass2_size(a, s);
+        launch_scan_u32_to_u64(a.row_len, c->row_off.as<uint64_t>(), c->nrows, c->scan_tmp.p, nullptr, s);
+    }
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->row_off.as<uint64_t>() + c->nrows, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, c->rows_out.ensure(total + 16));
+    a.out = c->rows_out.as<uint8_t>();
+    {
+        StageScope ts(c, ZDW_STAGE_PASS2_EMIT);
+        launch_pass2_emit(a, s);
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->rows_len = total;
+    c->p2_done = true;
+    return ZDW_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+uint32_t zdw_abi_version(void) { return ZDW_ABI_VERSION; }
+
+const char *zdw_last_error(const zdw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int zdw_ctx_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opts, zdw_ctx **out)
+{
+    if (!out) return fail(nullptr, ZDW_UNKNOWN_ERROR, "zdw_ctx_create: out is NULL");
+    *out = nullptr;
+    if (ncols && !col_types) return fail(nullptr, ZDW_UNKNOWN_ERROR, "zdw_ctx_create: col_types is NULL");
+    if (ncols >= COL_SKIP) return fail(nullptr, ZDW_UNKNOWN_ERROR, "zdw_ctx_create: too many columns (%u)", ncols);
+    zdw_ctx *c = new (std::nothrow) zdw_ctx();
+    if (!c) return fail(nullptr, ZDW_OUT_OF_MEMORY, "zdw_ctx_create: out of host memory");
+    int dev = opts ? opts->device : -1;
+    hipError_t e = hipSuccess;
+    if (dev < 0) e = hipGetDevice(&dev); else e = hipSetDevice(dev);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, ZDW_UNKNOWN_ERROR, "no usable HIP device: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    c->device = dev;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, ZDW_UNKNOWN_ERROR, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    c->ncols = ncols;
+    c->types.assign(col_types, col_types + ncols);
+    c->kind.resize(ncols); c->recoff.resize(ncols); c->numidx.resize(ncols);
+    // rec row layout: u64 slots (numeric columns) first, then u32 slots (text columns); 8-byte aligned stride
+    uint32_t off = 0, nnum = 0;
+    for (uint32_t k = 0; k < ncols; ++k) {
+        c->kind[k] = kind_of_type(col_types[k]);
+        if (c->kind[k] != K_TEXT) { c->recoff[k] = off; off += 8; c->numidx[k] = (int32_t)nnum++; }
+    }
+    for (uint32_t k = 0; k < ncols; ++k)
+        if (c->kind[k] == K_TEXT) { c->recoff[k] = off; off += 4; c->numidx[k] = -1; }
+    c->rec_stride = (off + 7u) & ~7u;
+    if (!c->rec_stride) c->rec_stride = 8;
+    c->nnum = nnum;
+    if (opts) {
+        c->trim = opts->trim_trailing_spaces != 0;
+        c->row_cap = opts->first_row_capacity ? opts->first_row_capacity : FIRST_ROW_CAP;
+        c->slots_opt = opts->dict_slots;
+    }
+    int rc = upload_schema(c);
+    if (rc) { g_create_error = c->err; zdw_ctx_destroy(c); return rc; }
+    *out = c;
+    return ZDW_OK;
+}
+
+void zdw_ctx_destroy(zdw_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    collect_times(c);
+    DevBuf *bufs[] = {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->scan_tmp, &c->rec,
+                      &c->slots, &c->slot_len, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
+                      &c->uniq_pos, &c->uniq_len, &c->uniq_slot, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
+                      &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
+                      &c->extra_lens, &c->extra_offs, &c->exp_bytes, &c->d_used_recoff, &c->d_used_kind, &c->d_used_size,
+                      &c->d_used_base, &c->d_prev0, &c->d_last, &c->row_len, &c->row_off, &c->rows_out};
+    for (DevBuf *b : bufs) b->release();
+    c->h_dict.release(); c->h_rows.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int zdw_ctx_enable_timing(zdw_ctx *c, int enable)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    collect_times(c);
+    c->timing = enable != 0;
+    memset(&c->times, 0, sizeof c->times);
+    return ZDW_OK;
+}
+
+int zdw_ctx_stage_times(const zdw_ctx *cc, zdw_stage_times *out)
+{
+    if (!cc || !out) return ZDW_UNKNOWN_ERROR;
+    zdw_ctx *c = const_cast<zdw_ctx *>(cc);
+    collect_times(c);
+    *out = c->times;
+    return ZDW_OK;
+}
+
+int zdw_set_input_host(zdw_ctx *c, const uint8_t *tsv, uint64_t len)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    if (len && !tsv) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_set_input_host: tsv is NULL");
+    if (len >= EXTRA_BASE) return fail(c, ZDW_OUT_OF_MEMORY, "input of %llu bytes is beyond this build's 2^39 limit", (unsigned long long)len);
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, c->in_owned.ensure(len + 64));
+    {
+        StageScope ts(c, ZDW_STAGE_H2D);
+        if (len) HIP_TRY(c, hipMemcpyAsync(c->in_owned.p, tsv, len, hipMemcpyHostToDevice, c->stream));
+    }
+    c->d_in = c->in_owned.as<uint8_t>();
+    c->n = len;
+    return after_input(c);
+}
+
+int zdw_set_input_device(zdw_ctx *c, const void *d_tsv, uint64_t len)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    if (len && !d_tsv) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_set_input_device: d_tsv is NULL");
+    if (reinterpret_cast<uintptr_t>(d_tsv) & 15u) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_set_input_device: buffer must be 16-byte aligned");
+    if (len >= EXTRA_BASE) return fail(c, ZDW_OUT_OF_MEMORY, "input of %llu bytes is beyond this build's 2^39 limit", (unsigned long long)len);
+    (void)hipSetDevice(c->device);
+    c->d_in = static_cast<const uint8_t *>(d_tsv);
+    c->n = len;
+    return after_input(c);
+}
+
+int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *res)
+{
+    if (!c || !res) return ZDW_UNKNOWN_ERROR;
+    memset(res, 0, sizeof *res);
+    if (!c->have_input) return fail(c, ZDW_UNKNOWN_ERROR, "no input set");
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    reset_block(c);
+    const uint64_t lo = c->lo, hi = c->hi;
+    res->longest_line = c->row_cap;
+    res->is_last_block = 1;
+    res->bytes_consumed = lo;
+    c->is_last = true;
+    c->next_lo = c->n;
+    HIP_TRY(c, c->status.ensure(sizeof(P1Status)));
+    HIP_TRY(c, c->d_scalar.ensure(64));
+
+    uint64_t total_rows = 0;
+    uint32_t nspans = 0;
+    uint64_t span0 = 0;
+    if (hi > lo) {
+        StageScope ts(c, ZDW_STAGE_SCAN_ROWS);
+        span0 = lo / SPAN_BYTES;
+        nspans = (uint32_t)((hi + SPAN_BYTES - 1) / SPAN_BYTES - span0);
+        HIP_TRY(c, c->span_starts.ensure((nspans + 1ull) * 4));
+        HIP_TRY(c, c->span_rowbase.ensure((nspans + 2ull) * 4));
+        HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(nspans + 1ull)));
+        P1Status init{};
+        init.bad_row = 0xFFFFFFFFu; init.split_pos = c->n;
+        HIP_TRY(c, hipMemcpyAsync(c->status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
+        launch_count_row_starts(c->d_in, c->n, lo, hi, span0, nspans, c->span_starts.as<uint32_t>(), c->status.as<P1Status>(), s);
+        launch_scan_u32_to_u32(c->span_starts.as<uint32_t>(), c->span_rowbase.as<uint32_t>(), nspans, c->scan_tmp.p,
+                               c->d_scalar.as<uint64_t>(), s);
+        HIP_TRY(c, hipMemcpyAsync(&total_rows, c->d_scalar.p, 8, hipMemcpyDeviceToHost, s));
+        P1Status st0{};
+        HIP_TRY(c, hipMemcpyAsync(&st0, c->status.p, sizeof st0, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (st0.nul_seen) return fail(c, ZDW_UNKNOWN_ERROR, "input contains a NUL byte: not representable in ZDW (C strings)");
+    }
+    if (total_rows >= 0xFFFFFFFFull) return fail(c, ZDW_UNKNOWN_ERROR, "more than 2^32-2 rows in one block");
+
+    uint32_t row_limit = 0xFFFFFFFFu, partial = 0;
+    bool tripped = false;
+    if (hint && hint->max_rows != 0xFFFFFFFFu && hint->max_rows < total_rows) {
+        tripped = true; row_limit = hint->max_rows; partial = hint->partial_fields;
+    }
+    const uint32_t nrows = tripped ? row_limit : (uint32_t)total_rows;
+    c->nrows = nrows;
+    c->is_last = !tripped;
+
+    // ---- pass 1 proper (also runs for zero rows when a partial row pollutes the block) ----
+    const bool lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) <= 20 * 1024;
+    uint64_t nslots = c->slots_opt;
+    if (!nslots) {
+        nslots = 1ull << 16;
+        const uint64_t want = (hi > lo ? hi - lo : 0) / 4;
+        while (nslots < want && nslots < (1ull << 22)) nslots <<= 1;
+    }
+    { uint64_t p2 = 1; while (p2 < nslots) p2 <<= 1; nslots = p2; }
+    HIP_TRY(c, c->col_min.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_max.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_seen.ensure(c->ncols + 8));
+    HIP_TRY(c, c->rec.ensure((uint64_t)nrows * c->rec_stride + 16));
+    const uint64_t blk_bytes = hi > lo ? hi - lo : 0;
+    const uint32_t long_cap = (uint32_t)std::min<uint64_t>(blk_bytes / (FIRST_ROW_CAP - 1) + 2, 1u << 26);
+    HIP_TRY(c, c->long_rows.ensure((uint64_t)long_cap * sizeof(LongRow)));
+    P1Status st{};
+    for (int attempt = 0;; ++attempt) {
+        if (nslots > (1ull << 32)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary needs more than 2^32 table slots; split the block");
+        HIP_TRY(c, c->slots.ensure(nslots * 8));
+        HIP_TRY(c, c->slot_len.ensure(nslots * 4));
+        HIP_TRY(c, hipMemsetAsync(c->slots.p, 0, nslots * 8, s));
+        HIP_TRY(c, hipMemsetAsync(c->col_min.p, 0xFF, c->ncols * 8 + 8, s));
+        HIP_TRY(c, hipMemsetAsync(c->col_max.p, 0, c->ncols * 8 + 8, s));
+        HIP_TRY(c, hipMemsetAsync(c->col_seen.p, 0, c->ncols + 8, s));
+        P1Status init{};
+        init.bad_row = 0xFFFFFFFFu; init.split_pos = c->n;
+        HIP_TRY(c, hipMemcpyAsync(c->status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
+        c->nslots = nslots;
+        if (hi > lo && total_rows) {
+            StageScope ts(c, ZDW_STAGE_PASS1);
+            Pass1Args a{};
+            a.in = c->d_in; a.n = c->n; a.lo = lo; a.hi = hi; a.span0 = span0; a.nspans = nspans;
+            a.span_rowbase = c->span_rowbase.as<uint32_t>();
+            a.extra = c->extra.as<uint8_t>();
+            a.ncols = c->ncols; a.col_kind = c->d_kind.as<uint8_t>(); a.col_recoff = c->d_recoff.as<uint32_t>();
+            a.col_numidx = c->d_numidx.as<int32_t>(); a.nnum = c->nnum; a.use_lds_ranges = lds_ranges ? 1u : 0u;
+            a.rec_stride = c->rec_stride; a.rec = c->rec.as<uint8_t>();
+            a.row_limit = row_limit; a.partial_fields = partial; a.trim = c->trim ? 1u : 0u;
+            a.slots = c->slots.as<uint64_t>(); a.slot_len = c->slot_len.as<uint32_t>(); a.slot_mask = nslots - 1;
+            a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 2, 0xFFFFFFF0ull);
+            a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
+            a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
+            launch_pass1(a, s);
+        }
+        HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));
+        if (!st.overflow) break;
+        nslots <<= 4;                       // table too small for this block's uniques: grow and redo the pass
+        if (attempt > 6) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
+    }
+    res->table_slots = nslots;
+    res->dict_entries = st.entries;
+
+    if (st.bad_row != 0xFFFFFFFFu && st.bad_row <= row_limit) {          // ConvertToZDW.cpp:810-812
+        res->bad_row = st.bad_row + 1;
+        return fail(c, ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW, "Row %u had the problem", res->bad_row);
+    }
+
+    // ---- m_LongestLine: replay the reference's buffer growth on rows that could have triggered it ----
+    {
+        std::vector<LongRow> lr;
+        uint32_t cnt = st.long_count;
+        if (cnt > long_cap) cnt = long_cap;
+        if (cnt) {
+            lr.resize(cnt);
+            HIP_TRY(c, hipMemcpy(lr.data(), c->long_rows.p, cnt * sizeof(LongRow), hipMemcpyDeviceToHost));
+            std::sort(lr.begin(), lr.end(), [](const LongRow &x, const LongRow &y) { return x.start < y.start; });
+        }
+        std::vector<uint8_t> rowbuf;
+        for (const LongRow &r : lr) {
+            if (r.len <= (uint64_t)c->row_cap - 1) continue;      // fits the current buffer: no growth possible
+            rowbuf.resize(r.len);
+            HIP_TRY(c, hipMemcpy(rowbuf.data(), c->d_in + r.start, r.len, hipMemcpyDeviceToHost));
+            replay_row_reads(rowbuf.data(), r.len, true, &c->row_cap);
+        }
+        if (!tripped && c->n > hi && c->n - hi >= (uint64_t)c->row_cap - 1) {   // unterminated tail read (and dropped) by pass 1
+            const uint64_t tl = c->n - hi;
+            rowbuf.resize(tl);
+            HIP_TRY(c, hipMemcpy(rowbuf.data(), c->d_in + hi, tl, hipMemcpyDeviceToHost));
+            replay_row_reads(rowbuf.data(), tl, false, &c->row_cap);
+        }
+    }
+    res->longest_line = c->row_cap;
+    res->num_rows = nrows;
+    res->is_last_block = tripped ? 0 : 1;
+    c->next_lo = tripped ? st.split_pos : c->n;
+    res->bytes_consumed = c->next_lo;
+
+    // column ranges to the host (the multi-GPU path may merge them before they are used)
+    c->h_min.assign(c->ncols, 0); c->h_max.assign(c->ncols, 0); c->h_seen.assign(c->ncols, 0);
+    if (c->ncols) {
+        HIP_TRY(c, hipMemcpy(c->h_min.data(), c->col_min.p, c->ncols * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_max.data(), c->col_max.p, c->ncols * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_seen.data(), c->col_seen.p, c->ncols, hipMemcpyDeviceToHost));
+    }
+    c->p1_done = true;
+    if (tripped && nrows == 0) return fail(c, ZDW_OUT_OF_MEMORY, "block limit leaves no room for a single row");
+    return ZDW_OK;
+}
+
+int zdw_block_dict_device(zdw_ctx *c, const void **d_section, uint64_t *section_len, uint8_t *index_size)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    int rc = ensure_dict(c);
+    if (rc) return rc;
+    if (d_section) *d_section = c->dict_sec.as<uint8_t>() + c->dict_sec_off;
+    if (section_len) *section_len = c->dict_sec_len;
+    if (index_size) *index_size = c->nuniq ? c->index_size : 0;
+    return ZDW_OK;
+}
+
+int zdw_block_dict(zdw_ctx *c, const uint8_t **section, uint64_t *section_len, uint8_t *index_size)
+{
+    const void *d = nullptr;
+    uint64_t len = 0;
+    int rc = zdw_block_dict_device(c, &d, &len, index_size);
+    if (rc) return rc;
+    HIP_TRY(c, c->h_dict.ensure(len));
+    {
+        StageScope ts(c, ZDW_STAGE_D2H);
+        HIP_TRY(c, hipMemcpyAsync(c->h_dict.p, d, len, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (section) *section = static_cast<const uint8_t *>(c->h_dict.p);
+    if (section_len) *section_len = len;
+    return ZDW_OK;
+}
+
+int zdw_block_stats(zdw_ctx *c, uint8_t *col_size, uint64_t *col_base, uint32_t *used)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    int rc = ensure_stats(c);
+    if (rc) return rc;
+    if (col_size && c->ncols) memcpy(col_size, c->col_size.data(), c->ncols);
+    if (col_base) for (size_t u = 0; u < c->used.size(); ++u) col_base[u] = c->col_base[c->used[u]];
+    if (used) *used = (uint32_t)c->used.size();
+    return ZDW_OK;
+}
+
+int zdw_block_pass2_device(zdw_ctx *c, const void **d_rows, uint64_t *rows_len)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    int rc = run_pass2(c);
+    if (rc) return rc;
+    if (d_rows) *d_rows = c->rows_out.p;
+    if (rows_len) *rows_len = c->rows_len;
+    return ZDW_OK;
+}
+
+int zdw_block_pass2(zdw_ctx *c, const uint8_t **rows, uint64_t *rows_len)
+{
+    const void *d = nullptr;
+    uint64_t len = 0;
+    int rc = zdw_block_pass2_device(c, &d, &len);
+    if (rc) return rc;
+    HIP_TRY(c, c->h_rows.ensure(len + 1));
+    if (len) {
+        StageScope ts(c, ZDW_STAGE_D2H);
+        HIP_TRY(c, hipMemcpyAsync(c->h_rows.p, d, len, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (rows) *rows = static_cast<const uint8_t *>(c->h_rows.p);
+    if (rows_len) *rows_len = len;
+    return ZDW_OK;
+}
+
+int zdw_block_next(zdw_ctx *c)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    c->lo = c->next_lo;
+    reset_block(c);
+    return ZDW_OK;
+}
+
+// ---- multi-GPU shard exchange ---------------------------------------------------------------------
+int zdw_shard_export_ranges(zdw_ctx *c, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen)
+{
+    if (!c || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    for (uint32_t k = 0; k < c->ncols; ++k) {
+        if (col_min) col_min[k] = c->h_min[k];
+        if (col_max) col_max[k] = c->h_max[k];
+        if (col_seen) col_seen[k] = c->h_seen[k];
+    }
+    return ZDW_OK;
+}
+
+int zdw_shard_import_ranges(zdw_ctx *c, const uint64_t *col_min, const uint64_t *col_max, const uint8_t *col_seen)
+{
+    if (!c || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    for (uint32_t k = 0; k < c->ncols; ++k) {
+        if (col_min) c->h_min[k] = col_min[k];
+        if (col_max) c->h_max[k] = col_max[k];
+        if (col_seen) c->h_seen[k] = col_seen[k];
+    }
+    c->stats_done = false; c->p2_done = false;
+    return ZDW_OK;
+}
+
+int zdw_shard_export_uniques(zdw_ctx *c, const void **d_lens, const void **d_bytes, uint64_t *count, uint64_t *nbytes)
+{
+    if (!c || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    uint32_t entries = 0;
+    HIP_TRY(c, hipMemcpy(&entries, &c->status.as<P1Status>()->entries, 4, hipMemcpyDeviceToHost));
+    const uint64_t u = entries;
+    HIP_TRY(c, c->uniq_pos.ensure((u + 1) * 8)); HIP_TRY(c, c->uniq_len.ensure((u + 1) * 4)); HIP_TRY(c, c->uniq_slot.ensure((u + 1) * 4));
+    HIP_TRY(c, c->lenp1.ensure((u + 1) * 4)); HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(u + 1)));
+    HIP_TRY(c, hipMemsetAsync(c->d_scalar.p, 0, 64, s));
+    launch_dict_compact(c->slots.as<uint64_t>(), c->slot_len.as<uint32_t>(), c->nslots, c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(),
+                        c->uniq_slot.as<uint32_t>(), c->d_scalar.as<uint32_t>(), s);
+    // identity order: lenp1[i] = len[i] + 1
+    HIP_TRY(c, c->order.ensure((u + 1) * 4));
+    {
+        std::vector<uint32_t> ident(u);
+        for (uint64_t i = 0; i < u; ++i) ident[i] = (uint32_t)i;
+        if (u) HIP_TRY(c, hipMemcpyAsync(c->order.p, ident.data(), u * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    launch_dict_lengths(c->order.as<uint32_t>(), c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, c->exp_bytes.ensure(total + 16));
+    launch_export_strings(c->d_in, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), c->off_excl.as<uint64_t>(), u,
+                          c->exp_bytes.as<uint8_t>(), s);
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (d_lens) *d_lens = c->uniq_len.p;
+    if (d_bytes) *d_bytes = c->exp_bytes.p;
+    if (count) *count = u;
+    if (nbytes) *nbytes = total;
+    return ZDW_OK;
+}
+
+int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes)
+{
+    if (!c || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    if (!count) return ZDW_OK;
+    if (nbytes >= EXTRA_BASE) return fail(c, ZDW_OUT_OF_MEMORY, "imported strings exceed 2^39 bytes");
+    // own copies: the caller's buffers may be reused while this block is alive
+    HIP_TRY(c, c->extra.ensure(nbytes + 16));
+    HIP_TRY(c, c->extra_lens.ensure((count + 1) * 4));
+    HIP_TRY(c, c->extra_offs.ensure((count + 2) * 8));
+    HIP_TRY(c, c->lenp1.ensure((count + 1) * 4));
+    HIP_TRY(c, c->order.ensure((count + 1) * 4));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(count + 1)));
+    HIP_TRY(c, hipMemcpyAsync(c->extra.p, d_bytes, nbytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->extra_lens.p, d_lens, count * 4, hipMemcpyDeviceToDevice, s));
+    {
+        std::vector<uint32_t> ident(count);
+        for (uint64_t i = 0; i < count; ++i) ident[i] = (uint32_t)i;
+        HIP_TRY(c, hipMemcpyAsync(c->order.p, ident.data(), count * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    launch_dict_lengths(c->order.as<uint32_t>(), c->extra_lens.as<uint32_t>(), count, c->lenp1.as<uint32_t>(), s);
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count, c->scan_tmp.p, nullptr, s);
+    launch_import_strings(c->d_in, c->extra.as<uint8_t>(), c->extra_lens.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count,
+                          c->slots.as<uint64_t>(), c->slot_len.as<uint32_t>(), c->nslots - 1,
+                          (uint32_t)std::min<uint64_t>(c->nslots - c->nslots / 8, 0xFFFFFFF0ull), c->trim ? 1u : 0u, c->hi,
+                          c->status.as<P1Status>(), s);
+    P1Status st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (st.overflow)
+        return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table (%llu slots) too small for the merged dictionary: raise zdw_opts.dict_slots",
+                    (unsigned long long)c->nslots);
+    c->extra_bytes = nbytes;
+    c->dict_done = c->stats_done = c->p2_done = false;
+    return ZDW_OK;
+}
+
+int zdw_shard_set_prev_row(zdw_ctx *c, const uint64_t *stored)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    c->have_prev = stored != nullptr;
+    if (stored) c->prev_row.assign(stored, stored + c->ncols);
+    c->p2_done = false;
+    return ZDW_OK;
+}
+
+int zdw_shard_last_row(zdw_ctx *c, uint64_t *stored)
+{
+    if (!c || !stored) return ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    int rc = run_pass2(c);
+    if (rc) return rc;
+    // columns that are unused carry 0; with no rows the previous row passes through unchanged
+    for (uint32_t k = 0; k < c->ncols; ++k) stored[k] = (c->nrows == 0 && c->have_prev) ? c->prev_row[k] : 0;
+    const uint32_t nu = (uint32_t)c->used.size();
+    if (c->nrows && nu) {
+        std::vector<uint64_t> last(nu);
+        HIP_TRY(c, hipMemcpy(last.data(), c->d_last.p, nu * 8, hipMemcpyDeviceToHost));
+        for (uint32_t u = 0; u < nu; ++u) stored[c->used[u]] = last[u];
+    }
+    return ZDW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// zdw_dev.h — device-side helpers shared by the gfx950 kernels of libzdw_hip.so.
+//
+// Everything here assumes wave64 (CDNA4) and is compiled for gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zdw {
+
+constexpr uint32_t WAVE = 64;
+constexpr uint32_t ROUND_BYTES = 256;   // bytes classified per wave step: one dword per lane
+constexpr uint32_t SPAN_BYTES = 16384;  // input bytes whose row starts one wave visit owns
+constexpr uint32_t FIRST_ROW_CAP = 16384;
+
+// column type ids (cplusplus/zdw_column_type_constants.h:17-35)
+enum : uint8_t {
+    T_VARCHAR = 0, T_TEXT = 1, T_DATETIME = 2, T_CHAR_2 = 3, T_CHAR = 6,
+    T_TINY = 7, T_SHORT = 8, T_LONG = 9, T_LONGLONG = 10, T_DECIMAL = 11,
+    T_TINY_SIGNED = 12, T_SHORT_SIGNED = 13, T_LONG_SIGNED = 14, T_LONGLONG_SIGNED = 15,
+    T_TINYTEXT = 16, T_MEDIUMTEXT = 17, T_LONGTEXT = 18
+};
+// how pass 1 treats a column
+enum : uint8_t { K_TEXT = 0, K_INT = 1, K_CHAR = 2 };
+
+__host__ __device__ inline uint8_t kind_of_type(uint8_t t)
+{
+    switch (t) {
+    case T_VARCHAR: case T_TEXT: case T_TINYTEXT: case T_MEDIUMTEXT: case T_LONGTEXT:
+    case T_DATETIME: case T_CHAR_2: case T_DECIMAL: return K_TEXT;
+    case T_CHAR: return K_CHAR;
+    default: return K_INT;
+    }
+}
+
+__device__ __forceinline__ uint32_t lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of m in lanes below the calling lane
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// bits [0, b] set; b in [-1, 63]
+__device__ __forceinline__ uint64_t mask_le(int b) { return b < 0 ? 0ull : ((2ull << b) - 1ull); }
+// bits [0, b) set; b in [0, 64]
+__device__ __forceinline__ uint64_t mask_lt(int b) { return b <= 0 ? 0ull : (b >= 64 ? ~0ull : ((1ull << b) - 1ull)); }
+__device__ __forceinline__ int highest_bit(uint64_t m) { return m ? 63 - __clzll((long long)m) : -1; }
+__device__ __forceinline__ int lowest_bit(uint64_t m) { return m ? __ffsll((long long)m) - 1 : -1; }
+__device__ __forceinline__ uint32_t popc64(uint64_t m) { return (uint32_t)__popcll(m); }
+
+__device__ __forceinline__ uint32_t bcast32(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane)
+{
+    uint32_t lo = bcast32((uint32_t)v, src_lane), hi = bcast32((uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v);
+}
+
+// ------------------------------------------------------------------------------------------
+// Byte access to the TSV image.  `n` is the size of the allocation: nothing at or past it is read.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t *in, uint64_t p, uint64_t n)
+{
+    if (p + 4 <= n) return *reinterpret_cast<const uint32_t *>(in + p);
+    uint32_t w = 0;
+    for (int k = 0; k < 4; ++k)
+        if (p + k < n) w |= (uint32_t)in[p + k] << (8 * k);
+    return w;
+}
+
+// number of consecutive backslashes directly before position p, never looking below lo
+__device__ inline uint32_t backslashes_before(const uint8_t *in, uint64_t lo, uint64_t p)
+{
+    uint32_t k = 0;
+    while (p > lo + k && in[p - 1 - k] == '\\') ++k;
+    return k;
+}
+// is byte p an unescaped newline (a row terminator)?  (getnextrow.cpp:45-53)
+__device__ inline bool is_row_terminator(const uint8_t *in, uint64_t lo, uint64_t p)
+{
+    return in[p] == '\n' && (backslashes_before(in, lo, p) & 1u) == 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// One classification round: 256 bytes starting at `pos` (a multiple of 4 from the buffer start),
+// lane l holds dword w = bytes pos+4l .. pos+4l+3.  Produces wave-uniform lane masks
+//     tab[k] / nl[k] : byte k of lane l is an UNESCAPED tab / newline at a position in [vlo, vhi)
+// (a tab/newline is special iff an even number of backslashes precedes it).
+// bs_carry: byte pos-1 is a backslash (in/out, for the next round).
+// ------------------------------------------------------------------------------------------
+struct RoundMasks {
+    uint64_t tab[4];
+    uint64_t nl[4];
+    uint64_t nul;     // any NUL byte at a valid position
+};
+
+__device__ inline void classify_round(const uint8_t *in, uint64_t lo, uint64_t vlo, uint64_t vhi, uint64_t pos,
+                                      uint32_t w, uint32_t lane, bool &bs_carry, RoundMasks &m)
+{
+    uint64_t bs[4];
+    uint64_t nul = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = (w >> (8 * k)) & 0xffu;
+        const uint64_t p = pos + 4ull * lane + k;
+        const bool in_block = p >= lo && p < vhi;        // backslashes count from the block start on
+        const bool valid = p >= vlo && p < vhi;
+        bs[k] = __ballot(in_block && b == '\\');
+        m.tab[k] = __ballot(valid && b == '\t');
+        m.nl[k] = __ballot(valid && b == '\n');
+        nul |= __ballot(valid && b == 0);
+    }
+    m.nul = nul;
+    uint64_t prevbs[4];
+    prevbs[0] = (bs[3] << 1) | (bs_carry ? 1ull : 0ull);
+    prevbs[1] = bs[0]; prevbs[2] = bs[1]; prevbs[3] = bs[2];
+    bs_carry = (bs[3] >> 63) & 1ull;
+    uint64_t cand = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cand |= (m.tab[k] | m.nl[k]) & prevbs[k];
+    if (cand) {   // wave-uniform: some special byte follows a backslash -> count the run exactly
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t ck = (m.tab[k] | m.nl[k]) & prevbs[k];
+            bool esc = false;
+            if ((ck >> lane) & 1ull) esc = backslashes_before(in, lo, pos + 4ull * lane + k) & 1u;
+            const uint64_t e = __ballot(esc);
+            m.tab[k] &= ~e;
+            m.nl[k] &= ~e;
+        }
+    }
+}
+
+// 64-bit FNV-style hash over a byte range, finished with an avalanche; only used inside the
+// dictionary table (never leaves the device).
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+}  // namespace zdw

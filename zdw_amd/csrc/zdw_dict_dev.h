@@ -1,0 +1,96 @@
+// zdw_dict_dev.h — device side of the block dictionary table (shared by pass 1 and the
+// multi-GPU string import).  Replaces Dictionary::insert / StringHeap (cplusplus/dictionary.cpp:31-51,
+// stringheap.cpp:31-86): an open-addressing table of first occurrences instead of a red-black tree
+// of heap copies; strings stay where they are in the TSV image.
+#pragma once
+#include "zdw_dev.h"
+#include "zdw_kernels.h"
+
+namespace zdw {
+
+__device__ __forceinline__ const uint8_t *string_at(const uint8_t *in, const uint8_t *extra, uint64_t pos)
+{
+    return pos >= EXTRA_BASE ? extra + (pos - EXTRA_BASE) : in + pos;
+}
+
+// Does the stored occurrence at position `pos` (same first `len` bytes as the candidate) END after
+// `len` bytes?  Imported strings are NUL terminated.  In the TSV image the next byte must be the
+// field's separator; it is a separator iff the run of backslashes before it is even, and that run is
+// the candidate's own trailing run (identical bytes), so its parity is passed in.  With -t the stored
+// raw field may carry trailing blanks before its separator.
+__device__ inline bool stored_ends_here(const uint8_t *in, const uint8_t *extra, uint64_t pos, uint32_t len, uint64_t hi,
+                                        bool trim, bool tail_bs_odd)
+{
+    if (pos >= EXTRA_BASE) return extra[pos - EXTRA_BASE + len] == 0;
+    uint64_t q = pos + len;
+    bool blanks = false;
+    if (trim) while (q < hi && in[q] == ' ') { ++q; blanks = true; }
+    if (q >= hi) return false;
+    const uint8_t b = in[q];
+    if (b != '\t' && b != '\n') return false;
+    return blanks || !tail_bs_odd;
+}
+
+// Insert-or-find in the block dictionary table.  slot word = tag(24) | position+1 (40); 0 = empty.
+// Returns slot index + 1, or 0 when the table is too full (caller retries with more slots).
+__device__ inline uint32_t dict_insert(const uint8_t *in, const uint8_t *extra, uint64_t hi, uint64_t *slots, uint32_t *slot_len,
+                                       uint64_t slot_mask, uint32_t max_entries, P1Status *st, uint64_t pos, uint32_t len,
+                                       bool trim)
+{
+    const uint8_t *p = string_at(in, extra, pos);
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint32_t i = 0; i < len; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    h = mix64(h ^ len);
+    uint32_t nbs = 0;
+    while (nbs < len && p[len - 1 - nbs] == '\\') ++nbs;
+    const bool tail_bs_odd = nbs & 1u;
+    const uint64_t tag = h >> POS_BITS;
+    const uint64_t mine = (tag << POS_BITS) | (pos + 1);
+    uint64_t i = h & slot_mask;
+    const uint32_t max_probe = slot_mask + 1 < 8192 ? (uint32_t)(slot_mask + 1) : 8192u;
+    for (uint32_t probe = 0; probe < max_probe; ++probe) {
+        uint64_t w = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) {
+            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[i]), 0ull, (unsigned long long)mine);
+            if (old == 0) {
+                slot_len[i] = len;
+                const uint32_t cnt = atomicAdd(&st->entries, 1u);
+                if (cnt >= max_entries) st->overflow = 1;
+                return (uint32_t)i + 1;
+            }
+            w = old;
+        }
+        if ((w >> POS_BITS) == tag) {
+            const uint64_t sp = (w & POS_MASK) - 1;
+            if (sp == pos) return (uint32_t)i + 1;
+            const bool stored_extra = sp >= EXTRA_BASE;
+            bool same = stored_extra || sp + len < hi;
+            if (same) {
+                const uint8_t *q = string_at(in, extra, sp);
+                for (uint32_t k = 0; k < len; ++k)
+                    if (q[k] != p[k] || (stored_extra && q[k] == 0)) { same = false; break; }   // never run past an imported string
+            }
+            if (same && stored_ends_here(in, extra, sp, len, hi, trim, tail_bs_odd)) return (uint32_t)i + 1;
+        }
+        i = (i + 1) & slot_mask;
+    }
+    st->overflow = 1;
+    return 0;
+}
+
+
+// big-endian 8-byte sort key of bytes [8*depth, 8*depth+8) of a string, zero padded.  Strings hold
+// no NUL byte, so zero padding orders a shorter prefix first, like strcmp (dictionary.h:30-35).
+__device__ inline uint64_t sort_key8(const uint8_t *p, uint32_t len, uint32_t depth)
+{
+    uint64_t k = 0;
+    const uint64_t base = 8ull * depth;
+#pragma unroll
+    for (uint32_t b = 0; b < 8; ++b) {
+        const uint64_t i = base + b;
+        k = (k << 8) | (i < len ? p[i] : 0u);
+    }
+    return k;
+}
+
+}  // namespace zdw

@@ -1,0 +1,106 @@
+// zdw_kernels.h — launch-level interface between the C ABI (zdw_capi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zdw {
+
+// position space of dictionary strings: [0, 2^39) = the TSV image, [2^39, 2^40) = imported strings
+constexpr uint64_t POS_BITS = 40;
+constexpr uint64_t POS_MASK = (1ull << POS_BITS) - 1ull;
+constexpr uint64_t EXTRA_BASE = 1ull << 39;
+constexpr uint32_t COL_SKIP = 0xFFFFFFu;
+
+struct P1Status {
+    uint32_t bad_row;       // smallest 0-based row with a wrong field count, 0xFFFFFFFF = none
+    uint32_t overflow;      // dictionary table too small: retry with more slots
+    uint32_t entries;       // unique strings inserted
+    uint32_t long_count;    // rows >= 16383 bytes recorded in long_rows
+    uint64_t split_pos;     // start of row `row_limit` (the first row of the next block)
+    uint32_t nul_seen;      // NUL byte in the input (unsupported)
+    uint32_t pad;
+};
+
+struct LongRow { uint64_t start; uint64_t len; };   // len includes the terminating newline
+
+struct Pass1Args {
+    const uint8_t *in; uint64_t n;        // TSV image and its allocation size
+    uint64_t lo, hi;                      // block start; effective end (last row terminator + 1)
+    uint64_t span0; uint32_t nspans;      // spans [span0, span0 + nspans) cover [lo, hi)
+    const uint32_t *span_rowbase;         // exclusive scan of per-span row starts
+    const uint8_t *extra;                 // imported strings (multi-GPU merge), NUL terminated
+    uint32_t ncols;
+    const uint8_t *col_kind;
+    const uint32_t *col_recoff;
+    const int32_t *col_numidx;
+    uint32_t nnum;
+    uint32_t use_lds_ranges;              // 1: per-wave LDS min/max + seen, flushed once per wave
+    uint32_t rec_stride; uint8_t *rec;    // rec[row][...]: u64 per numeric column, u32 id per text column
+    uint32_t row_limit, partial_fields;
+    uint32_t trim;
+    uint64_t *slots; uint32_t *slot_len; uint64_t slot_mask; uint32_t max_entries;
+    uint64_t *col_min; uint64_t *col_max; uint8_t *col_seen;
+    P1Status *st;
+    LongRow *long_rows; uint32_t long_cap;
+};
+
+struct Pass2Args {
+    const uint8_t *rec; uint32_t rec_stride; uint32_t nrows;
+    uint32_t nused;
+    const uint32_t *used_recoff;   // per used column: offset inside a rec row
+    const uint8_t *used_kind;      // K_TEXT / K_INT / K_CHAR
+    const uint8_t *used_size;      // bytes stored per value
+    const uint64_t *used_base;     // column base (min - 1; 0 for text)
+    const uint32_t *slot_off;      // dictionary offset per table slot
+    const uint64_t *prev0;         // stored values of the row before row 0 (per used column)
+    uint32_t *row_len;             // out (size kernel)
+    const uint64_t *row_off;       // in (emit kernel): exclusive scan of row_len
+    uint8_t *out;
+    uint64_t *last_stored;         // optional: stored values of the last row (per used column)
+};
+
+// ---- launchers (all asynchronous on `s`) ----
+void launch_find_effective_end(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t *d_out, hipStream_t s);
+void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t hi, uint64_t span0, uint32_t nspans,
+                             uint32_t *span_starts, P1Status *st, hipStream_t s);
+void launch_pass1(const Pass1Args &a, hipStream_t s);
+size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds);
+
+// exclusive scans; tmp must hold scan_tmp_bytes(n) bytes; total (optional) receives the sum
+size_t scan_tmp_bytes(uint64_t n);
+void launch_scan_u32_to_u32(const uint32_t *in, uint32_t *out, uint64_t n, void *tmp, uint64_t *total, hipStream_t s);
+void launch_scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, uint64_t *total, hipStream_t s);
+
+// dictionary
+void launch_dict_compact(const uint64_t *slots, const uint32_t *slot_len, uint64_t nslots,
+                         uint64_t *uniq_pos, uint32_t *uniq_len, uint32_t *uniq_slot, uint32_t *count, hipStream_t s);
+struct SortBuffers {   // all sized for n elements unless noted
+    uint64_t *key_a, *key_b;
+    uint32_t *val_a, *val_b;
+    uint32_t *order;       // result: order[rank] = unique index
+    uint32_t *group;       // tie-group id per position
+    uint32_t *active_a, *active_b;   // positions still tied
+    uint32_t *flags;       // scratch, n+1
+    uint32_t *hist;        // 256 * sort_blocks(n)
+    void *scan_tmp;
+    uint32_t *counter;     // small device scratch (>= 4 u32)
+};
+uint32_t sort_blocks(uint64_t n);
+// sorts unique strings into strcmp order; returns through `order`.  Host-driven loop (synchronises on s).
+int dict_sort(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n,
+              SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len);
+void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s);
+void launch_dict_emit(const uint8_t *in, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
+                      const uint32_t *uniq_len, const uint32_t *uniq_slot, const uint64_t *off_excl, uint64_t n,
+                      uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *slot_off, hipStream_t s);
+void launch_import_strings(const uint8_t *in, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
+                           uint64_t *slots, uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim,
+                           uint64_t hi, P1Status *st, hipStream_t s);
+void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                           const uint64_t *off_excl, uint64_t n, uint8_t *bytes, hipStream_t s);
+
+// pass 2
+void launch_pass2_size(const Pass2Args &a, hipStream_t s);
+void launch_pass2_emit(const Pass2Args &a, hipStream_t s);
+
+}  // namespace zdw
