@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — TSV -> ZDW encode throughput on MI355X (BASELINE.json metric).
+
+One step = one full two-pass block encode (row scan, pass 1, dictionary sort, column stats, pass 2)
+of a synthetic TSV that is already resident in HBM; outputs stay in HBM.  Workload at N = 1:
+BASELINE.json configs[3], "Synthetic 10 GB TSV, 200 cols mixed VARCHAR/LONG, Zipf strings"
+(zdw_amd/synth.py).  N > 1 (launched by torch.distributed.run, one rank per GPU):
+weak scaling, every rank holds its own 10 GB row range of ONE ZDW block; RCCL carries the column
+range all-reduce, the dictionary merge (all-gather of unique strings) and the previous-row halo.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--gb G] [--cols C] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(desc, sample, cores_note=1):
+    """Times the reference encoder (oracle/_ref, kind 'reference') or the C oracle ('port') on `sample`."""
+    from oracle import oracle
+    mb = len(sample) / 1e6
+    if oracle.have_ref():
+        d = tempfile.mkdtemp(prefix="zdwbase_")
+        try:
+            with open(os.path.join(d, "s.sql"), "wb") as f:
+                f.write(sample)
+            with open(os.path.join(d, "s.desc.sql"), "wb") as f:
+                f.write(desc)
+            env = dict(os.environ)
+            env["PATH"] = oracle.REF_SHIM + os.pathsep + env.get("PATH", "")
+            t0 = time.perf_counter()
+            p = subprocess.run([oracle.REF_BIN, "-q", os.path.join(d, "s.sql")], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            out_bytes = os.path.getsize(os.path.join(d, "s.zdw.gz")) if p.returncode == 0 else 0
+            kind = "reference"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        if p.returncode != 0:
+            return {"value": None, "unit": "MB/s", "cores": 1, "kind": kind, "sample": "reference failed: %s" % p.stderr[-200:]}
+    else:
+        t0 = time.perf_counter()
+        rc, out, _ = oracle.encode(desc, sample)
+        dt = time.perf_counter() - t0
+        out_bytes = len(out) if rc == 0 else 0
+        kind = "port"
+    return {"value": round(mb / dt, 2), "unit": "MB/s", "cores": 1, "kind": kind,
+            "sample": "first %.1f MB (whole rows) of the same synthetic table, compressor child replaced by cat, %.1f s, ratio %.2f"
+                      % (mb, dt, len(sample) / max(1, out_bytes))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gb", type=float, default=10.0, help="input GB (1e9 bytes) per GPU")
+    ap.add_argument("--cols", type=int, default=200)
+    ap.add_argument("--cpu-mb", type=float, default=200.0, help="size of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from zdw_amd import capi, sharded, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    # ---- synthetic table, generated in HBM; rank r holds rows [r*R, (r+1)*R) ----
+    table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local)
+    rows_per_rank = table.rows_for_bytes(args.gb * 1e9)
+    buf, nbytes = table.generate(rank * rows_per_rank, rows_per_rank)
+    torch.cuda.synchronize()
+
+    enc = capi.Encoder(table.types, device=local, dict_slots=(1 << 23) if world > 1 else 0)
+    enc.set_input_device(buf.data_ptr(), nbytes, keepalive=buf)
+    enc.enable_timing(True)
+
+    def step():
+        if world > 1:
+            return sharded.encode_shard_dist(enc, rank, world)
+        rc, p1 = enc.pass1()
+        if rc:
+            raise capi.ZdwError(rc, "pass1")
+        _, dlen, _ = enc.dict_section_device()
+        enc.stats()
+        _, rlen = enc.pass2_device()
+        return p1.num_rows, dlen, rlen
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    enc.enable_timing(True)      # reset stage accumulators after warm-up
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nrows, dict_len, rows_len = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([nbytes, dict_len + rows_len + nrows * 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        total_in, total_out = int(tot[0].item()), int(tot[1].item())
+    else:
+        total_in, total_out = nbytes, dict_len + rows_len
+    ms = dt / args.steps * 1e3
+    stages = enc.stage_times()
+
+    if rank == 0:
+        out_local = dict_len + rows_len + 9 + args.cols * 9
+        per = {k: round(v[0] / max(1, args.steps), 3) for k, v in stages.items() if v[1]}
+        # dominant kernel: pass 1 (tokenise + dedupe + parse).  Algorithmic bytes per launch: one read of
+        # the block's TSV (B_in); the whole encode is priced at 2*B_in + B_out.
+        dom = max((k for k in per if k not in ("h2d", "d2h")), key=lambda k: per[k])
+        alg = {"scan_rows": nbytes, "pass1": nbytes, "pass2_size": 0, "pass2_emit": rows_len, "dict_sort": 0,
+               "dict_compact": 0, "dict_emit": dict_len}.get(dom, 0)
+        dom_ms = per[dom]
+        achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
+        b_alg = 2 * nbytes + out_local
+        res = {
+            "metric": "TSV->ZDW encode throughput (input bytes / wall time, input resident in HBM, raw .zdw left in HBM)",
+            "value": round(total_in / 1e6 / (dt / args.steps), 1), "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
+            "config": {"workload": "synthetic TSV %.1f GB x %d cols per GPU, mixed VARCHAR/LONG, Zipf(1.1) strings over 2^20 words, 25%% empty, 30%% repeat (BASELINE configs[3])"
+                                   % (nbytes / 1e9, args.cols),
+                       "rows_per_gpu": int(nrows), "input_bytes_per_gpu": int(nbytes), "zdw_bytes_per_gpu": int(out_local),
+                       "compression_ratio": round(nbytes / max(1, out_local), 3),
+                       "parallelism": "one ZDW block row-sharded over %d GPU(s)" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg),
+                         "whole_encode": {"b_alg": int(b_alg), "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1),
+                                          "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}},
+            "stage_ms": per,
+        }
+        if not args.no_cpu:
+            # bounded sample: whole rows from the head of rank 0's table
+            want = int(min(args.cpu_mb * 1e6, nbytes))
+            head = buf[:want].cpu().numpy().tobytes()
+            cut = head.rfind(b"\n") + 1
+            res["cpu_baseline"] = cpu_baseline(table.desc, head[:cut])
+            res["cpu_baseline"]["host_cores"] = os.cpu_count()
+        else:
+            res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 1, "kind": "port", "sample": "skipped (--no-cpu)"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    enc.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""CPU tests (gloo, world_size 2) of the multi-GPU exchange in zdw_amd/sharded.py: the collectives
+must give exactly what the pure merge functions give."""
+import os
+import random
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from zdw_amd import sharded
+
+
+def _shard_data(rank, ncols=7):
+    rnd = random.Random(100 + rank)
+    mn = [rnd.choice([sharded.NO_MIN, rnd.getrandbits(64), rnd.randrange(1, 1000)]) for _ in range(ncols)]
+    mx = [0 if m == sharded.NO_MIN else max(m, rnd.getrandbits(64)) for m in mn]
+    seen = [rnd.randrange(2) for _ in range(ncols)]
+    words = [bytes(rnd.choice(b"abcxyz\xff\\") for _ in range(rnd.randrange(1, 9))) for _ in range(5 + 3 * rank)]
+    lens = torch.tensor([len(w) for w in words], dtype=torch.int32)
+    byts = torch.tensor(list(b"".join(w + b"\0" for w in words)), dtype=torch.uint8)
+    last = [rnd.getrandbits(64) for _ in range(ncols)]
+    nrows = 0 if rank == 1 and ncols == 3 else 10 + rank
+    return mn, mx, seen, lens, byts, last, nrows
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mn, mx, seen, lens, byts, last, nrows = _shard_data(rank)
+    r = sharded.allreduce_ranges(mn, mx, seen, device="cpu")
+    ol, ob = sharded.allgather_uniques(lens, byts, rank, world)
+    prev = sharded.exchange_prev_row(last, nrows, rank, world, device="cpu")
+    q.put((rank, r, ol.tolist(), ob.tolist(), prev))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collectives_match_pure_merges():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, r, ol, ob, prev = q.get(timeout=120)
+        got[rank] = (r, ol, ob, prev)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    data = [_shard_data(r) for r in range(world)]
+    want_ranges = sharded.merge_ranges([(d[0], d[1], d[2]) for d in data])
+    want_prev = sharded.chain_prev_rows([d[5] for d in data], [d[6] for d in data])
+    for rank in range(world):
+        r, ol, ob, prev = got[rank]
+        assert (list(r[0]), list(r[1]), list(r[2])) == (want_ranges[0], want_ranges[1], want_ranges[2])
+        wl, wb = sharded.concat_uniques([(d[3], d[4]) for d in data], skip=rank)
+        assert ol == wl.tolist() and ob == wb.tolist()
+        assert prev == want_prev[rank]
+
+
+def test_pure_merges():
+    mn, mx, seen = sharded.merge_ranges([([5, sharded.NO_MIN], [9, 0], [0, 0]), ([3, 7], [4, 1 << 63], [1, 0])])
+    assert (mn, mx, seen) == ([3, 7], [9, 1 << 63], [1, 0])
+    vals = [0, 1, (1 << 63) - 1, 1 << 63, (1 << 64) - 1]
+    t = sharded.u64_to_ordered_i64(vals)
+    assert t.tolist() == sorted(t.tolist())              # unsigned order survives as signed order
+    assert sharded.ordered_i64_to_u64(t) == vals
+    assert sharded.chain_prev_rows([[1], [2], [3]], [4, 0, 5]) == [None, [1], [1]]

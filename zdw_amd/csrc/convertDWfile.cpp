@@ -68,7 +68,7 @@ int badParam(const char *exe, const char *param)
 
 // The whole command line as a callable, so that tests can drive it in-process (one HIP
 // initialisation for hundreds of cases); `main` below is a one-line wrapper.
-extern "C" int zdw_convertDWfile_main(int argc, char *argv[])
+static int runCommandLine(int argc, char *argv[])
 {
     const char *program = argv[0];
     if (argc < 2) {
@@ -164,6 +164,14 @@ extern "C" int zdw_convertDWfile_main(int argc, char *argv[])
         }
     }
     return exitCode;
+}
+
+extern "C" int zdw_convertDWfile_main(int argc, char *argv[])
+{
+    const int rc = runCommandLine(argc, argv);
+    fflush(stdout);
+    fflush(stderr);
+    return rc;
 }
 
 #ifndef ZDW_CLI_AS_LIBRARY

@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
                 uint8_t *q = a.out + out_row + nflag + running + (inc - mine);
                 for (uint32_t j = 0; j < sz; ++j) q[j] = (uint8_t)(cur >> (8 * j));   // little-endian truncating store
             }
-            if (ok && a.last_stored && row == a.nrows - 1) a.last_stored[u] = cur;
         }
         running += tot;
     }
@@ -95,6 +94,20 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
     case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<32, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<64, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
     }
+}
+
+// stored values of the block's last row (what the next shard of a row-sharded block compares its
+// first row with); independent of the flags, so it needs no pass over the rows
+__global__ __launch_bounds__(256) void k_last_row(const Pass2Args a)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < a.nused) a.last_stored[u] = stored_value(a, a.nrows - 1, u);
+}
+
+void launch_last_row(const Pass2Args &a, hipStream_t s)
+{
+    if (!a.nrows || !a.nused) return;
+    hipLaunchKernelGGL(k_last_row, dim3((a.nused + 255) / 256), dim3(256), 0, s, a);
 }
 
 void launch_pass2_size(const Pass2Args &a, hipStream_t s) { launch_pass2<false>(a, s); }

@@ -336,15 +336,16 @@ int ensure_stats(zdw_ctx *c)
     return ZDW_OK;
 }
 
-int run_pass2(zdw_ctx *c)
+// uploads the per-used-column tables pass 2 reads and fills the kernel arguments
+int prepare_pass2(zdw_ctx *c, Pass2Args &a)
 {
-    if (c->p2_done) return ZDW_OK;
     int rc = ensure_stats(c);
     if (rc) return rc;
     hipStream_t s = c->stream;
     const uint32_t nu = (uint32_t)c->used.size();
-    c->rows_len = 0;
-    if (nu == 0 || c->nrows == 0) { c->p2_done = true; HIP_TRY(c, c->rows_out.ensure(16)); return ZDW_OK; }
+    memset(&a, 0, sizeof a);
+    a.nrows = c->nrows; a.nused = nu; a.rec_stride = c->rec_stride;
+    if (nu == 0 || c->nrows == 0) return ZDW_OK;
     std::vector<uint32_t> uo(nu); std::vector<uint8_t> uk(nu), us(nu); std::vector<uint64_t> ub(nu), up(nu, 0);
     for (uint32_t u = 0; u < nu; ++u) {
         const uint32_t k = c->used[u];
@@ -359,16 +360,27 @@ int run_pass2(zdw_ctx *c)
     HIP_TRY(c, hipMemcpyAsync(c->d_used_base.p, ub.data(), nu * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->d_prev0.p, up.data(), nu * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));      // the host vectors above go out of scope
-    HIP_TRY(c, c->row_len.ensure((c->nrows + 1ull) * 4));
-    HIP_TRY(c, c->row_off.ensure((c->nrows + 2ull) * 8));
-    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(c->nrows + 1ull)));
-    Pass2Args a{};
-    a.rec = c->rec.as<uint8_t>(); a.rec_stride = c->rec_stride; a.nrows = c->nrows; a.nused = nu;
+    a.rec = c->rec.as<uint8_t>();
     a.used_recoff = c->d_used_recoff.as<uint32_t>(); a.used_kind = c->d_used_kind.as<uint8_t>();
     a.used_size = c->d_used_size.as<uint8_t>(); a.used_base = c->d_used_base.as<uint64_t>();
     a.slot_off = c->slot_off.as<uint32_t>(); a.prev0 = c->d_prev0.as<uint64_t>();
-    a.row_len = c->row_len.as<uint32_t>(); a.row_off = c->row_off.as<uint64_t>(); a.out = nullptr;
     a.last_stored = c->d_last.as<uint64_t>();
+    return ZDW_OK;
+}
+
+int run_pass2(zdw_ctx *c)
+{
+    if (c->p2_done) return ZDW_OK;
+    Pass2Args a;
+    int rc = prepare_pass2(c, a);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    c->rows_len = 0;
+    if (a.nused == 0 || c->nrows == 0) { c->p2_done = true; HIP_TRY(c, c->rows_out.ensure(16)); return ZDW_OK; }
+    HIP_TRY(c, c->row_len.ensure((c->nrows + 1ull) * 4));
+    HIP_TRY(c, c->row_off.ensure((c->nrows + 2ull) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(c->nrows + 1ull)));
+    a.row_len = c->row_len.as<uint32_t>(); a.row_off = c->row_off.as<uint64_t>(); a.out = nullptr;
     {
         StageScope ts(c, ZDW_STAGE_PASS2_SIZE);
         launch_pass2_size(a, s);
@@ -852,15 +864,17 @@ int zdw_shard_last_row(zdw_ctx *c, uint64_t *stored)
 {
     if (!c || !stored) return ZDW_UNKNOWN_ERROR;
     (void)hipSetDevice(c->device);
-    int rc = run_pass2(c);
+    Pass2Args a;
+    int rc = prepare_pass2(c, a);
     if (rc) return rc;
-    // columns that are unused carry 0; with no rows the previous row passes through unchanged
+    // unused columns carry 0; a shard without rows passes its predecessor's row through
     for (uint32_t k = 0; k < c->ncols; ++k) stored[k] = (c->nrows == 0 && c->have_prev) ? c->prev_row[k] : 0;
-    const uint32_t nu = (uint32_t)c->used.size();
-    if (c->nrows && nu) {
-        std::vector<uint64_t> last(nu);
-        HIP_TRY(c, hipMemcpy(last.data(), c->d_last.p, nu * 8, hipMemcpyDeviceToHost));
-        for (uint32_t u = 0; u < nu; ++u) stored[c->used[u]] = last[u];
+    if (c->nrows && a.nused) {
+        launch_last_row(a, c->stream);
+        std::vector<uint64_t> last(a.nused);
+        HIP_TRY(c, hipMemcpyAsync(last.data(), c->d_last.p, a.nused * 8ull, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (uint32_t u = 0; u < a.nused; ++u) stored[c->used[u]] = last[u];
     }
     return ZDW_OK;
 }

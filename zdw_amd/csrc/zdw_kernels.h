@@ -56,7 +56,7 @@ struct Pass2Args {
     uint32_t *row_len;             // out (size kernel)
     const uint64_t *row_off;       // in (emit kernel): exclusive scan of row_len
     uint8_t *out;
-    uint64_t *last_stored;         // optional: stored values of the last row (per used column)
+    uint64_t *last_stored;         // k_last_row only: stored values of the last row (per used column)
 };
 
 // ---- launchers (all asynchronous on `s`) ----
@@ -102,5 +102,6 @@ void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64
 // pass 2
 void launch_pass2_size(const Pass2Args &a, hipStream_t s);
 void launch_pass2_emit(const Pass2Args &a, hipStream_t s);
+void launch_last_row(const Pass2Args &a, hipStream_t s);
 
 }  // namespace zdw
