@@ -19,43 +19,71 @@ namespace zdw {
 // ------------------------------------------------------------------------------------------
 // table -> list of uniques (order is arbitrary; the sort makes it canonical)
 // ------------------------------------------------------------------------------------------
+// Each workgroup owns a contiguous run of slots: it counts its occupied slots (ballots, no atomics),
+// reserves that many output entries with ONE atomic, then walks the run again (L2-warm) to fill them.
 __global__ __launch_bounds__(256) void k_dict_compact(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ slot_len,
-                                                       uint64_t nslots, uint64_t *__restrict__ uniq_pos,
+                                                       uint64_t nslots, uint64_t per_block, uint64_t *__restrict__ uniq_pos,
                                                        uint32_t *__restrict__ uniq_len, uint32_t *__restrict__ uniq_slot,
                                                        uint32_t *count)
 {
-    const uint32_t lane = lane_id();
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t rounds = (nslots + stride - 1) / stride;
-    for (uint64_t r = 0; r < rounds; ++r) {
-        const uint64_t i = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const uint64_t w = i < nslots ? slots[i] : 0ull;
-        const uint64_t m = __ballot(w != 0);
-        if (m) {
-            uint32_t base = 0;
-            if (lane == (uint32_t)lowest_bit(m)) base = atomicAdd(count, popc64(m));
-            base = bcast32(base, lowest_bit(m));
-            if (w != 0) {
-                const uint32_t k = base + mbcnt64(m);
-                uniq_pos[k] = (w & POS_MASK) - 1;
-                uniq_len[k] = slot_len[i];
-                uniq_slot[k] = (uint32_t)i;
-            }
-            // count[1] = longest string (bounds the number of sort rounds)
-            uint32_t ml = w != 0 ? slot_len[i] : 0u;
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t wave_max[4];
+    __shared__ uint32_t block_base;
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint64_t beg = (uint64_t)blockIdx.x * per_block;
+    const uint64_t end = beg + per_block < nslots ? beg + per_block : nslots;
+    uint32_t mine = 0, ml = 0;
+    for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
+        if (slots[i] != 0) { ++mine; const uint32_t l = slot_len[i]; ml = l > ml ? l : ml; }
+    }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)ml, d, 64); ml = o > ml ? o : ml; }
-            if (lane == 0 && ml) atomicMax(count + 1, ml);
+    for (int d = 32; d >= 1; d >>= 1) {
+        mine += (uint32_t)__shfl_xor((int)mine, d, 64);
+        const uint32_t o = (uint32_t)__shfl_xor((int)ml, d, 64);
+        ml = o > ml ? o : ml;
+    }
+    if (lane == 0) { wave_cnt[wv] = mine; wave_max[wv] = ml; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        uint32_t m = wave_max[0];
+        for (int k = 1; k < 4; ++k) m = wave_max[k] > m ? wave_max[k] : m;
+        block_base = tot ? atomicAdd(count, tot) : 0u;
+        if (m) atomicMax(count + 1, m);          // count[1] = longest string (bounds the sort rounds)
+    }
+    __syncthreads();
+    // second walk, wave by wave in slot order: wave w handles rounds w, w+4, ... of 64 slots
+    uint32_t running = block_base;
+    for (uint64_t r0 = beg; r0 < end; r0 += 256) {
+        // occupied counts of the four 64-slot groups of this 256-slot step
+        uint32_t before = 0, step_total = 0;
+        uint64_t my_mask = 0; uint64_t my_w = 0; uint64_t my_i = 0;
+        for (uint32_t g = 0; g < 4; ++g) {
+            const uint64_t i = r0 + 64ull * g + lane;
+            const uint64_t w = i < end ? slots[i] : 0ull;
+            const uint64_t m = __ballot(w != 0);
+            if (g < wv) before += popc64(m);
+            if (g == wv) { my_mask = m; my_w = w; my_i = i; }
+            step_total += popc64(m);
         }
+        if (my_w != 0) {
+            const uint32_t k = running + before + mbcnt64(my_mask);
+            uniq_pos[k] = (my_w & POS_MASK) - 1;
+            uniq_len[k] = slot_len[my_i];
+            uniq_slot[k] = (uint32_t)my_i;
+        }
+        running += step_total;
     }
 }
 
 void launch_dict_compact(const uint64_t *slots, const uint32_t *slot_len, uint64_t nslots, uint64_t *uniq_pos, uint32_t *uniq_len,
                          uint32_t *uniq_slot, uint32_t *count, hipStream_t s)
 {
-    const uint64_t blocks = (nslots + 255) / 256;
-    const uint32_t grid = blocks < 4096 ? (uint32_t)blocks : 4096u;
-    hipLaunchKernelGGL(k_dict_compact, dim3(grid), dim3(256), 0, s, slots, slot_len, nslots, uniq_pos, uniq_len, uniq_slot, count);
+    uint64_t per_block = 256ull * 16;                      // 4096 slots (32 KiB of table) per workgroup
+    while ((nslots + per_block - 1) / per_block > 65536) per_block *= 2;
+    const uint32_t grid = (uint32_t)((nslots + per_block - 1) / per_block);
+    hipLaunchKernelGGL(k_dict_compact, dim3(grid ? grid : 1), dim3(256), 0, s, slots, slot_len, nslots, per_block, uniq_pos, uniq_len,
+                       uniq_slot, count);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -330,22 +358,22 @@ void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64
                        (uint32_t)n, bytes);
 }
 
-__global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, const uint8_t *extra, const uint32_t *__restrict__ lens,
+__global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *__restrict__ lens,
                                                          const uint64_t *__restrict__ offs, uint64_t count, uint64_t *slots,
                                                          uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim,
                                                          uint64_t hi, P1Status *st)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    dict_insert(in, extra, hi, slots, slot_len, slot_mask, max_entries, st, EXTRA_BASE + offs[i], lens[i], trim != 0);
+    dict_insert(in, n, extra, hi, slots, slot_len, slot_mask, max_entries, st, EXTRA_BASE + offs[i], lens[i], trim != 0);
 }
 
-void launch_import_strings(const uint8_t *in, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
+void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
                            uint64_t *slots, uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim, uint64_t hi,
                            P1Status *st, hipStream_t s)
 {
     if (!count) return;
-    hipLaunchKernelGGL(k_import_strings, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, in, extra, lens, offs, count, slots,
+    hipLaunchKernelGGL(k_import_strings, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, in, n, extra, lens, offs, count, slots,
                        slot_len, slot_mask, max_entries, trim, hi, st);
 }
 

@@ -9,11 +9,13 @@
 //   * the TSV image is cut into 16 KiB spans; a wave visit owns every row that STARTS in its span
 //     and follows the last of them past the span end;
 //   * the wave streams 256-byte rounds (one coalesced dword per lane); `v_cmp` ballots give
-//     wave-wide bitmaps of tabs / newlines / backslashes, so row starts, field ordinals and field
-//     starts are mbcnt / find-highest-bit arithmetic on SGPR masks, no per-byte loops;
-//   * every field boundary becomes a 16-byte descriptor in a per-wave LDS ring; whenever 64 are
-//     pending the wave processes them one per lane (hash + table insert, strtoull, char(1)),
-//     so field work runs at full lane occupancy whatever the field length distribution is;
+//     wave-wide bitmaps of tabs / newlines / backslashes in SGPRs, so row starts, field ordinals
+//     and boundaries are mbcnt / scalar bit arithmetic, no per-byte loops.  Rounds that lie inside
+//     the span and hold no row terminator (the common case for wide rows) take a short path;
+//   * every field boundary becomes a 16-byte descriptor (end position, column, row) in a per-wave
+//     LDS ring; a field starts where the previous descriptor ends.  Whenever 64 are pending the wave
+//     processes them one per lane (hash + table insert, strtoull, char(1)), so field work runs at
+//     full lane occupancy whatever the field length distribution is;
 //   * pass 2 never re-reads the text: each field leaves a fixed-width record (u32 table slot id
 //     or u64 parsed value) in rec[row][column].
 #include "zdw_dev.h"
@@ -22,8 +24,60 @@
 
 namespace zdw {
 
-constexpr uint32_t QCAP = 512;            // ring entries per wave (<= 63 pending + <= 256 new per round)
-constexpr uint32_t P1_MAX_WAVES = 256 * 12;
+constexpr uint32_t QCAP = 384;   // ring entries per wave: <= 63 pending + 1 anchor + <= 256 new per round, + the predecessor of the head
+constexpr uint32_t P1_MAX_WAVES = 256 * 16;
+
+// ------------------------------------------------------------------------------------------
+// byte classes of one round as wave-wide lane masks (bit l of mask[k] <-> byte k of lane l's dword)
+// ------------------------------------------------------------------------------------------
+struct RawMasks {
+    uint64_t tab[4], nl[4], bs[4];
+    uint64_t nul;
+};
+
+__device__ __forceinline__ void raw_classify(uint32_t w, RawMasks &r)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = w & (0xffu << (8 * k));
+        r.tab[k] = __ballot(b == ((uint32_t)'\t' << (8 * k)));
+        r.nl[k] = __ballot(b == ((uint32_t)'\n' << (8 * k)));
+        r.bs[k] = __ballot(b == ((uint32_t)'\\' << (8 * k)));
+    }
+    r.nul = __ballot(((w - 0x01010101u) & ~w & 0x80808080u) != 0u);   // some byte of the dword is zero
+}
+
+// Drops escaped tabs/newlines: special iff an even number of backslashes precedes.
+// bs_carry: the byte before this round is a backslash (in/out).
+__device__ __forceinline__ void resolve_escapes(const uint8_t *in, uint64_t lo, uint64_t pos, uint32_t lane, RawMasks &r, bool &bs_carry)
+{
+    uint64_t prevbs[4];
+    prevbs[0] = (r.bs[3] << 1) | (bs_carry ? 1ull : 0ull);
+    prevbs[1] = r.bs[0]; prevbs[2] = r.bs[1]; prevbs[3] = r.bs[2];
+    bs_carry = (r.bs[3] >> 63) & 1ull;
+    uint64_t cand = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cand |= (r.tab[k] | r.nl[k]) & prevbs[k];
+    if (cand) {   // rare: count the run exactly (bounded by the block start)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t ck = (r.tab[k] | r.nl[k]) & prevbs[k];
+            bool esc = false;
+            if (__builtin_amdgcn_inverse_ballot_w64(ck)) esc = backslashes_before(in, lo, pos + 4ull * lane + k) & 1u;
+            const uint64_t e = __ballot(esc);
+            r.tab[k] &= ~e;
+            r.nl[k] &= ~e;
+        }
+    }
+}
+
+// lanes whose byte k lies at a round-relative position in [rel_lo, rel_hi)
+__device__ __forceinline__ uint64_t lanes_in(uint32_t rel_lo, uint32_t rel_hi, int k)
+{
+    const int l_lo = rel_lo > (uint32_t)k ? (int)((rel_lo - k + 3) >> 2) : 0;
+    const int l_hi = rel_hi > (uint32_t)k ? (int)((rel_hi - k + 3) >> 2) : 0;
+    return mask_lt(l_hi) & ~mask_lt(l_lo);
+}
 
 // ------------------------------------------------------------------------------------------
 // effective end of the image = last row terminator + 1 (an unterminated tail is dropped,
@@ -38,12 +92,15 @@ __global__ __launch_bounds__(64) void k_find_effective_end(const uint8_t *in, ui
         for (;;) {
             const uint32_t w = load_dword_guarded(in, pos + 4ull * lane, n);
             bool bs_carry = pos > lo && in[pos - 1] == '\\';
-            RoundMasks m;
-            classify_round(in, lo, lo, n, pos, w, lane, bs_carry, m);
+            RawMasks r;
+            raw_classify(w, r);
+            resolve_escapes(in, lo, pos, lane, r, bs_carry);
+            const uint32_t rel_lo = lo > pos ? (uint32_t)(lo - pos) : 0u;
+            const uint32_t rel_hi = n - pos < ROUND_BYTES ? (uint32_t)(n - pos) : ROUND_BYTES;
             int best = -1;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int hb = highest_bit(m.nl[k]);
+                const int hb = highest_bit(r.nl[k] & lanes_in(rel_lo, rel_hi, k));
                 if (hb >= 0 && 4 * hb + k > best) best = 4 * hb + k;
             }
             if (best >= 0) { result = pos + (uint64_t)best + 1; break; }
@@ -62,6 +119,7 @@ void launch_find_effective_end(const uint8_t *in, uint64_t n, uint64_t lo, uint6
 // ------------------------------------------------------------------------------------------
 // rows that start in each span.  A row start is a non-terminator byte that follows a row
 // terminator (or the block start): blank lines are no rows (getnextrow.cpp:38-43).
+// HBM-bound streaming kernel: 1 byte read per input byte, ~16 VALU + ~30 SALU per 256 bytes.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restrict__ in, uint64_t n, uint64_t lo, uint64_t hi,
                                                           uint64_t span0, uint32_t nspans, uint32_t *__restrict__ span_starts,
@@ -76,32 +134,47 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
         uint64_t nul = 0;
         if (ss < se) {
             bool prev_term = (ss == lo) || is_row_terminator(in, lo, ss - 1);
-            uint64_t pos = ss & ~(uint64_t)(ROUND_BYTES - 1);
-            bool bs_carry = pos > lo && in[pos - 1] == '\\';
-            bool first = true;
-            for (; pos < se; pos += ROUND_BYTES) {
-                const uint32_t w = load_dword_guarded(in, pos + 4ull * lane, n);
-                RoundMasks m;
-                classify_round(in, lo, ss, se, pos, w, lane, bs_carry, m);
-                nul |= m.nul;
-                uint64_t pt[4];
-                pt[0] = m.nl[3] << 1; pt[1] = m.nl[0]; pt[2] = m.nl[1]; pt[3] = m.nl[2];
-                if (first) {
-                    const uint32_t fv = (uint32_t)(ss - pos);
-                    if (prev_term) pt[fv & 3] |= 1ull << (fv >> 2);
-                    first = false;
-                } else if (prev_term) pt[0] |= 1ull;
-                // positions in [ss, se) that hold a real byte
-                const uint64_t rel_lo = ss > pos ? ss - pos : 0, rel_hi = se - pos < ROUND_BYTES ? se - pos : ROUND_BYTES;
+            const uint64_t pos0 = ss & ~(uint64_t)(ROUND_BYTES - 1);
+            bool bs_carry = pos0 > lo && in[pos0 - 1] == '\\';
+            for (uint64_t pos = pos0; pos < se; pos += 4 * ROUND_BYTES) {
+                // four rounds of loads in flight before the first is looked at
+                uint32_t wq[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // lanes l with rel_lo <= 4l+k < rel_hi
-                    const int l_lo = rel_lo > (uint64_t)k ? (int)((rel_lo - k + 3) >> 2) : 0;
-                    const int l_hi = rel_hi > (uint64_t)k ? (int)((rel_hi - k + 3) >> 2) : 0;   // exclusive
-                    const uint64_t valid = mask_lt(l_hi) & ~mask_lt(l_lo);
-                    count += popc64(pt[k] & ~m.nl[k] & valid);
+                for (int q = 0; q < 4; ++q) wq[q] = load_dword_guarded(in, pos + (uint64_t)q * ROUND_BYTES + 4ull * lane, n);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t rpos = pos + (uint64_t)q * ROUND_BYTES;
+                    if (rpos >= se) break;
+                    RawMasks r;
+                    raw_classify(wq[q], r);
+                    resolve_escapes(in, lo, rpos, lane, r, bs_carry);
+                    if (rpos >= ss && rpos + ROUND_BYTES <= se) {
+                        // interior round: every byte counts
+                        const uint64_t pt0 = (r.nl[3] << 1) | (prev_term ? 1ull : 0ull);
+                        count += popc64(pt0 & ~r.nl[0]) + popc64(r.nl[0] & ~r.nl[1]) + popc64(r.nl[1] & ~r.nl[2]) + popc64(r.nl[2] & ~r.nl[3]);
+                        nul |= r.nul;
+                        prev_term = (r.nl[3] >> 63) & 1ull;
+                    } else {
+                        // first / last round of the span: only positions in [ss, se) exist
+                        const uint32_t rel_lo = ss > rpos ? (uint32_t)(ss - rpos) : 0u;
+                        const uint32_t rel_hi = se - rpos < ROUND_BYTES ? (uint32_t)(se - rpos) : ROUND_BYTES;
+                        uint64_t nl[4], vm[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { vm[k] = lanes_in(rel_lo, rel_hi, k); nl[k] = r.nl[k] & vm[k]; }
+                        uint64_t pt[4];
+                        pt[0] = nl[3] << 1; pt[1] = nl[0]; pt[2] = nl[1]; pt[3] = nl[2];
+                        if (prev_term) pt[rel_lo & 3] |= 1ull << (rel_lo >> 2);   // the byte before position rel_lo terminated a row
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) count += popc64(pt[k] & ~nl[k] & vm[k]);
+                        // a NUL only matters inside the span
+                        const uint32_t w = wq[q];
+                        bool z = false;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) z |= __builtin_amdgcn_inverse_ballot_w64(vm[k]) && ((w >> (8 * k)) & 0xffu) == 0u;
+                        nul |= __ballot(z);
+                        prev_term = (nl[3] >> 63) & 1ull;
+                    }
                 }
-                prev_term = (m.nl[3] >> 63) & 1ull;
             }
         }
         if (lane == 0) {
@@ -122,17 +195,22 @@ void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_
 // ------------------------------------------------------------------------------------------
 // field-level work
 // ------------------------------------------------------------------------------------------
-// C-locale strtoull(s, NULL, 10) on a byte range (ConvertToZDW.cpp:385,564)
-__device__ inline uint64_t parse_u64(const uint8_t *p, uint32_t len)
+// C-locale strtoull(s, NULL, 10) on a byte range (ConvertToZDW.cpp:385,564): the
+// general form, one 8-byte window load per 8 characters.
+__device__ inline uint64_t parse_u64_general(const uint8_t *p, uint32_t len, const uint8_t *end)
 {
-    uint32_t i = 0;
-    while (i < len && (p[i] == ' ' || (p[i] >= 9 && p[i] <= 13))) ++i;
-    bool neg = false;
-    if (i < len && (p[i] == '+' || p[i] == '-')) { neg = p[i] == '-'; ++i; }
-    uint64_t v = 0;
-    bool any = false, ovf = false;
-    for (; i < len; ++i) {
-        const uint32_t d = (uint32_t)p[i] - '0';
+    uint64_t win = 0, v = 0;
+    bool neg = false, any = false, ovf = false;
+    uint32_t state = 0;     // 0 leading space, 1 digits
+    for (uint32_t i = 0; i < len; ++i) {
+        if ((i & 7u) == 0) win = load_upto8(p + i, len - i < 8 ? len - i : 8u, end);
+        const uint32_t b = (uint32_t)(win >> (8 * (i & 7u))) & 0xffu;
+        if (state == 0) {
+            if (b == ' ' || (b >= 9 && b <= 13)) continue;
+            state = 1;
+            if (b == '+' || b == '-') { neg = b == '-'; continue; }
+        }
+        const uint32_t d = b - '0';
         if (d > 9) break;
         any = true;
         if (v > 0xFFFFFFFFFFFFFFFFull / 10 || (v == 0xFFFFFFFFFFFFFFFFull / 10 && d > 5)) ovf = true;
@@ -143,6 +221,39 @@ __device__ inline uint64_t parse_u64(const uint8_t *p, uint32_t len)
     return neg ? (uint64_t)0 - v : v;
 }
 
+// eight ASCII digits (first character in the low byte) -> value, three multiplies
+__device__ __forceinline__ uint32_t eight_digits(uint64_t v)
+{
+    v -= 0x3030303030303030ull;
+    v = v * 10 + (v >> 8);
+    v = (((v & 0x000000FF000000FFull) * 0x000F424000000064ull) + (((v >> 16) & 0x000000FF000000FFull) * 0x0000271000000001ull)) >> 32;
+    return (uint32_t)v;
+}
+__device__ __forceinline__ bool all_digits(uint64_t w)
+{
+    return (((w + 0x4646464646464646ull) | (w - 0x3030303030303030ull)) & 0x8080808080808080ull) == 0ull;
+}
+// `len` (1..8) characters in the low bytes -> eight characters, '0'-padded in front
+__device__ __forceinline__ uint64_t pad_digits(uint64_t w, uint32_t len)
+{
+    return len >= 8 ? w : ((w << (8 * (8 - len))) | (0x3030303030303030ull >> (8 * len)));
+}
+
+// 1..16 plain digits take the SWAR route (two window loads, no per-character loop); anything else
+// (sign, blanks, junk, 17+ characters) goes through the general parser.  Same result either way.
+__device__ inline uint64_t parse_u64(const uint8_t *p, uint32_t len, const uint8_t *end)
+{
+    if (len <= 8) {
+        const uint64_t w = pad_digits(load_upto8(p, len, end), len);
+        if (all_digits(w)) return eight_digits(w);
+    } else if (len <= 16) {
+        const uint64_t w1 = pad_digits(load_upto8(p, len - 8, end), len - 8);
+        const uint64_t w2 = load_upto8(p + len - 8, 8, end);
+        if (all_digits(w1) && all_digits(w2)) return (uint64_t)eight_digits(w1) * 100000000ull + eight_digits(w2);
+    }
+    return parse_u64_general(p, len, end);
+}
+
 struct RangeSink {           // where per-column ranges of this wave accumulate
     uint64_t *mn, *mx;       // indexed by numeric index (LDS) or column (global)
     uint8_t *seen;           // indexed by column
@@ -151,9 +262,11 @@ struct RangeSink {           // where per-column ranges of this wave accumulate
 
 __device__ __forceinline__ void range_update(const RangeSink &r, uint32_t idx, uint64_t v)
 {
-    // unsigned 64-bit compare like the reference (ConvertToZDW.cpp:362-373,386-397)
-    atomicMin(reinterpret_cast<unsigned long long *>(&r.mn[idx]), (unsigned long long)v);
-    atomicMax(reinterpret_cast<unsigned long long *>(&r.mx[idx]), (unsigned long long)v);
+    // unsigned 64-bit compare like the reference (ConvertToZDW.cpp:362-373,386-397).  The plain reads
+    // only filter: min only falls and max only rises, so a stale value can cost a needless atomic,
+    // never lose an update.
+    if (v < r.mn[idx]) atomicMin(reinterpret_cast<unsigned long long *>(&r.mn[idx]), (unsigned long long)v);
+    if (v > r.mx[idx]) atomicMax(reinterpret_cast<unsigned long long *>(&r.mx[idx]), (unsigned long long)v);
 }
 
 __device__ inline void process_field(const Pass1Args &a, const RangeSink &rs, uint64_t fs, uint32_t len, uint32_t col, uint32_t row)
@@ -168,15 +281,16 @@ __device__ inline void process_field(const Pass1Args &a, const RangeSink &rs, ui
         uint32_t id = 0;
         if (len) {                                                    // empty fields are skipped (:340-341)
             if (!rs.seen[col]) rs.seen[col] = 1;
-            id = dict_insert(a.in, a.extra, a.hi, a.slots, a.slot_len, a.slot_mask, a.max_entries, a.st, fs, len, a.trim);
+            if (!(a.debug_skip & 2u))
+                id = dict_insert(a.in, a.n, a.extra, a.hi, a.slots, a.slot_len, a.slot_mask, a.max_entries, a.st, fs, len, a.trim);
         }
-        if (in_block) *reinterpret_cast<uint32_t *>(recp) = id;
+        if (in_block && !(a.debug_skip & 8u)) *reinterpret_cast<uint32_t *>(recp) = id;
         return;
     }
     uint64_t v_range = 0, v_rec = 0;
     if (len) {
         if (kind == K_INT) {
-            v_range = v_rec = parse_u64(p, len);
+            v_range = v_rec = (a.debug_skip & 4u) ? 1 : parse_u64(p, len, a.in + a.n);
         } else {   // char(1): pass 1 adds byte 1 only after a backslash (:358-361), pass 2 always (:543-547)
             const int64_t c0 = (int8_t)p[0];
             const int64_t hi8 = (int64_t)((int)(int8_t)(len >= 2 ? p[1] : 0) * 256);
@@ -185,17 +299,35 @@ __device__ inline void process_field(const Pass1Args &a, const RangeSink &rs, ui
         }
         if (v_range > 0) range_update(rs, rs.lds ? (uint32_t)a.col_numidx[col] : col, v_range);
     }
-    if (in_block) *reinterpret_cast<uint64_t *>(recp) = v_rec;
+    if (in_block && !(a.debug_skip & 8u)) *reinterpret_cast<uint64_t *>(recp) = v_rec;
 }
 
-// ring entry: x = start[31:0], y = start[39:32] | col << 8, z = length, w = row
+// ring entry: x = end[31:0], y = end[39:32] | col << 8, z = row.  The field it closes starts one
+// byte after the end recorded by the entry before it (anchors and blank-line terminators are kept
+// in the ring as COL_SKIP entries for exactly that purpose).
+__device__ __forceinline__ uint4 make_entry(uint64_t end, uint32_t col, uint32_t row)
+{
+    uint4 e;
+    e.x = (uint32_t)end;
+    e.y = (uint32_t)((end >> 32) & 0xffu) | (col << 8);
+    e.z = row;
+    e.w = 0;
+    return e;
+}
+__device__ __forceinline__ uint64_t entry_end(const uint4 &e) { return ((uint64_t)(e.y & 0xffu) << 32) | e.x; }
+
 __device__ __forceinline__ void consume(const Pass1Args &a, const RangeSink &rs, const uint4 *ring, uint32_t head, uint32_t count,
                                         uint32_t lane)
 {
     if (lane < count) {
-        const uint4 e = ring[(head + lane) & (QCAP - 1)];
+        const uint4 e = ring[(head + lane) % QCAP];
         const uint32_t col = e.y >> 8;
-        if (col != COL_SKIP) process_field(a, rs, ((uint64_t)(e.y & 0xffu) << 32) | e.x, e.z, col, e.w);
+        if (col != COL_SKIP && !(a.debug_skip & 1u)) {
+            const uint4 pe = ring[(head + lane + QCAP - 1) % QCAP];
+            // positions are 40-bit; the predecessor's end + 1 is where this field begins
+            const uint64_t fs = (entry_end(pe) + 1) & POS_MASK;
+            process_field(a, rs, fs, (uint32_t)(entry_end(e) - fs), col, e.z);
+        }
     }
 }
 
@@ -224,7 +356,7 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
     }
     __syncthreads();
 
-    uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running
+    uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running (kept small enough for % QCAP to stay exact)
 
     for (uint32_t si = blockIdx.x; si < a.nspans; si += gridDim.x) {
         const uint32_t rowbase = a.span_rowbase[si];
@@ -235,9 +367,9 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
         const uint64_t ss = s0 > a.lo ? s0 : a.lo;
         const uint64_t se = s0 + SPAN_BYTES < a.hi ? s0 + SPAN_BYTES : a.hi;
 
-        // wave-uniform running state of the open row / field
+        // wave-uniform running state of the open row
         const bool at_row_start = (ss == a.lo) || is_row_terminator(a.in, a.lo, ss - 1);
-        uint64_t st_row_start = ss, st_field_start = ss;
+        uint64_t st_row_start = ss;
         uint32_t st_tabs = 0, st_rows = 0;
         bool st_ignore = !at_row_start;      // the row open at ss began in an earlier span
         bool prev_term = at_row_start;
@@ -245,138 +377,152 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
         bool bs_carry = pos > a.lo && a.in[pos - 1] == '\\';
         bool first = true, done = false;
 
+        // anchor: the first field of this visit starts at ss
+        if (lane == 0) ring[q_tail % QCAP] = make_entry((ss - 1) & POS_MASK, COL_SKIP, 0);
+        q_tail += 1;
+
         for (; !done && pos < a.hi; pos += ROUND_BYTES) {
             const uint32_t w = load_dword_guarded(a.in, pos + 4ull * lane, a.n);
-            RoundMasks m;
-            classify_round(a.in, a.lo, ss, a.hi, pos, w, lane, bs_carry, m);
-            uint64_t term[4], tabm[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { term[k] = m.nl[k]; tabm[k] = m.tab[k]; }
+            RawMasks r;
+            raw_classify(w, r);
+            resolve_escapes(a.in, a.lo, pos, lane, r, bs_carry);
 
-            // the visit ends with the first terminator at or after se - 1
-            uint64_t keep[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-            if (pos + ROUND_BYTES > se - 1) {
-                const uint32_t thr = se - 1 > pos ? (uint32_t)(se - 1 - pos) : 0u;
-                int cut = 1 << 30;
+            const bool interior = !first && pos + ROUND_BYTES <= se - 1;     // wholly inside the span, not its last byte
+            if (interior && (r.nl[0] | r.nl[1] | r.nl[2] | r.nl[3]) == 0ull) {
+                // ---------- short path: no row terminator in this round ----------
+                if (prev_term) { st_rows += 1; st_row_start = pos; prev_term = false; }
+                const uint32_t before = mbcnt64(r.tab[0]) + mbcnt64(r.tab[1]) + mbcnt64(r.tab[2]) + mbcnt64(r.tab[3]);
+                uint32_t col = st_tabs + before;
+                uint32_t qi = q_tail + before;
+                const uint32_t row = rowbase + st_rows - 1;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int l_lo = thr > (uint32_t)k ? (int)((thr - k + 3) >> 2) : 0;
-                    const int lb = lowest_bit(term[k] & ~mask_lt(l_lo));
-                    if (lb >= 0 && 4 * lb + k < cut) cut = 4 * lb + k;
+                    if (__builtin_amdgcn_inverse_ballot_w64(r.tab[k])) {
+                        const uint32_t c = (st_ignore || col >= a.ncols) ? COL_SKIP : col;
+                        ring[qi % QCAP] = make_entry(pos + 4ull * lane + k, c, row);
+                        ++qi; ++col;
+                    }
                 }
-                if (cut < (1 << 30)) {
-                    done = true;
+                const uint32_t total = popc64(r.tab[0]) + popc64(r.tab[1]) + popc64(r.tab[2]) + popc64(r.tab[3]);
+                st_tabs += total;
+                q_tail += total;
+            } else {
+                // ---------- general path: terminators, span edges ----------
+                const uint32_t rel_lo = ss > pos ? (uint32_t)(ss - pos) : 0u;
+                const uint32_t rel_hi = a.hi - pos < ROUND_BYTES ? (uint32_t)(a.hi - pos) : ROUND_BYTES;
+                uint64_t term[4], tabm[4], keep[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    keep[k] = lanes_in(rel_lo, rel_hi, k);
+                    term[k] = r.nl[k] & keep[k];
+                    tabm[k] = r.tab[k] & keep[k];
+                }
+                // the visit ends with the first terminator at or after se - 1
+                if (pos + ROUND_BYTES > se - 1) {
+                    const uint32_t thr = se - 1 > pos ? (uint32_t)(se - 1 - pos) : 0u;
+                    int cut = 1 << 30;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        keep[k] = cut >= k ? mask_le((cut - k) >> 2) : 0ull;
-                        term[k] &= keep[k];
-                        tabm[k] &= keep[k];
+                        const int lb = lowest_bit(term[k] & lanes_in(thr, ROUND_BYTES, k));
+                        if (lb >= 0 && 4 * lb + k < cut) cut = 4 * lb + k;
                     }
-                }
-            }
-
-            uint64_t pt[4];
-            pt[0] = term[3] << 1; pt[1] = term[0]; pt[2] = term[1]; pt[3] = term[2];
-            if (first) {
-                const uint32_t fv = (uint32_t)(ss - pos);
-                if (prev_term) pt[fv & 3] |= 1ull << (fv >> 2);
-                first = false;
-            } else if (prev_term) pt[0] |= 1ull;
-
-            uint64_t sep[4], bnd[4], start[4];
-            const uint64_t rel_lo = ss > pos ? ss - pos : 0;
-            const uint64_t rel_hi = a.hi - pos < ROUND_BYTES ? a.hi - pos : ROUND_BYTES;
-            uint32_t nsep_before = 0, nstart_before = 0, ntab_before = 0, nsep_total = 0;
-            int tpos = -1, bpos = -1;
-            const uint64_t lt = mask_lt((int)lane);
+                    if (cut < (1 << 30)) {
+                        done = true;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int l_lo = rel_lo > (uint64_t)k ? (int)((rel_lo - k + 3) >> 2) : 0;
-                const int l_hi = rel_hi > (uint64_t)k ? (int)((rel_hi - k + 3) >> 2) : 0;
-                const uint64_t valid = mask_lt(l_hi) & ~mask_lt(l_lo);
-                const uint64_t blank = term[k] & pt[k];            // empty line: terminator right after a terminator
-                bnd[k] = tabm[k] | term[k];
-                sep[k] = bnd[k] & ~blank;
-                start[k] = pt[k] & ~term[k] & valid & keep[k];
-                nsep_before += mbcnt64(sep[k]);
-                nstart_before += mbcnt64(start[k]);
-                ntab_before += mbcnt64(tabm[k]);
-                nsep_total += popc64(sep[k]);
-                const int ht = highest_bit(term[k] & lt);
-                if (ht >= 0 && 4 * ht + k > tpos) tpos = 4 * ht + k;
-                const int hb = highest_bit(bnd[k] & lt);
-                if (hb >= 0 && 4 * hb + k > bpos) bpos = 4 * hb + k;
-            }
-
-            // this lane's view of the open row / field at its first byte
-            uint64_t my_row_start, my_field_start;
-            uint32_t my_tabs;
-            bool my_ignore;
-            if (tpos >= 0) {
-                my_row_start = pos + (uint64_t)tpos + 1;
-                my_ignore = false;
-                const int tl = tpos >> 2, tk = tpos & 3;
-                uint32_t upto = 0;   // tabs at positions <= tpos
-#pragma unroll
-                for (int k = 0; k < 4; ++k) upto += popc64(tabm[k] & mask_le(k <= tk ? tl : tl - 1));
-                my_tabs = ntab_before - upto;
-            } else {
-                my_row_start = st_row_start;
-                my_ignore = st_ignore;
-                my_tabs = st_tabs + ntab_before;
-            }
-            my_field_start = bpos >= 0 ? pos + (uint64_t)bpos + 1 : st_field_start;
-            uint32_t my_rows = st_rows + nstart_before;
-            uint32_t qi = q_tail + nsep_before;
-
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t p = pos + 4ull * lane + k;
-                if ((start[k] >> lane) & 1ull) ++my_rows;
-                const bool is_term = (term[k] >> lane) & 1ull;
-                const bool is_sep = (sep[k] >> lane) & 1ull;
-                if (is_sep) {
-                    const uint32_t row = rowbase + my_rows - 1;
-                    uint32_t col = my_tabs;
-                    if (my_ignore || col >= a.ncols || col >= COL_SKIP) col = COL_SKIP;
-                    uint4 e;
-                    e.x = (uint32_t)my_field_start;
-                    e.y = (uint32_t)((my_field_start >> 32) & 0xffu) | (col << 8);
-                    e.z = (uint32_t)(p - my_field_start);
-                    e.w = row;
-                    ring[qi & (QCAP - 1)] = e;
-                    ++qi;
-                    if (is_term && !my_ignore && row <= a.row_limit) {
-                        if (my_tabs + 1 != a.ncols) atomicMin(&a.st->bad_row, row);       // ConvertToZDW.cpp:336-337
-                        const uint64_t rl = p - my_row_start + 1;
-                        if (rl >= FIRST_ROW_CAP - 1) {                                     // may grow m_LongestLine
-                            const uint32_t li = atomicAdd(&a.st->long_count, 1u);
-                            if (li < a.long_cap) { a.long_rows[li].start = my_row_start; a.long_rows[li].len = rl; }
+                        for (int k = 0; k < 4; ++k) {
+                            keep[k] &= lanes_in(0, (uint32_t)cut + 1, k);
+                            term[k] &= keep[k];
+                            tabm[k] &= keep[k];
                         }
-                        if (row == a.row_limit) a.st->split_pos = my_row_start;
                     }
                 }
-                if (is_term) {
-                    my_tabs = 0; my_row_start = p + 1; my_field_start = p + 1; my_ignore = false;
-                } else if ((tabm[k] >> lane) & 1ull) {
-                    ++my_tabs; my_field_start = p + 1;
-                }
-            }
 
-            // lane 63 now holds the state at the end of the round
-            st_row_start = bcast64(my_row_start, 63);
-            st_field_start = bcast64(my_field_start, 63);
-            st_tabs = bcast32(my_tabs, 63);
-            st_rows = bcast32(my_rows, 63);
-            st_ignore = bcast32(my_ignore ? 1u : 0u, 63) != 0;
-            prev_term = (term[3] >> 63) & 1ull;
-            q_tail += nsep_total;
+                uint64_t pt[4];
+                pt[0] = term[3] << 1; pt[1] = term[0]; pt[2] = term[1]; pt[3] = term[2];
+                if (first) {
+                    if (prev_term) pt[rel_lo & 3] |= 1ull << (rel_lo >> 2);
+                    first = false;
+                } else if (prev_term) pt[0] |= 1ull;
+
+                uint64_t bnd[4], blank[4], start[4];
+                uint32_t nbnd_before = 0, nstart_before = 0, ntab_before = 0, nbnd_total = 0;
+                int tpos = -1;
+                const uint64_t lt = mask_lt((int)lane);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    blank[k] = term[k] & pt[k];                // empty line: terminator right after a terminator
+                    bnd[k] = tabm[k] | term[k];
+                    start[k] = pt[k] & ~term[k] & keep[k];
+                    nbnd_before += mbcnt64(bnd[k]);
+                    nstart_before += mbcnt64(start[k]);
+                    ntab_before += mbcnt64(tabm[k]);
+                    nbnd_total += popc64(bnd[k]);
+                    const int ht = highest_bit(term[k] & lt);
+                    if (ht >= 0 && 4 * ht + k > tpos) tpos = 4 * ht + k;
+                }
+
+                // this lane's view of the open row at its first byte
+                uint64_t my_row_start;
+                uint32_t my_tabs;
+                bool my_ignore;
+                if (tpos >= 0) {
+                    my_row_start = pos + (uint64_t)tpos + 1;
+                    my_ignore = false;
+                    const int tl = tpos >> 2, tk = tpos & 3;
+                    uint32_t upto = 0;   // tabs at positions <= tpos
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) upto += popc64(tabm[k] & mask_le(k <= tk ? tl : tl - 1));
+                    my_tabs = ntab_before - upto;
+                } else {
+                    my_row_start = st_row_start;
+                    my_ignore = st_ignore;
+                    my_tabs = st_tabs + ntab_before;
+                }
+                uint32_t my_rows = st_rows + nstart_before;
+                uint32_t qi = q_tail + nbnd_before;
+
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint64_t p = pos + 4ull * lane + k;
+                    if (__builtin_amdgcn_inverse_ballot_w64(start[k])) ++my_rows;
+                    const bool is_term = __builtin_amdgcn_inverse_ballot_w64(term[k]);
+                    const bool is_tab = __builtin_amdgcn_inverse_ballot_w64(tabm[k]);
+                    const bool is_blank = __builtin_amdgcn_inverse_ballot_w64(blank[k]);
+                    if (is_term || is_tab) {
+                        const uint32_t row = rowbase + my_rows - 1;
+                        uint32_t col = my_tabs;
+                        if (is_blank || my_ignore || col >= a.ncols) col = COL_SKIP;
+                        ring[qi % QCAP] = make_entry(p, col, row);
+                        ++qi;
+                        if (is_term && !is_blank && !my_ignore && row <= a.row_limit) {
+                            if (my_tabs + 1 != a.ncols) atomicMin(&a.st->bad_row, row);       // ConvertToZDW.cpp:336-337
+                            const uint64_t rl = p - my_row_start + 1;
+                            if (rl >= FIRST_ROW_CAP - 1) {                                     // may grow m_LongestLine
+                                const uint32_t li = atomicAdd(&a.st->long_count, 1u);
+                                if (li < a.long_cap) { a.long_rows[li].start = my_row_start; a.long_rows[li].len = rl; }
+                            }
+                            if (row == a.row_limit) a.st->split_pos = my_row_start;
+                        }
+                    }
+                    if (is_term) { my_tabs = 0; my_row_start = p + 1; my_ignore = false; }
+                    else if (is_tab) ++my_tabs;
+                }
+
+                // lane 63 now holds the state at the end of the round
+                st_row_start = bcast64(my_row_start, 63);
+                st_tabs = bcast32(my_tabs, 63);
+                st_rows = bcast32(my_rows, 63);
+                st_ignore = bcast32(my_ignore ? 1u : 0u, 63) != 0;
+                prev_term = (term[3] >> 63) & 1ull;
+                q_tail += nbnd_total;
+            }
 
             __syncthreads();
             while (q_tail - q_head >= 64) {
                 consume(a, rs, ring, q_head, 64, lane);
                 q_head += 64;
             }
+            if (q_head >= QCAP * 4096u) { q_head -= QCAP * 4096u; q_tail -= QCAP * 4096u; }   // keep (index % QCAP) exact
             __syncthreads();
         }
     }

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -73,7 +74,7 @@ struct zdw_ctx {
     DevBuf d_kind, d_recoff, d_numidx;
     bool trim = false;
     uint32_t row_cap = FIRST_ROW_CAP;      // emulated m_LongestLine, persists across blocks
-    uint64_t slots_opt = 0;
+    uint64_t slots_opt = 0, slots_learned = 0;
     // input image
     const uint8_t *d_in = nullptr;
     uint64_t n = 0;
@@ -574,11 +575,14 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
 
     // ---- pass 1 proper (also runs for zero rows when a partial row pollutes the block) ----
     const bool lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) <= 20 * 1024;
+    // dictionary table: one slot per 16 input bytes (load factor limit 1/2 => up to one new string per
+    // 32 bytes of TSV before a retry), within [2^16, 2^27]; a context remembers what its last block needed
     uint64_t nslots = c->slots_opt;
     if (!nslots) {
         nslots = 1ull << 16;
-        const uint64_t want = (hi > lo ? hi - lo : 0) / 4;
-        while (nslots < want && nslots < (1ull << 22)) nslots <<= 1;
+        const uint64_t want = (hi > lo ? hi - lo : 0) / 16;
+        while (nslots < want && nslots < (1ull << 27)) nslots <<= 1;
+        if (c->slots_learned > nslots) nslots = c->slots_learned;
     }
     { uint64_t p2 = 1; while (p2 < nslots) p2 <<= 1; nslots = p2; }
     HIP_TRY(c, c->col_min.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_max.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_seen.ensure(c->ncols + 8));
@@ -612,6 +616,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             a.slots = c->slots.as<uint64_t>(); a.slot_len = c->slot_len.as<uint32_t>(); a.slot_mask = nslots - 1;
             a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 2, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
+            if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
             launch_pass1(a, s);
         }
@@ -624,6 +629,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         if (attempt > 6) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
     }
     res->table_slots = nslots;
+    c->slots_learned = nslots;
     res->dict_entries = st.entries;
 
     if (st.bad_row != 0xFFFFFFFFu && st.bad_row <= row_limit) {          // ConvertToZDW.cpp:810-812
@@ -836,7 +842,7 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
     }
     launch_dict_lengths(c->order.as<uint32_t>(), c->extra_lens.as<uint32_t>(), count, c->lenp1.as<uint32_t>(), s);
     launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count, c->scan_tmp.p, nullptr, s);
-    launch_import_strings(c->d_in, c->extra.as<uint8_t>(), c->extra_lens.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count,
+    launch_import_strings(c->d_in, c->n, c->extra.as<uint8_t>(), c->extra_lens.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count,
                           c->slots.as<uint64_t>(), c->slot_len.as<uint32_t>(), c->nslots - 1,
                           (uint32_t)std::min<uint64_t>(c->nslots - c->nslots / 8, 0xFFFFFFF0ull), c->trim ? 1u : 0u, c->hi,
                           c->status.as<P1Status>(), s);

@@ -13,6 +13,21 @@ __device__ __forceinline__ const uint8_t *string_at(const uint8_t *in, const uin
     return pos >= EXTRA_BASE ? extra + (pos - EXTRA_BASE) : in + pos;
 }
 
+// ---- unaligned 8-byte window reads (gfx950 runs in unaligned access mode: one global_load_dwordx2) ----
+struct __attribute__((packed)) PackedU64 { uint64_t v; };
+__device__ __forceinline__ uint64_t load8(const uint8_t *p) { return reinterpret_cast<const PackedU64 *>(p)->v; }
+// the next `want` (1..8) bytes at p as a little-endian word, upper bytes zero; never touches `end` or beyond
+__device__ __forceinline__ uint64_t load_upto8(const uint8_t *p, uint32_t want, const uint8_t *end)
+{
+    if (p + 8 <= end) {
+        const uint64_t w = load8(p);
+        return want >= 8 ? w : (w & ((1ull << (8 * want)) - 1ull));
+    }
+    uint64_t w = 0;
+    for (uint32_t k = 0; k < want; ++k) w |= (uint64_t)p[k] << (8 * k);
+    return w;
+}
+
 // Does the stored occurrence at position `pos` (same first `len` bytes as the candidate) END after
 // `len` bytes?  Imported strings are NUL terminated.  In the TSV image the next byte must be the
 // field's separator; it is a separator iff the run of backslashes before it is even, and that run is
@@ -33,17 +48,27 @@ __device__ inline bool stored_ends_here(const uint8_t *in, const uint8_t *extra,
 
 // Insert-or-find in the block dictionary table.  slot word = tag(24) | position+1 (40); 0 = empty.
 // Returns slot index + 1, or 0 when the table is too full (caller retries with more slots).
-__device__ inline uint32_t dict_insert(const uint8_t *in, const uint8_t *extra, uint64_t hi, uint64_t *slots, uint32_t *slot_len,
-                                       uint64_t slot_mask, uint32_t max_entries, P1Status *st, uint64_t pos, uint32_t len,
-                                       bool trim)
+// `n` = allocation size of the TSV image (reads never reach it); imported strings sit in a buffer
+// with >= 16 bytes of slack.
+__device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
+                                       uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, P1Status *st, uint64_t pos,
+                                       uint32_t len, bool trim)
 {
     const uint8_t *p = string_at(in, extra, pos);
-    uint64_t h = 0xcbf29ce484222325ull;
-    for (uint32_t i = 0; i < len; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
-    h = mix64(h ^ len);
-    uint32_t nbs = 0;
-    while (nbs < len && p[len - 1 - nbs] == '\\') ++nbs;
-    const bool tail_bs_odd = nbs & 1u;
+    const uint8_t *p_end = pos >= EXTRA_BASE ? p + len + 16 : in + n;
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
+    for (uint32_t i = 0; i < len; i += 8) {
+        const uint64_t w = load_upto8(p + i, len - i < 8 ? len - i : 8u, p_end);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    h = mix64(h);
+    bool tail_bs_odd = false;
+    if (p[len - 1] == '\\') {
+        uint32_t nbs = 1;
+        while (nbs < len && p[len - 1 - nbs] == '\\') ++nbs;
+        tail_bs_odd = nbs & 1u;
+    }
     const uint64_t tag = h >> POS_BITS;
     const uint64_t mine = (tag << POS_BITS) | (pos + 1);
     uint64_t i = h & slot_mask;
@@ -66,9 +91,14 @@ __device__ inline uint32_t dict_insert(const uint8_t *in, const uint8_t *extra, 
             const bool stored_extra = sp >= EXTRA_BASE;
             bool same = stored_extra || sp + len < hi;
             if (same) {
+                // 8 bytes at a time.  An imported string shorter than `len` shows its NUL inside the
+                // compared window (the candidate holds no NUL), so the walk stops before leaving it.
                 const uint8_t *q = string_at(in, extra, sp);
-                for (uint32_t k = 0; k < len; ++k)
-                    if (q[k] != p[k] || (stored_extra && q[k] == 0)) { same = false; break; }   // never run past an imported string
+                const uint8_t *q_end = stored_extra ? q + len + 16 : in + n;
+                for (uint32_t k = 0; k < len; k += 8) {
+                    const uint32_t want = len - k < 8 ? len - k : 8u;
+                    if (load_upto8(q + k, want, stored_extra ? q + k + 8 : q_end) != load_upto8(p + k, want, p_end)) { same = false; break; }
+                }
             }
             if (same && stored_ends_here(in, extra, sp, len, hi, trim, tail_bs_odd)) return (uint32_t)i + 1;
         }
@@ -77,7 +107,6 @@ __device__ inline uint32_t dict_insert(const uint8_t *in, const uint8_t *extra, 
     st->overflow = 1;
     return 0;
 }
-
 
 // big-endian 8-byte sort key of bytes [8*depth, 8*depth+8) of a string, zero padded.  Strings hold
 // no NUL byte, so zero padding orders a shorter prefix first, like strcmp (dictionary.h:30-35).

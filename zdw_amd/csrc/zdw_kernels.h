@@ -42,6 +42,7 @@ struct Pass1Args {
     uint64_t *col_min; uint64_t *col_max; uint8_t *col_seen;
     P1Status *st;
     LongRow *long_rows; uint32_t long_cap;
+    uint32_t debug_skip;                  // profiling only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary, 4 no integer parse, 8 no rec stores
 };
 
 struct Pass2Args {
@@ -93,7 +94,7 @@ void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64
 void launch_dict_emit(const uint8_t *in, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
                       const uint32_t *uniq_len, const uint32_t *uniq_slot, const uint64_t *off_excl, uint64_t n,
                       uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *slot_off, hipStream_t s);
-void launch_import_strings(const uint8_t *in, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
+void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
                            uint64_t *slots, uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim,
                            uint64_t hi, P1Status *st, hipStream_t s);
 void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
