@@ -364,8 +364,13 @@ __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint6
                                                          uint64_t hi, P1Status *st)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    dict_insert(in, n, extra, hi, slots, slot_len, slot_mask, max_entries, st, EXTRA_BASE + offs[i], lens[i], trim != 0);
+    bool is_new = false;
+    if (i < count) dict_insert(in, n, extra, hi, slots, slot_len, slot_mask, st, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
+    const uint64_t m = __ballot(is_new);
+    if (m && lane_id() == 0) {
+        const uint32_t total = atomicAdd(&st->entries, popc64(m)) + popc64(m);
+        if (total > max_entries) st->overflow = 1;
+    }
 }
 
 void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,

@@ -269,7 +269,8 @@ __device__ __forceinline__ void range_update(const RangeSink &r, uint32_t idx, u
     if (v > r.mx[idx]) atomicMax(reinterpret_cast<unsigned long long *>(&r.mx[idx]), (unsigned long long)v);
 }
 
-__device__ inline void process_field(const Pass1Args &a, const RangeSink &rs, uint64_t fs, uint32_t len, uint32_t col, uint32_t row)
+__device__ inline void process_field(const Pass1Args &a, const RangeSink &rs, uint64_t fs, uint32_t len, uint32_t col, uint32_t row,
+                                     bool &is_new)
 {
     const bool in_block = row < a.row_limit;
     if (!in_block && !(row == a.row_limit && col < a.partial_fields)) return;
@@ -282,7 +283,7 @@ __device__ inline void process_field(const Pass1Args &a, const RangeSink &rs, ui
         if (len) {                                                    // empty fields are skipped (:340-341)
             if (!rs.seen[col]) rs.seen[col] = 1;
             if (!(a.debug_skip & 2u))
-                id = dict_insert(a.in, a.n, a.extra, a.hi, a.slots, a.slot_len, a.slot_mask, a.max_entries, a.st, fs, len, a.trim);
+                id = dict_insert(a.in, a.n, a.extra, a.hi, a.slots, a.slot_len, a.slot_mask, a.st, fs, len, a.trim, is_new);
         }
         if (in_block && !(a.debug_skip & 8u)) *reinterpret_cast<uint32_t *>(recp) = id;
         return;
@@ -316,9 +317,11 @@ __device__ __forceinline__ uint4 make_entry(uint64_t end, uint32_t col, uint32_t
 }
 __device__ __forceinline__ uint64_t entry_end(const uint4 &e) { return ((uint64_t)(e.y & 0xffu) << 32) | e.x; }
 
-__device__ __forceinline__ void consume(const Pass1Args &a, const RangeSink &rs, const uint4 *ring, uint32_t head, uint32_t count,
-                                        uint32_t lane)
+// returns how many new dictionary entries the batch created
+__device__ __forceinline__ uint32_t consume(const Pass1Args &a, const RangeSink &rs, const uint4 *ring, uint32_t head, uint32_t count,
+                                            uint32_t lane)
 {
+    bool is_new = false;
     if (lane < count) {
         const uint4 e = ring[(head + lane) % QCAP];
         const uint32_t col = e.y >> 8;
@@ -326,9 +329,10 @@ __device__ __forceinline__ void consume(const Pass1Args &a, const RangeSink &rs,
             const uint4 pe = ring[(head + lane + QCAP - 1) % QCAP];
             // positions are 40-bit; the predecessor's end + 1 is where this field begins
             const uint64_t fs = (entry_end(pe) + 1) & POS_MASK;
-            process_field(a, rs, fs, (uint32_t)(entry_end(e) - fs), col, e.z);
+            process_field(a, rs, fs, (uint32_t)(entry_end(e) - fs), col, e.z, is_new);
         }
     }
+    return popc64(__ballot(is_new));
 }
 
 size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds)
@@ -357,12 +361,20 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
     __syncthreads();
 
     uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running (kept small enough for % QCAP to stay exact)
+    uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
     for (uint32_t si = blockIdx.x; si < a.nspans; si += gridDim.x) {
         const uint32_t rowbase = a.span_rowbase[si];
         if (a.span_rowbase[si + 1] == rowbase) continue;          // no row starts in this span
         if (rowbase > a.row_limit) break;                         // later spans hold rows of later blocks only
         if (__hip_atomic_load(&a.st->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (new_entries >= 128) {        // publish this wave's inserts in bulk; stop everybody once the table is half full
+            uint32_t seen_total = 0;
+            if (lane == 0) seen_total = atomicAdd(&a.st->entries, new_entries) + new_entries;
+            seen_total = bcast32(seen_total, 0);
+            new_entries = 0;
+            if (seen_total >= a.max_entries) { if (lane == 0) a.st->overflow = 1; break; }
+        }
         const uint64_t s0 = (a.span0 + si) * (uint64_t)SPAN_BYTES;
         const uint64_t ss = s0 > a.lo ? s0 : a.lo;
         const uint64_t se = s0 + SPAN_BYTES < a.hi ? s0 + SPAN_BYTES : a.hi;
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
 
             __syncthreads();
             while (q_tail - q_head >= 64) {
-                consume(a, rs, ring, q_head, 64, lane);
+                new_entries += consume(a, rs, ring, q_head, 64, lane);
                 q_head += 64;
             }
             if (q_head >= QCAP * 4096u) { q_head -= QCAP * 4096u; q_tail -= QCAP * 4096u; }   // keep (index % QCAP) exact
@@ -527,8 +539,12 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
         }
     }
     __syncthreads();
-    if (q_tail != q_head) consume(a, rs, ring, q_head, q_tail - q_head, lane);
+    if (q_tail != q_head) new_entries += consume(a, rs, ring, q_head, q_tail - q_head, lane);
     __syncthreads();
+    if (new_entries && lane == 0) {
+        const uint32_t total = atomicAdd(&a.st->entries, new_entries) + new_entries;
+        if (total > a.max_entries) a.st->overflow = 1;
+    }
 
     if (rs.lds) {   // one flush per wave
         for (uint32_t c = lane; c < a.ncols; c += 64) {

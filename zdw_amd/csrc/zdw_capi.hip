@@ -578,6 +578,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     // dictionary table: one slot per 16 input bytes (load factor limit 1/2 => up to one new string per
     // 32 bytes of TSV before a retry), within [2^16, 2^27]; a context remembers what its last block needed
     uint64_t nslots = c->slots_opt;
+    if (const char *e = getenv("ZDW_DICT_SLOTS")) nslots = strtoull(e, nullptr, 10);   // experiments
     if (!nslots) {
         nslots = 1ull << 16;
         const uint64_t want = (hi > lo ? hi - lo : 0) / 16;

@@ -51,9 +51,11 @@ __device__ inline bool stored_ends_here(const uint8_t *in, const uint8_t *extra,
 // `n` = allocation size of the TSV image (reads never reach it); imported strings sit in a buffer
 // with >= 16 bytes of slack.
 __device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
-                                       uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, P1Status *st, uint64_t pos,
-                                       uint32_t len, bool trim)
+                                       uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len, bool trim,
+                                       bool &is_new)
 {
+    // The caller counts new entries per wave (is_new) and adds them to st->entries in bulk: one
+    // returning atomic per insert on a single counter serialises the whole chip (~70 M/s).
     const uint8_t *p = string_at(in, extra, pos);
     const uint8_t *p_end = pos >= EXTRA_BASE ? p + len + 16 : in + n;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
@@ -79,8 +81,7 @@ __device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint
             const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[i]), 0ull, (unsigned long long)mine);
             if (old == 0) {
                 slot_len[i] = len;
-                const uint32_t cnt = atomicAdd(&st->entries, 1u);
-                if (cnt >= max_entries) st->overflow = 1;
+                is_new = true;
                 return (uint32_t)i + 1;
             }
             w = old;
