@@ -49,12 +49,12 @@ __device__ __forceinline__ void raw_classify(uint32_t w, RawMasks &r)
 
 // Drops escaped tabs/newlines: special iff an even number of backslashes precedes.
 // bs_carry: the byte before this round is a backslash (in/out).
-__device__ __forceinline__ void resolve_escapes(const uint8_t *in, uint64_t lo, uint64_t pos, uint32_t lane, RawMasks &r, bool &bs_carry)
+__device__ __forceinline__ void resolve_escapes(const uint8_t *in, uint64_t lo, uint64_t pos, uint32_t lane, RawMasks &r, uint64_t &bs_carry)
 {
     uint64_t prevbs[4];
-    prevbs[0] = (r.bs[3] << 1) | (bs_carry ? 1ull : 0ull);
+    prevbs[0] = (r.bs[3] << 1) | bs_carry;
     prevbs[1] = r.bs[0]; prevbs[2] = r.bs[1]; prevbs[3] = r.bs[2];
-    bs_carry = (r.bs[3] >> 63) & 1ull;
+    bs_carry = r.bs[3] >> 63;
     uint64_t cand = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) cand |= (r.tab[k] | r.nl[k]) & prevbs[k];
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(64) void k_find_effective_end(const uint8_t *in, ui
     if (n > lo) {
         uint64_t pos = (n - 1) & ~(uint64_t)(ROUND_BYTES - 1);
         for (;;) {
-            const uint32_t w = load_dword_guarded(in, pos + 4ull * lane, n);
-            bool bs_carry = pos > lo && in[pos - 1] == '\\';
+            const uint32_t w = load_round_dword(in, pos, lane, n);
+            uint64_t bs_carry = (pos > lo && in[pos - 1] == '\\') ? 1ull : 0ull;
             RawMasks r;
             raw_classify(w, r);
             resolve_escapes(in, lo, pos, lane, r, bs_carry);
@@ -133,14 +133,17 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
         uint32_t count = 0;
         uint64_t nul = 0;
         if (ss < se) {
-            bool prev_term = (ss == lo) || is_row_terminator(in, lo, ss - 1);
+            uint64_t prev_term = ((ss == lo) || is_row_terminator(in, lo, ss - 1)) ? 1ull : 0ull;
             const uint64_t pos0 = ss & ~(uint64_t)(ROUND_BYTES - 1);
-            bool bs_carry = pos0 > lo && in[pos0 - 1] == '\\';
+            uint64_t bs_carry = (pos0 > lo && in[pos0 - 1] == '\\') ? 1ull : 0ull;
+            uint32_t nq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nq[q] = load_round_dword(in, pos0 + (uint64_t)q * ROUND_BYTES, lane, n);
             for (uint64_t pos = pos0; pos < se; pos += 4 * ROUND_BYTES) {
-                // four rounds of loads in flight before the first is looked at
+                // the next four rounds are requested before the current four are looked at
                 uint32_t wq[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) wq[q] = load_dword_guarded(in, pos + (uint64_t)q * ROUND_BYTES + 4ull * lane, n);
+                for (int q = 0; q < 4; ++q) { wq[q] = nq[q]; nq[q] = load_round_dword(in, pos + (uint64_t)(q + 4) * ROUND_BYTES, lane, n); }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint64_t rpos = pos + (uint64_t)q * ROUND_BYTES;
@@ -150,10 +153,10 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
                     resolve_escapes(in, lo, rpos, lane, r, bs_carry);
                     if (rpos >= ss && rpos + ROUND_BYTES <= se) {
                         // interior round: every byte counts
-                        const uint64_t pt0 = (r.nl[3] << 1) | (prev_term ? 1ull : 0ull);
+                        const uint64_t pt0 = (r.nl[3] << 1) | prev_term;
                         count += popc64(pt0 & ~r.nl[0]) + popc64(r.nl[0] & ~r.nl[1]) + popc64(r.nl[1] & ~r.nl[2]) + popc64(r.nl[2] & ~r.nl[3]);
                         nul |= r.nul;
-                        prev_term = (r.nl[3] >> 63) & 1ull;
+                        prev_term = r.nl[3] >> 63;
                     } else {
                         // first / last round of the span: only positions in [ss, se) exist
                         const uint32_t rel_lo = ss > rpos ? (uint32_t)(ss - rpos) : 0u;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
 #pragma unroll
                         for (int k = 0; k < 4; ++k) z |= __builtin_amdgcn_inverse_ballot_w64(vm[k]) && ((w >> (8 * k)) & 0xffu) == 0u;
                         nul |= __ballot(z);
-                        prev_term = (nl[3] >> 63) & 1ull;
+                        prev_term = nl[3] >> 63;
                     }
                 }
             }
@@ -315,6 +318,18 @@ __device__ __forceinline__ uint4 make_entry(uint64_t end, uint32_t col, uint32_t
     e.w = 0;
     return e;
 }
+// same, from the low word and bits 39:32 of the position (a round never straddles a 4 GiB line,
+// so the low word of pos + 4*lane + k is a plain 32-bit add)
+__device__ __forceinline__ uint4 make_entry32(uint32_t end_lo, uint32_t end_hi8, uint32_t col, uint32_t row)
+{
+    uint4 e;
+    e.x = end_lo;
+    e.y = end_hi8 | (col << 8);
+    e.z = row;
+    e.w = 0;
+    return e;
+}
+__device__ __forceinline__ uint32_t ring_next(uint32_t i) { return i + 1 == QCAP ? 0u : i + 1; }
 __device__ __forceinline__ uint64_t entry_end(const uint4 &e) { return ((uint64_t)(e.y & 0xffu) << 32) | e.x; }
 
 // returns how many new dictionary entries the batch created
@@ -384,17 +399,33 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
         uint64_t st_row_start = ss;
         uint32_t st_tabs = 0, st_rows = 0;
         bool st_ignore = !at_row_start;      // the row open at ss began in an earlier span
-        bool prev_term = at_row_start;
+        uint64_t prev_term = at_row_start ? 1ull : 0ull;
         uint64_t pos = ss & ~(uint64_t)(ROUND_BYTES - 1);
-        bool bs_carry = pos > a.lo && a.in[pos - 1] == '\\';
+        uint64_t bs_carry = (pos > a.lo && a.in[pos - 1] == '\\') ? 1ull : 0ull;
         bool first = true, done = false;
 
         // anchor: the first field of this visit starts at ss
         if (lane == 0) ring[q_tail % QCAP] = make_entry((ss - 1) & POS_MASK, COL_SKIP, 0);
         q_tail += 1;
 
-        for (; !done && pos < a.hi; pos += ROUND_BYTES) {
-            const uint32_t w = load_dword_guarded(a.in, pos + 4ull * lane, a.n);
+        // four rounds of input in flight: the dword of round r+4 is requested while round r is classified
+        // Input arrives in groups of four rounds (1 KiB per wave): the next group is requested before the
+        // current one is looked at, so its HBM latency hides behind four rounds of work.
+        uint32_t n0 = load_round_dword(a.in, pos, lane, a.n);
+        uint32_t n1 = load_round_dword(a.in, pos + 1 * ROUND_BYTES, lane, a.n);
+        uint32_t n2 = load_round_dword(a.in, pos + 2 * ROUND_BYTES, lane, a.n);
+        uint32_t n3 = load_round_dword(a.in, pos + 3 * ROUND_BYTES, lane, a.n);
+        for (uint64_t gpos = pos; !done && gpos < a.hi; gpos += 4 * ROUND_BYTES) {
+          const uint32_t c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+          n0 = load_round_dword(a.in, gpos + 4 * ROUND_BYTES, lane, a.n);
+          n1 = load_round_dword(a.in, gpos + 5 * ROUND_BYTES, lane, a.n);
+          n2 = load_round_dword(a.in, gpos + 6 * ROUND_BYTES, lane, a.n);
+          n3 = load_round_dword(a.in, gpos + 7 * ROUND_BYTES, lane, a.n);
+#pragma unroll 1
+          for (uint32_t j = 0; j < 4 && !done; ++j) {
+            pos = gpos + (uint64_t)j * ROUND_BYTES;
+            if (pos >= a.hi) break;
+            const uint32_t w = j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
             RawMasks r;
             raw_classify(w, r);
             resolve_escapes(a.in, a.lo, pos, lane, r, bs_carry);
@@ -402,18 +433,21 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
             const bool interior = !first && pos + ROUND_BYTES <= se - 1;     // wholly inside the span, not its last byte
             if (interior && (r.nl[0] | r.nl[1] | r.nl[2] | r.nl[3]) == 0ull) {
                 // ---------- short path: no row terminator in this round ----------
-                if (prev_term) { st_rows += 1; st_row_start = pos; prev_term = false; }
+                if (prev_term) { st_rows += 1; st_row_start = pos; prev_term = 0; }
                 const uint32_t before = mbcnt64(r.tab[0]) + mbcnt64(r.tab[1]) + mbcnt64(r.tab[2]) + mbcnt64(r.tab[3]);
-                uint32_t col = st_tabs + before;
-                uint32_t qi = q_tail + before;
+                uint32_t col = st_ignore ? COL_SKIP : st_tabs + before;      // COL_SKIP + small stays >= ncols
+                uint32_t qi = (q_tail + before) % QCAP;
                 const uint32_t row = rowbase + st_rows - 1;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(r.tab[k])) {
-                        const uint32_t c = (st_ignore || col >= a.ncols) ? COL_SKIP : col;
-                        ring[qi % QCAP] = make_entry(pos + 4ull * lane + k, c, row);
-                        ++qi; ++col;
-                    }
+                const uint32_t lane_lo = (uint32_t)pos + 4u * lane, pos_hi8 = (uint32_t)(pos >> 32) & 0xffu;
+                // this lane's tabs as a 4-bit set; lanes loop over their own (0.4 per lane on average)
+                uint32_t mine = (__builtin_amdgcn_inverse_ballot_w64(r.tab[0]) ? 1u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(r.tab[1]) ? 2u : 0u) |
+                                (__builtin_amdgcn_inverse_ballot_w64(r.tab[2]) ? 4u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(r.tab[3]) ? 8u : 0u);
+                while (mine) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(mine);
+                    mine &= mine - 1;
+                    ring[qi] = make_entry32(lane_lo + k, pos_hi8, col >= a.ncols ? COL_SKIP : col, row);
+                    qi = ring_next(qi);
+                    ++col;
                 }
                 const uint32_t total = popc64(r.tab[0]) + popc64(r.tab[1]) + popc64(r.tab[2]) + popc64(r.tab[3]);
                 st_tabs += total;
@@ -454,7 +488,7 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
                 if (first) {
                     if (prev_term) pt[rel_lo & 3] |= 1ull << (rel_lo >> 2);
                     first = false;
-                } else if (prev_term) pt[0] |= 1ull;
+                } else pt[0] |= prev_term;
 
                 uint64_t bnd[4], blank[4], start[4];
                 uint32_t nbnd_before = 0, nstart_before = 0, ntab_before = 0, nbnd_total = 0;
@@ -525,17 +559,18 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
                 st_tabs = bcast32(my_tabs, 63);
                 st_rows = bcast32(my_rows, 63);
                 st_ignore = bcast32(my_ignore ? 1u : 0u, 63) != 0;
-                prev_term = (term[3] >> 63) & 1ull;
+                prev_term = term[3] >> 63;
                 q_tail += nbnd_total;
             }
 
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();      // one wave per workgroup: LDS operations of a wave execute in order
             while (q_tail - q_head >= 64) {
                 new_entries += consume(a, rs, ring, q_head, 64, lane);
                 q_head += 64;
             }
             if (q_head >= QCAP * 4096u) { q_head -= QCAP * 4096u; q_tail -= QCAP * 4096u; }   // keep (index % QCAP) exact
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
+          }
         }
     }
     __syncthreads();

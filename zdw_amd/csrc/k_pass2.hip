@@ -15,15 +15,25 @@
 
 namespace zdw {
 
+// what pass 1 left for (row, used column u): table slot id + 1 (text) or the parsed value (numeric)
+__device__ __forceinline__ uint64_t raw_value(const Pass2Args &a, uint32_t row, uint32_t off, bool text)
+{
+    const uint8_t *p = a.rec + (uint64_t)row * a.rec_stride + off;
+    return text ? (uint64_t)*reinterpret_cast<const uint32_t *>(p) : *reinterpret_cast<const uint64_t *>(p);
+}
+// the value the file stores for it: dictionary offset (ConvertToZDW.cpp:528-531) or value - base
+// (:543-547, :564-566).  The mapping is injective per column (distinct strings have distinct offsets,
+// v -> v - base is one-to-one, 0 <-> empty), so "differs from the previous row" can be decided on the
+// raw values and the dictionary gather is only paid for values that are actually written.
+__device__ __forceinline__ uint64_t stored_from_raw(const Pass2Args &a, uint64_t raw, uint32_t u, bool text)
+{
+    if (!raw) return 0ull;
+    return text ? (uint64_t)a.slot_off[(uint32_t)raw - 1] : raw - a.used_base[u];
+}
 __device__ __forceinline__ uint64_t stored_value(const Pass2Args &a, uint32_t row, uint32_t u)
 {
-    const uint8_t *p = a.rec + (uint64_t)row * a.rec_stride + a.used_recoff[u];
-    if (a.used_kind[u] == K_TEXT) {
-        const uint32_t id = *reinterpret_cast<const uint32_t *>(p);
-        return id ? (uint64_t)a.slot_off[id - 1] : 0ull;            // ConvertToZDW.cpp:528-531
-    }
-    const uint64_t v = *reinterpret_cast<const uint64_t *>(p);
-    return v ? v - a.used_base[u] : 0ull;                           // :543-547, :564-566
+    const bool text = a.used_kind[u] == K_TEXT;
+    return stored_from_raw(a, raw_value(a, row, a.used_recoff[u], text), u, text);
 }
 
 template <uint32_t G, bool EMIT>
@@ -43,14 +53,17 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
     for (uint32_t u0 = 0; u0 < a.nused; u0 += G) {
         const uint32_t u = u0 + sub;
         const bool ok = row_ok && u < a.nused;
-        uint64_t cur = 0, prev = 0;
+        uint64_t cur = 0;
         uint32_t sz = 0;
+        bool flag = false, text = false;
         if (ok) {
-            cur = stored_value(a, row, u);
-            prev = row ? stored_value(a, row - 1, u) : a.prev0[u];
+            text = a.used_kind[u] == K_TEXT;
+            const uint32_t off = a.used_recoff[u];
+            cur = raw_value(a, row, off, text);
             sz = a.used_size[u];
+            if (row) flag = cur != raw_value(a, row - 1, off, text);
+            else flag = stored_from_raw(a, cur, u, text) != a.prev0[u];      // the halo row arrives as stored values
         }
-        const bool flag = ok && cur != prev;
         const uint32_t mine = flag ? sz : 0u;
         // inclusive prefix over the G lanes of the group
         uint32_t inc = mine;
@@ -68,8 +81,9 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
             if (row_ok && sub < FB && u0 + 8 * sub < a.nused)
                 a.out[out_row + (u0 >> 3) + sub] = (uint8_t)(bits >> (8 * sub));
             if (flag) {
+                const uint64_t v = stored_from_raw(a, cur, u, text);
                 uint8_t *q = a.out + out_row + nflag + running + (inc - mine);
-                for (uint32_t j = 0; j < sz; ++j) q[j] = (uint8_t)(cur >> (8 * j));   // little-endian truncating store
+                for (uint32_t j = 0; j < sz; ++j) q[j] = (uint8_t)(v >> (8 * j));     // little-endian truncating store
             }
         }
         running += tot;

@@ -73,6 +73,19 @@ __device__ __forceinline__ uint32_t load_dword_guarded(const uint8_t *in, uint64
     return w;
 }
 
+// One round's dword for this lane, branch-free.  Lanes whose dword would start at or past the end of
+// the allocation read the last dword that starts inside it instead (an aligned dword whose first byte
+// is inside an allocation never leaves its page); their bytes lie past `hi` and are masked by callers.
+__device__ __forceinline__ uint32_t load_round_dword(const uint8_t *in, uint64_t pos, uint32_t lane, uint64_t n)
+{
+    const uint64_t last = (n - 1) & ~3ull;                    // n > 0
+    const uint64_t base = pos <= last ? pos : last;            // wave-uniform
+    const uint64_t room = last - base;
+    const uint32_t maxoff = room < ROUND_BYTES - 4 ? (uint32_t)room : ROUND_BYTES - 4;
+    const uint32_t off = 4u * lane < maxoff ? 4u * lane : maxoff;
+    return *reinterpret_cast<const uint32_t *>(in + base + off);
+}
+
 // number of consecutive backslashes directly before position p, never looking below lo
 __device__ inline uint32_t backslashes_before(const uint8_t *in, uint64_t lo, uint64_t p)
 {
@@ -84,56 +97,6 @@ __device__ inline uint32_t backslashes_before(const uint8_t *in, uint64_t lo, ui
 __device__ inline bool is_row_terminator(const uint8_t *in, uint64_t lo, uint64_t p)
 {
     return in[p] == '\n' && (backslashes_before(in, lo, p) & 1u) == 0;
-}
-
-// ------------------------------------------------------------------------------------------
-// One classification round: 256 bytes starting at `pos` (a multiple of 4 from the buffer start),
-// lane l holds dword w = bytes pos+4l .. pos+4l+3.  Produces wave-uniform lane masks
-//     tab[k] / nl[k] : byte k of lane l is an UNESCAPED tab / newline at a position in [vlo, vhi)
-// (a tab/newline is special iff an even number of backslashes precedes it).
-// bs_carry: byte pos-1 is a backslash (in/out, for the next round).
-// ------------------------------------------------------------------------------------------
-struct RoundMasks {
-    uint64_t tab[4];
-    uint64_t nl[4];
-    uint64_t nul;     // any NUL byte at a valid position
-};
-
-__device__ inline void classify_round(const uint8_t *in, uint64_t lo, uint64_t vlo, uint64_t vhi, uint64_t pos,
-                                      uint32_t w, uint32_t lane, bool &bs_carry, RoundMasks &m)
-{
-    uint64_t bs[4];
-    uint64_t nul = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t b = (w >> (8 * k)) & 0xffu;
-        const uint64_t p = pos + 4ull * lane + k;
-        const bool in_block = p >= lo && p < vhi;        // backslashes count from the block start on
-        const bool valid = p >= vlo && p < vhi;
-        bs[k] = __ballot(in_block && b == '\\');
-        m.tab[k] = __ballot(valid && b == '\t');
-        m.nl[k] = __ballot(valid && b == '\n');
-        nul |= __ballot(valid && b == 0);
-    }
-    m.nul = nul;
-    uint64_t prevbs[4];
-    prevbs[0] = (bs[3] << 1) | (bs_carry ? 1ull : 0ull);
-    prevbs[1] = bs[0]; prevbs[2] = bs[1]; prevbs[3] = bs[2];
-    bs_carry = (bs[3] >> 63) & 1ull;
-    uint64_t cand = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) cand |= (m.tab[k] | m.nl[k]) & prevbs[k];
-    if (cand) {   // wave-uniform: some special byte follows a backslash -> count the run exactly
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint64_t ck = (m.tab[k] | m.nl[k]) & prevbs[k];
-            bool esc = false;
-            if ((ck >> lane) & 1ull) esc = backslashes_before(in, lo, pos + 4ull * lane + k) & 1u;
-            const uint64_t e = __ballot(esc);
-            m.tab[k] &= ~e;
-            m.nl[k] &= ~e;
-        }
-    }
 }
 
 // 64-bit FNV-style hash over a byte range, finished with an avalanche; only used inside the

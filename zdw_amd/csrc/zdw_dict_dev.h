@@ -28,20 +28,18 @@ __device__ __forceinline__ uint64_t load_upto8(const uint8_t *p, uint32_t want, 
     return w;
 }
 
-// Does the stored occurrence at position `pos` (same first `len` bytes as the candidate) END after
-// `len` bytes?  Imported strings are NUL terminated.  In the TSV image the next byte must be the
-// field's separator; it is a separator iff the run of backslashes before it is even, and that run is
-// the candidate's own trailing run (identical bytes), so its parity is passed in.  With -t the stored
-// raw field may carry trailing blanks before its separator.
-__device__ inline bool stored_ends_here(const uint8_t *in, const uint8_t *extra, uint64_t pos, uint32_t len, uint64_t hi,
-                                        bool trim, bool tail_bs_odd)
+// Does the stored occurrence at image position `pos` (same first `len` bytes as the candidate) END
+// after `len` bytes?  The next byte must be the field's separator; it is a separator iff the run of
+// backslashes before it is even, and that run is the candidate's own trailing run (identical bytes),
+// so its parity is passed in.  With -t the stored raw field may carry trailing blanks before its
+// separator.  `next` is the byte at pos+len when the caller already holds it (else < 0).
+__device__ inline bool stored_ends_here(const uint8_t *in, uint64_t pos, uint32_t len, uint64_t hi, bool trim, bool tail_bs_odd, int next)
 {
-    if (pos >= EXTRA_BASE) return extra[pos - EXTRA_BASE + len] == 0;
     uint64_t q = pos + len;
-    bool blanks = false;
-    if (trim) while (q < hi && in[q] == ' ') { ++q; blanks = true; }
     if (q >= hi) return false;
-    const uint8_t b = in[q];
+    uint32_t b = next >= 0 ? (uint32_t)next : in[q];
+    bool blanks = false;
+    if (trim) while (b == ' ') { ++q; blanks = true; if (q >= hi) return false; b = in[q]; }
     if (b != '\t' && b != '\n') return false;
     return blanks || !tail_bs_odd;
 }
@@ -49,7 +47,8 @@ __device__ inline bool stored_ends_here(const uint8_t *in, const uint8_t *extra,
 // Insert-or-find in the block dictionary table.  slot word = tag(24) | position+1 (40); 0 = empty.
 // Returns slot index + 1, or 0 when the table is too full (caller retries with more slots).
 // `n` = allocation size of the TSV image (reads never reach it); imported strings sit in a buffer
-// with >= 16 bytes of slack.
+// with >= 16 bytes of slack.  Memory round trips on the common path: the candidate's first 16
+// bytes (kept in registers for the compare), the slot word, the stored string's words.
 __device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
                                        uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len, bool trim,
                                        bool &is_new)
@@ -58,15 +57,20 @@ __device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint
     // returning atomic per insert on a single counter serialises the whole chip (~70 M/s).
     const uint8_t *p = string_at(in, extra, pos);
     const uint8_t *p_end = pos >= EXTRA_BASE ? p + len + 16 : in + n;
+    const uint64_t c0 = load_upto8(p, len < 8 ? len : 8u, p_end);
+    const uint64_t c1 = len > 8 ? load_upto8(p + 8, len - 8 < 8 ? len - 8 : 8u, p_end) : 0ull;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
-    for (uint32_t i = 0; i < len; i += 8) {
-        const uint64_t w = load_upto8(p + i, len - i < 8 ? len - i : 8u, p_end);
-        h = (h ^ w) * 0xff51afd7ed558ccdull;
+    h = (h ^ c0) * 0xff51afd7ed558ccdull; h ^= h >> 32;
+    uint64_t last = c0;
+    if (len > 8) { h = (h ^ c1) * 0xff51afd7ed558ccdull; h ^= h >> 32; last = c1; }
+    for (uint32_t i = 16; i < len; i += 8) {
+        last = load_upto8(p + i, len - i < 8 ? len - i : 8u, p_end);
+        h = (h ^ last) * 0xff51afd7ed558ccdull;
         h ^= h >> 32;
     }
     h = mix64(h);
     bool tail_bs_odd = false;
-    if (p[len - 1] == '\\') {
+    if (((last >> (8 * ((len - 1) & 7u))) & 0xffu) == '\\') {
         uint32_t nbs = 1;
         while (nbs < len && p[len - 1 - nbs] == '\\') ++nbs;
         tail_bs_odd = nbs & 1u;
@@ -89,19 +93,36 @@ __device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint
         if ((w >> POS_BITS) == tag) {
             const uint64_t sp = (w & POS_MASK) - 1;
             if (sp == pos) return (uint32_t)i + 1;
-            const bool stored_extra = sp >= EXTRA_BASE;
-            bool same = stored_extra || sp + len < hi;
-            if (same) {
-                // 8 bytes at a time.  An imported string shorter than `len` shows its NUL inside the
-                // compared window (the candidate holds no NUL), so the walk stops before leaving it.
-                const uint8_t *q = string_at(in, extra, sp);
-                const uint8_t *q_end = stored_extra ? q + len + 16 : in + n;
-                for (uint32_t k = 0; k < len; k += 8) {
+            if (sp >= EXTRA_BASE) {
+                // imported string (NUL terminated, >= 16 bytes of slack behind it): a shorter one shows
+                // its NUL inside the compared window, so the walk stops before leaving it
+                const uint8_t *q = extra + (sp - EXTRA_BASE);
+                bool same = true;
+                for (uint32_t k = 0; k < len && same; k += 8) {
                     const uint32_t want = len - k < 8 ? len - k : 8u;
-                    if (load_upto8(q + k, want, stored_extra ? q + k + 8 : q_end) != load_upto8(p + k, want, p_end)) { same = false; break; }
+                    const uint64_t m = want >= 8 ? ~0ull : ((1ull << (8 * want)) - 1ull);
+                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : load_upto8(p + k, want, p_end));
+                    same = (load8(q + k) & m) == cw;
                 }
+                if (same && q[len] == 0) return (uint32_t)i + 1;
+            } else if (sp + len < hi) {
+                const uint8_t *q = in + sp;
+                const uint8_t *q_end = in + n;
+                bool same = true;
+                int next = -1;                              // the stored byte right after the compared bytes, when it came along
+                for (uint32_t k = 0; k < len && same; k += 8) {
+                    const uint32_t want = len - k < 8 ? len - k : 8u;
+                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : load_upto8(p + k, want, p_end));
+                    if (q + k + 8 <= q_end) {
+                        const uint64_t sw = load8(q + k);
+                        if (want < 8) { same = (sw & ((1ull << (8 * want)) - 1ull)) == cw; next = (int)((sw >> (8 * want)) & 0xffu); }
+                        else same = sw == cw;
+                    } else {
+                        same = load_upto8(q + k, want, q_end) == cw;
+                    }
+                }
+                if (same && stored_ends_here(in, sp, len, hi, trim, tail_bs_odd, next)) return (uint32_t)i + 1;
             }
-            if (same && stored_ends_here(in, extra, sp, len, hi, trim, tail_bs_odd)) return (uint32_t)i + 1;
         }
         i = (i + 1) & slot_mask;
     }
