@@ -58,6 +58,22 @@ def cpu_baseline(desc, sample, cores_note=1):
                       % (mb, dt, len(sample) / max(1, out_bytes))}
 
 
+def pmc_traffic(kernel, nbytes):
+    """HBM bytes per launch of `kernel` from the latest committed rocprofv3 --pmc summary (profiles/), collected
+    in separate FETCH_SIZE / WRITE_SIZE passes of this same command and corrected as MI355X_MICROARCH.md says;
+    None when no summary matches this workload size."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if abs(d.get("input_bytes", 0) - nbytes) <= 0.02 * nbytes and kernel in d.get("kernels", {}):
+            best = (d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.basename(f))
+    return best if best else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +157,8 @@ def main():
         dom_ms = per[dom]
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         b_alg = 2 * nbytes + out_local
+        traffic, traffic_note = pmc_traffic({"pass1": "zdw::k_pass1", "scan_rows": "zdw::k_count_row_starts",
+                                             "pass2_emit": "void zdw::k_pass2<64u, true>", "pass2_size": "void zdw::k_pass2<64u, false>"}.get(dom), nbytes)
         res = {
             "metric": "TSV->ZDW encode throughput (input bytes / wall time, input resident in HBM, raw .zdw left in HBM)",
             "value": round(total_in / 1e6 / (dt / args.steps), 1), "unit": "MB/s",
@@ -152,7 +170,7 @@ def main():
                        "compression_ratio": round(nbytes / max(1, out_local), 3),
                        "parallelism": "one ZDW block row-sharded over %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": int(alg),
                          "whole_encode": {"b_alg": int(b_alg), "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1),
                                           "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}},
