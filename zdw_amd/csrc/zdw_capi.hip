@@ -649,7 +649,9 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             std::sort(lr.begin(), lr.end(), [](const LongRow &x, const LongRow &y) { return x.start < y.start; });
         }
         std::vector<uint8_t> rowbuf;
+        const uint64_t read_end = tripped ? st.split_pos : c->n;   // pass 1 reads rows up to and including the one at the split
         for (const LongRow &r : lr) {
+            if (r.start > read_end) continue;                      // belongs to a later block
             if (r.len <= (uint64_t)c->row_cap - 1) continue;      // fits the current buffer: no growth possible
             rowbuf.resize(r.len);
             HIP_TRY(c, hipMemcpy(rowbuf.data(), c->d_in + r.start, r.len, hipMemcpyDeviceToHost));
