@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--cols", type=int, default=200)
     ap.add_argument("--cpu-mb", type=float, default=200.0, help="size of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -91,12 +93,15 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- synthetic table, generated in HBM; rank r holds rows [r*R, (r+1)*R) ----
     table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local)
@@ -104,7 +109,9 @@ def main():
     buf, nbytes = table.generate(rank * rows_per_rank, rows_per_rank)
     torch.cuda.synchronize()
 
-    enc = capi.Encoder(table.types, device=local, dict_slots=(1 << 23) if world > 1 else 0)
+    # N > 1: every rank's table must hold the union of all ranks' strings (record ids are slot indices, so it
+    # cannot be regrown after pass 1): 2^27 slots = 1.6 GB, room for 67 M distinct strings
+    enc = capi.Encoder(table.types, device=local, dict_slots=(1 << 27) if world > 1 and args.gb >= 2 else ((1 << 23) if world > 1 else 0))
     enc.set_input_device(buf.data_ptr(), nbytes, keepalive=buf)
     enc.enable_timing(True)
 
@@ -151,7 +158,7 @@ def main():
         per = {k: round(v[0] / max(1, args.steps), 3) for k, v in stages.items() if v[1]}
         # dominant kernel: pass 1 (tokenise + dedupe + parse).  Algorithmic bytes per launch: one read of
         # the block's TSV (B_in); the whole encode is priced at 2*B_in + B_out.
-        dom = max((k for k in per if k not in ("h2d", "d2h")), key=lambda k: per[k])
+        dom = max((k for k in per if k in ("scan_rows", "pass1", "pass2_emit")), key=lambda k: per[k])
         alg = {"scan_rows": nbytes, "pass1": nbytes, "pass2_size": 0, "pass2_emit": rows_len, "dict_sort": 0,
                "dict_compact": 0, "dict_emit": dict_len}.get(dom, 0)
         dom_ms = per[dom]

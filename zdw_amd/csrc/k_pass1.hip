@@ -26,11 +26,13 @@
 #include "zdw_dict_dev.h"
 #include "zdw_field_dev.h"
 
+#include <cstdlib>
+
 namespace zdw {
 
 constexpr uint32_t WROUND = 1024;                 // bytes per wave round (16 per lane)
-constexpr uint32_t QCAP = 1152;                   // ring entries per wave: <= 63 pending + 2 anchor + <= 1024 new + the head's predecessor
-constexpr uint32_t P1_MAX_WAVES = 256 * 12;
+constexpr uint32_t QCAP = 640;                    // ring entries per wave; a round that does not fit is emitted in two half-wave pieces (<= 512 each)
+constexpr uint32_t P1_MAX_WAVES = 256 * 16;   // measured sweet spot on MI355X (8: -40 %, 24: -15 %)
 constexpr uint32_t COL_FIELD_MASK = 0x7FFFFFu;    // descriptor: y = pos[39:32] | col << 8 | ends_row << 31
 constexpr uint32_t COL_NONE = 0x7FFFFFu;          // boundary only (blank line, foreign row, anchor position)
 constexpr uint32_t COL_ANCHOR = 0x7FFFFEu;        // x = row index of the rows that follow
@@ -386,24 +388,47 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
                 }
             }
 
-            // emit this lane's boundaries
-            uint32_t qi = q_tail + nb_before;
-            if (qi >= QCAP) qi -= QCAP;
+            // emit this lane's boundaries.  The ring always keeps the head's predecessor, so it can take
+            // QCAP - 1 - pending new descriptors; a denser round is emitted as two half-wave pieces with the
+            // ring drained in between (each half holds <= 512 boundaries).
             const uint32_t lp_lo = (uint32_t)pos + 16u * lane, pos_hi8 = (uint32_t)(pos >> 32) & 0xffu;
             const bool lane_ign = st_ignore && (ft_lane < 0 || lane <= (uint32_t)ft_lane);
-            uint32_t bits = bnd;
-            while (bits) {
-                const uint32_t i = (uint32_t)__builtin_ctz(bits);
-                const uint32_t bit = bits & (0u - bits);
-                bits &= bits - 1;
-                const bool is_term = (nl & bit) != 0;
-                const bool ign = lane_ign && !(lane == (uint32_t)ft_lane && i > ft_bit);
-                uint32_t c = col < COL_ANCHOR ? col : COL_ANCHOR - 1;       // absurdly wide rows still count as "wrong"
-                uint32_t ends = is_term ? 0x80000000u : 0u;
-                if ((blank & bit) || ign) { c = COL_NONE; if (blank & bit) ends = 0; }
-                ring[qi] = make_uint2(lp_lo + i, pos_hi8 | (c << 8) | ends);
-                qi = ring_next(qi);
-                col = is_term ? 0u : col + 1;
+            const bool whole = q_count + nb_total <= QCAP - 1;
+            const uint32_t nb_half = bcast32(nb_before, 32);                  // boundaries in lanes 0..31
+            for (uint32_t piece = 0; piece < (whole ? 1u : 2u); ++piece) {
+                if (!whole) {
+                    __builtin_amdgcn_wave_barrier();
+                    while (q_count) {                                         // drain: batches of 64, then the rest
+                        const uint32_t cnt = q_count < 64 ? q_count : 64u;
+                        new_entries += consume(a, rs, ring, q_head, cnt, lane, row_cur);
+                        q_head += cnt;
+                        if (q_head >= QCAP) q_head -= QCAP;
+                        q_count -= cnt;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const bool active = whole || (lane >> 5) == piece;
+                const uint32_t piece_base = (!whole && piece == 1) ? nb_half : 0u;
+                const uint32_t piece_total = whole ? nb_total : (piece == 0 ? nb_half : nb_total - nb_half);
+                uint32_t qi = q_tail + (nb_before - piece_base);
+                if (qi >= QCAP) qi -= QCAP;
+                uint32_t bits = active ? bnd : 0u;
+                while (bits) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(bits);
+                    const uint32_t bit = bits & (0u - bits);
+                    bits &= bits - 1;
+                    const bool is_term = (nl & bit) != 0;
+                    const bool ign = lane_ign && !(lane == (uint32_t)ft_lane && i > ft_bit);
+                    uint32_t c = col < COL_ANCHOR ? col : COL_ANCHOR - 1;       // absurdly wide rows still count as "wrong"
+                    uint32_t ends = is_term ? 0x80000000u : 0u;
+                    if ((blank & bit) || ign) { c = COL_NONE; if (blank & bit) ends = 0; }
+                    ring[qi] = make_uint2(lp_lo + i, pos_hi8 | (c << 8) | ends);
+                    qi = ring_next(qi);
+                    col = is_term ? 0u : col + 1;
+                }
+                q_tail += piece_total;
+                if (q_tail >= QCAP) q_tail -= QCAP;
+                q_count += piece_total;
             }
 
             // state at the end of the round
@@ -415,9 +440,6 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
                 st_row_start = pos + 16ull * (uint32_t)lt_lane + lt_bit + 1;
             }
             prev_term = bcast32(nl >> 15, 63);
-            q_tail += nb_total;
-            if (q_tail >= QCAP) q_tail -= QCAP;
-            q_count += nb_total;
 
             __builtin_amdgcn_wave_barrier();      // one wave per workgroup: LDS operations of a wave execute in order
             while (q_count >= 64) {
@@ -456,7 +478,9 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
 {
     if (!a.nspans) return;
     const size_t lds = pass1_lds_bytes(a.ncols, a.nnum, a.use_lds_ranges != 0);
-    const uint32_t grid = a.nspans < P1_MAX_WAVES ? a.nspans : P1_MAX_WAVES;
+    uint32_t max_waves = P1_MAX_WAVES;
+    if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_waves = 256u * (uint32_t)atoi(e);   // tuning experiments
+    const uint32_t grid = a.nspans < max_waves ? a.nspans : max_waves;
     hipLaunchKernelGGL(k_pass1, dim3(grid), dim3(64), lds, s, a);
 }
 

@@ -602,6 +602,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         HIP_TRY(c, hipMemsetAsync(c->col_seen.p, 0, c->ncols + 8, s));
         P1Status init{};
         init.bad_row = 0xFFFFFFFFu; init.split_pos = c->n;
+        if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) init.pad = (uint32_t)atoi(dbg) & 16u;
         HIP_TRY(c, hipMemcpyAsync(c->status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
         c->nslots = nslots;
         if (hi > lo && total_rows) {
@@ -845,6 +846,14 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
     }
     launch_dict_lengths(c->order.as<uint32_t>(), c->extra_lens.as<uint32_t>(), count, c->lenp1.as<uint32_t>(), s);
     launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count, c->scan_tmp.p, nullptr, s);
+    {   // the lengths must describe exactly the bytes that came with them, or the insert kernel would walk off the buffer
+        uint64_t total = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, c->extra_offs.as<uint64_t>() + count, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (total != nbytes)
+            return fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_import_uniques: lengths add up to %llu bytes, %llu were passed",
+                        (unsigned long long)total, (unsigned long long)nbytes);
+    }
     launch_import_strings(c->d_in, c->n, c->extra.as<uint8_t>(), c->extra_lens.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count,
                           c->slots.as<uint64_t>(), c->slot_len.as<uint32_t>(), c->nslots - 1,
                           (uint32_t)std::min<uint64_t>(c->nslots - c->nslots / 8, 0xFFFFFFF0ull), c->trim ? 1u : 0u, c->hi,

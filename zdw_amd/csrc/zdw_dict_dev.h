@@ -75,6 +75,7 @@ __device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint
         while (nbs < len && p[len - 1 - nbs] == '\\') ++nbs;
         tail_bs_odd = nbs & 1u;
     }
+    if (st->pad == 16u) return (uint32_t)(h & slot_mask) + 1;   // profiling only (ZDW_DEBUG_SKIP=16): no table access
     const uint64_t tag = h >> POS_BITS;
     const uint64_t mine = (tag << POS_BITS) | (pos + 1);
     uint64_t i = h & slot_mask;

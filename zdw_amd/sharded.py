@@ -82,11 +82,18 @@ def _wrap(ptr, nbytes, typestr, device):
     return torch.as_tensor(_RawCuda(ptr, nbytes, typestr), device=device)
 
 
+def _torch_done():
+    """The library works on its own HIP stream: anything torch produced for it must be complete first."""
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+
+
 def export_uniques_tensors(enc, device):
     """(lens int32[count], bytes uint8[nbytes]) as torch tensors owned by the caller (copies)."""
     d_lens, d_bytes, count, nbytes = enc.export_uniques()
     lens = _wrap(d_lens, count * 4, "<i4", device).clone()
     byts = _wrap(d_bytes, nbytes, "|u1", device).clone()
+    _torch_done()          # the library may reuse its buffers as soon as we return
     return lens, byts
 
 
@@ -107,6 +114,7 @@ def encode_shards_local(encoders, device="cuda"):
     for i, e in enumerate(encoders):
         e.import_ranges(mn, mx, seen)
         lens, byts = concat_uniques(uniq, skip=i)
+        _torch_done()
         if lens.numel():
             e.import_uniques(lens.data_ptr(), byts.data_ptr(), lens.numel(), byts.numel())
     prev = chain_prev_rows([e.last_row() for e in encoders], [p.num_rows for p in p1s])
@@ -182,6 +190,7 @@ def encode_shard_dist(enc, rank, world, group=None, fetch=False):
     enc.import_ranges(mn, mx, seen)
     lens, byts = export_uniques_tensors(enc, device)
     olens, obyts = allgather_uniques(lens, byts, rank, world, group=group)
+    _torch_done()
     if olens.numel():
         enc.import_uniques(olens.data_ptr(), obyts.data_ptr(), olens.numel(), obyts.numel())
     prev = exchange_prev_row(enc.last_row(), p1.num_rows, rank, world, device, group=group)
