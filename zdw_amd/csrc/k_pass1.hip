@@ -31,7 +31,7 @@
 namespace zdw {
 
 constexpr uint32_t WROUND = 1024;                 // bytes per wave round (16 per lane)
-constexpr uint32_t QCAP = 640;                    // ring entries per wave; a round that does not fit is emitted in two half-wave pieces (<= 512 each)
+constexpr uint32_t QCAP = 448;                    // ring entries per wave; a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
 constexpr uint32_t P1_MAX_WAVES = 256 * 16;   // measured sweet spot on MI355X (8: -40 %, 24: -15 %)
 constexpr uint32_t COL_FIELD_MASK = 0x7FFFFFu;    // descriptor: y = pos[39:32] | col << 8 | ends_row << 31
 constexpr uint32_t COL_NONE = 0x7FFFFFu;          // boundary only (blank line, foreign row, anchor position)
@@ -389,13 +389,14 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
             }
 
             // emit this lane's boundaries.  The ring always keeps the head's predecessor, so it can take
-            // QCAP - 1 - pending new descriptors; a denser round is emitted as two half-wave pieces with the
-            // ring drained in between (each half holds <= 512 boundaries).
+            // QCAP - 1 - pending new descriptors; a denser round is emitted as four 16-lane pieces (<= 256
+            // boundaries each, which always fit an empty ring) with the ring drained in between.
+            static_assert(QCAP >= 256 + 2, "a drained ring must take one 16-lane piece");
             const uint32_t lp_lo = (uint32_t)pos + 16u * lane, pos_hi8 = (uint32_t)(pos >> 32) & 0xffu;
             const bool lane_ign = st_ignore && (ft_lane < 0 || lane <= (uint32_t)ft_lane);
             const bool whole = q_count + nb_total <= QCAP - 1;
-            const uint32_t nb_half = bcast32(nb_before, 32);                  // boundaries in lanes 0..31
-            for (uint32_t piece = 0; piece < (whole ? 1u : 2u); ++piece) {
+            const uint32_t b16 = bcast32(nb_before, 16), b32 = bcast32(nb_before, 32), b48 = bcast32(nb_before, 48);
+            for (uint32_t piece = 0; piece < (whole ? 1u : 4u); ++piece) {
                 if (!whole) {
                     __builtin_amdgcn_wave_barrier();
                     while (q_count) {                                         // drain: batches of 64, then the rest
@@ -407,9 +408,10 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-                const bool active = whole || (lane >> 5) == piece;
-                const uint32_t piece_base = (!whole && piece == 1) ? nb_half : 0u;
-                const uint32_t piece_total = whole ? nb_total : (piece == 0 ? nb_half : nb_total - nb_half);
+                const bool active = whole || (lane >> 4) == piece;
+                const uint32_t piece_base = whole ? 0u : (piece == 0 ? 0u : (piece == 1 ? b16 : (piece == 2 ? b32 : b48)));
+                const uint32_t piece_end = whole ? nb_total : (piece == 0 ? b16 : (piece == 1 ? b32 : (piece == 2 ? b48 : nb_total)));
+                const uint32_t piece_total = piece_end - piece_base;
                 uint32_t qi = q_tail + (nb_before - piece_base);
                 if (qi >= QCAP) qi -= QCAP;
                 uint32_t bits = active ? bnd : 0u;
@@ -478,8 +480,17 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
 {
     if (!a.nspans) return;
     const size_t lds = pass1_lds_bytes(a.ncols, a.nnum, a.use_lds_ranges != 0);
-    uint32_t max_waves = P1_MAX_WAVES;
-    if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_waves = 256u * (uint32_t)atoi(e);   // tuning experiments
+    // Waves walk the spans with a grid stride, so every wave carries the same share of the block: the grid
+    // must not exceed what is resident at once, or the surplus waves run alone after the others finish.
+    int per_cu = 0, dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pass1, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules
+    if ((size_t)per_cu > by_lds && by_lds >= 1) per_cu = (int)by_lds;
+    uint32_t max_waves = (uint32_t)cus * (uint32_t)(per_cu > 16 ? 16 : per_cu);   // 16/CU measured best on MI355X
+    if (max_waves > P1_MAX_WAVES) max_waves = P1_MAX_WAVES;
+    if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_waves = (uint32_t)cus * (uint32_t)atoi(e);   // tuning experiments
     const uint32_t grid = a.nspans < max_waves ? a.nspans : max_waves;
     hipLaunchKernelGGL(k_pass1, dim3(grid), dim3(64), lds, s, a);
 }

@@ -44,37 +44,49 @@ __device__ inline bool stored_ends_here(const uint8_t *in, uint64_t pos, uint32_
     return blanks || !tail_bs_odd;
 }
 
-// Insert-or-find in the block dictionary table.  slot word = tag(24) | position+1 (40); 0 = empty.
-// Returns slot index + 1, or 0 when the table is too full (caller retries with more slots).
-// `n` = allocation size of the TSV image (reads never reach it); imported strings sit in a buffer
-// with >= 16 bytes of slack.  Memory round trips on the common path: the candidate's first 16
-// bytes (kept in registers for the compare), the slot word, the stored string's words.
-__device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
-                                       uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len, bool trim,
-                                       bool &is_new)
+// A string's identity for the table: its first 24 bytes in registers (zero padded; strings hold no NUL, so
+// for len <= 24 the three words ARE the string), a 64-bit hash of all of it, parity of its trailing backslashes.
+struct StrKey {
+    uint64_t c0, c1, c2, h;
+    bool tail_bs_odd;
+};
+
+__device__ inline void make_key(const uint8_t *p, const uint8_t *p_end, uint32_t len, StrKey &k)
 {
-    // The caller counts new entries per wave (is_new) and adds them to st->entries in bulk: one
-    // returning atomic per insert on a single counter serialises the whole chip (~70 M/s).
-    const uint8_t *p = string_at(in, extra, pos);
-    const uint8_t *p_end = pos >= EXTRA_BASE ? p + len + 16 : in + n;
-    const uint64_t c0 = load_upto8(p, len < 8 ? len : 8u, p_end);
-    const uint64_t c1 = len > 8 ? load_upto8(p + 8, len - 8 < 8 ? len - 8 : 8u, p_end) : 0ull;
+    k.c0 = load_upto8(p, len < 8 ? len : 8u, p_end);
+    k.c1 = len > 8 ? load_upto8(p + 8, len - 8 < 8 ? len - 8 : 8u, p_end) : 0ull;
+    k.c2 = 0;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
-    h = (h ^ c0) * 0xff51afd7ed558ccdull; h ^= h >> 32;
-    uint64_t last = c0;
-    if (len > 8) { h = (h ^ c1) * 0xff51afd7ed558ccdull; h ^= h >> 32; last = c1; }
+    h = (h ^ k.c0) * 0xff51afd7ed558ccdull; h ^= h >> 32;
+    uint64_t last = k.c0;
+    if (len > 8) { h = (h ^ k.c1) * 0xff51afd7ed558ccdull; h ^= h >> 32; last = k.c1; }
     for (uint32_t i = 16; i < len; i += 8) {
         last = load_upto8(p + i, len - i < 8 ? len - i : 8u, p_end);
+        if (i == 16) k.c2 = last;
         h = (h ^ last) * 0xff51afd7ed558ccdull;
         h ^= h >> 32;
     }
-    h = mix64(h);
-    bool tail_bs_odd = false;
+    k.h = mix64(h);
+    k.tail_bs_odd = false;
     if (((last >> (8 * ((len - 1) & 7u))) & 0xffu) == '\\') {
         uint32_t nbs = 1;
         while (nbs < len && p[len - 1 - nbs] == '\\') ++nbs;
-        tail_bs_odd = nbs & 1u;
+        k.tail_bs_odd = nbs & 1u;
     }
+}
+
+// Insert-or-find in the block dictionary table.  slot word = tag(24) | position+1 (40); 0 = empty.
+// Returns slot index + 1, or 0 when the table is too full (caller retries with more slots).
+// `n` = allocation size of the TSV image (reads never reach it); imported strings sit in a buffer
+// with >= 16 bytes of slack.  Memory round trips: the slot word, then the stored string's words.
+// The caller counts new entries per wave (is_new) and adds them to st->entries in bulk: one
+// returning atomic per insert on a single counter serialises the whole chip (~70 M/s).
+__device__ inline uint32_t dict_probe(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
+                                      uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len, bool trim,
+                                      const StrKey &key, const uint8_t *p, const uint8_t *p_end, bool &is_new)
+{
+    const uint64_t h = key.h, c0 = key.c0, c1 = key.c1;
+    const bool tail_bs_odd = key.tail_bs_odd;
     if (st->pad == 16u) return (uint32_t)(h & slot_mask) + 1;   // profiling only (ZDW_DEBUG_SKIP=16): no table access
     const uint64_t tag = h >> POS_BITS;
     const uint64_t mine = (tag << POS_BITS) | (pos + 1);
@@ -129,6 +141,17 @@ __device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint
     }
     st->overflow = 1;
     return 0;
+}
+
+__device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
+                                       uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len, bool trim,
+                                       bool &is_new)
+{
+    const uint8_t *p = string_at(in, extra, pos);
+    const uint8_t *p_end = pos >= EXTRA_BASE ? p + len + 16 : in + n;
+    StrKey key;
+    make_key(p, p_end, len, key);
+    return dict_probe(in, n, extra, hi, slots, slot_len, slot_mask, st, pos, len, trim, key, p, p_end, is_new);
 }
 
 // big-endian 8-byte sort key of bytes [8*depth, 8*depth+8) of a string, zero padded.  Strings hold
