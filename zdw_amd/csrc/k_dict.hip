@@ -365,7 +365,10 @@ __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint6
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool is_new = false;
-    if (i < count) dict_insert(in, n, extra, hi, slots, slot_len, slot_mask, st, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
+    if (i < count) {
+        const uint8_t *p = extra + offs[i];
+        dict_insert(global_bytes(p, p + lens[i] + 16), in, n, extra, hi, slots, slot_len, slot_mask, st, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
+    }
     const uint64_t m = __ballot(is_new);
     if (m && lane_id() == 0) {
         const uint32_t total = atomicAdd(&st->entries, popc64(m)) + popc64(m);

@@ -31,8 +31,8 @@
 namespace zdw {
 
 constexpr uint32_t WROUND = 1024;                 // bytes per wave round (16 per lane)
-constexpr uint32_t QCAP = 448;                    // ring entries per wave; a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
-constexpr uint32_t P1_MAX_WAVES = 256 * 16;   // measured sweet spot on MI355X (8: -40 %, 24: -15 %)
+constexpr uint32_t QCAP = 384;                    // ring entries per wave; a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
+constexpr uint32_t P1_WPB = 2;                    // independent waves per workgroup (the CU takes 16 workgroups; 32 waves need 2 each)
 constexpr uint32_t COL_FIELD_MASK = 0x7FFFFFu;    // descriptor: y = pos[39:32] | col << 8 | ends_row << 31
 constexpr uint32_t COL_NONE = 0x7FFFFFu;          // boundary only (blank line, foreign row, anchor position)
 constexpr uint32_t COL_ANCHOR = 0x7FFFFEu;        // x = row index of the rows that follow
@@ -220,9 +220,10 @@ __device__ __forceinline__ uint64_t entry_pos(const uint2 &e) { return ((uint64_
 
 // Processes `count` (<= 64) descriptors starting at ring index `head`, one per lane.  row_cur = row
 // index that applies at `head` (updated).  Returns how many new dictionary entries were created.
-__device__ __forceinline__ uint32_t consume(const Pass1Args &a, const RangeSink &rs, const uint2 *ring, uint32_t head, uint32_t count,
-                                            uint32_t lane, uint32_t &row_cur)
+__device__ __forceinline__ uint32_t consume(const Pass1Args &a, const WaveCtx &w, uint32_t head, uint32_t count, uint32_t lane,
+                                            uint32_t &row_cur)
 {
+    const uint2 *ring = reinterpret_cast<const uint2 *>(zdw_lds + w.ring);
     const bool live = lane < count;
     uint2 e = make_uint2(0u, COL_NONE << 8);
     uint32_t idx = head + lane;
@@ -245,7 +246,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const RangeSink 
         if (col < a.ncols && !(a.debug_skip & 1u)) {
             const uint2 pe = ring[idx ? idx - 1 : QCAP - 1];
             const uint64_t fs = (entry_pos(pe) + 1) & POS_MASK;                  // a field begins after its predecessor's end
-            process_field(a, rs, fs, (uint32_t)(entry_pos(e) - fs), col, row, is_new);
+            process_field(a, w, fs, (uint32_t)(entry_pos(e) - fs), col, row, is_new);
         }
     }
     // lanes past `count` hold no descriptor, so lane 63 sees the state after the last live one
@@ -253,28 +254,39 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const RangeSink 
     return popc64(__ballot(is_new));
 }
 
+// per-wave LDS: descriptor ring | byte ring + mirror | [column meta | min | max | seen]
 size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds)
 {
-    size_t b = QCAP * sizeof(uint2);
-    if (use_lds) b += (size_t)nnum * 16 + ((ncols + 15) & ~15u);
-    return b;
+    size_t b = QCAP * sizeof(uint2) + BYTE_RING + 16;
+    if (use_lds) b += (((size_t)ncols * 4 + 7) & ~(size_t)7) + (size_t)nnum * 16 + ((ncols + 15) & ~15u);
+    return (b + 15) & ~(size_t)15;
 }
 
-__global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
+__global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32_t lds_per_wave)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    uint2 *ring = reinterpret_cast<uint2 *>(lds_raw);
+    // every wave of the workgroup is an independent worker with its own slice of the LDS
+    const uint32_t wb = (threadIdx.x >> 6) * lds_per_wave;
+    const uint32_t wave_id = blockIdx.x * P1_WPB + (threadIdx.x >> 6), wave_count = gridDim.x * P1_WPB;
     const uint32_t lane = lane_id();
-    RangeSink rs;
-    rs.lds = a.use_lds_ranges != 0;
-    if (rs.lds) {
-        rs.mn = reinterpret_cast<uint64_t *>(lds_raw + QCAP * sizeof(uint2));
-        rs.mx = rs.mn + a.nnum;
-        rs.seen = reinterpret_cast<uint8_t *>(rs.mx + a.nnum);
-        for (uint32_t i = lane; i < a.nnum; i += 64) { rs.mn[i] = ~0ull; rs.mx[i] = 0; }
-        for (uint32_t i = lane; i < a.ncols; i += 64) rs.seen[i] = 0;
-    } else {
-        rs.mn = a.col_min; rs.mx = a.col_max; rs.seen = a.col_seen;
+    WaveCtx w;
+    w.ring = wb;
+    w.bytes = wb + QCAP * sizeof(uint2);
+    w.meta = w.bytes + BYTE_RING + 16;
+    w.mn = w.meta + ((4 * a.ncols + 7u) & ~7u);           // 64-bit LDS atomics need 8-byte alignment
+    w.mx = w.mn + 8 * a.nnum;
+    w.seen = w.mx + 8 * a.nnum;
+    w.cols_in_lds = a.use_lds_ranges != 0;
+    w.lds_lo = w.lds_hi = 0;
+    uint2 *ring = reinterpret_cast<uint2 *>(zdw_lds + w.ring);
+    if (w.cols_in_lds) {
+        for (uint32_t c = lane; c < a.ncols; c += 64) {
+            *reinterpret_cast<uint32_t *>(zdw_lds + w.meta + 4 * c) = pack_col_meta(a.col_kind[c], (uint32_t)a.col_numidx[c] & 0x3fffu, a.col_recoff[c]);
+            zdw_lds[w.seen + c] = 0;
+        }
+        for (uint32_t i = lane; i < a.nnum; i += 64) {
+            reinterpret_cast<uint64_t *>(zdw_lds + w.mn)[i] = ~0ull;
+            reinterpret_cast<uint64_t *>(zdw_lds + w.mx)[i] = 0;
+        }
     }
     __syncthreads();
 
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
     uint32_t row_cur = 0;              // row index at q_head
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
-    for (uint32_t si = blockIdx.x; si < a.nspans; si += gridDim.x) {
+    for (uint32_t si = wave_id; si < a.nspans; si += wave_count) {
         const uint32_t rowbase = a.span_rowbase[si];
         if (a.span_rowbase[si + 1] == rowbase) continue;          // no row starts in this span
         if (rowbase > a.row_limit) break;                         // later spans hold rows of later blocks only
@@ -322,6 +334,16 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
             const uint4 v = nxt;
             nxt = load_round16(a.in, pos + WROUND, lane, a.n);            // next round in flight
             const uint64_t lp = pos + 16ull * lane;
+            // keep the round in the LDS byte ring (two rounds deep): field work reads its bytes from there
+            {
+                const uint32_t slot = (uint32_t)pos & (BYTE_RING - 1);            // 0 or 1024
+                *reinterpret_cast<uint4 *>(zdw_lds + w.bytes + slot + 16u * lane) = v;
+                if (slot == 0 && lane == 0) *reinterpret_cast<uint2 *>(zdw_lds + w.bytes + BYTE_RING) = make_uint2(v.x, v.y);   // mirror for reads that straddle the wrap
+                if (pos == w.lds_hi) { w.lds_hi = pos + WROUND; if (w.lds_hi - w.lds_lo > BYTE_RING) w.lds_lo = w.lds_hi - BYTE_RING; }
+                else { w.lds_lo = pos; w.lds_hi = pos + WROUND; }
+                // bytes past the end of the image are re-read filler: never trust them
+                if (w.lds_hi > a.n) w.lds_hi = a.n > w.lds_lo ? a.n : w.lds_lo;
+            }
             Lane16 m;
             classify16(a.in, a.lo, a.n, lp, v, lane, bs_carry, m, true);
 
@@ -401,7 +423,7 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
                     __builtin_amdgcn_wave_barrier();
                     while (q_count) {                                         // drain: batches of 64, then the rest
                         const uint32_t cnt = q_count < 64 ? q_count : 64u;
-                        new_entries += consume(a, rs, ring, q_head, cnt, lane, row_cur);
+                        new_entries += consume(a, w, q_head, cnt, lane, row_cur);
                         q_head += cnt;
                         if (q_head >= QCAP) q_head -= QCAP;
                         q_count -= cnt;
@@ -445,7 +467,7 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
 
             __builtin_amdgcn_wave_barrier();      // one wave per workgroup: LDS operations of a wave execute in order
             while (q_count >= 64) {
-                new_entries += consume(a, rs, ring, q_head, 64, lane, row_cur);
+                new_entries += consume(a, w, q_head, 64, lane, row_cur);
                 q_head += 64;
                 if (q_head >= QCAP) q_head -= QCAP;
                 q_count -= 64;
@@ -454,22 +476,23 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (q_count) new_entries += consume(a, rs, ring, q_head, q_count, lane, row_cur);
+    if (q_count) new_entries += consume(a, w, q_head, q_count, lane, row_cur);
     __syncthreads();
     if (new_entries && lane == 0) {
         const uint32_t total = atomicAdd(&a.st->entries, new_entries) + new_entries;
         if (total > a.max_entries) a.st->overflow = 1;
     }
 
-    if (rs.lds) {   // one flush per wave
+    if (w.cols_in_lds) {   // one flush per wave
         for (uint32_t c = lane; c < a.ncols; c += 64) {
             if (a.col_kind[c] == K_TEXT) {
-                if (rs.seen[c]) a.col_seen[c] = 1;
+                if (zdw_lds[w.seen + c]) a.col_seen[c] = 1;
             } else {
                 const uint32_t i = (uint32_t)a.col_numidx[c];
-                if (rs.mx[i] != 0) {
-                    atomicMin(reinterpret_cast<unsigned long long *>(&a.col_min[c]), (unsigned long long)rs.mn[i]);
-                    atomicMax(reinterpret_cast<unsigned long long *>(&a.col_max[c]), (unsigned long long)rs.mx[i]);
+                const uint64_t mn = reinterpret_cast<const uint64_t *>(zdw_lds + w.mn)[i], mx = reinterpret_cast<const uint64_t *>(zdw_lds + w.mx)[i];
+                if (mx != 0) {
+                    atomicMin(reinterpret_cast<unsigned long long *>(&a.col_min[c]), (unsigned long long)mn);
+                    atomicMax(reinterpret_cast<unsigned long long *>(&a.col_max[c]), (unsigned long long)mx);
                 }
             }
         }
@@ -479,20 +502,22 @@ __global__ __launch_bounds__(64) void k_pass1(const Pass1Args a)
 void launch_pass1(const Pass1Args &a, hipStream_t s)
 {
     if (!a.nspans) return;
-    const size_t lds = pass1_lds_bytes(a.ncols, a.nnum, a.use_lds_ranges != 0);
+    const size_t lds_wave = (pass1_lds_bytes(a.ncols, a.nnum, a.use_lds_ranges != 0) + 15) & ~(size_t)15;
+    const size_t lds = lds_wave * P1_WPB;
     // Waves walk the spans with a grid stride, so every wave carries the same share of the block: the grid
     // must not exceed what is resident at once, or the surplus waves run alone after the others finish.
     int per_cu = 0, dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pass1, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pass1, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 4;
     const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules
     if ((size_t)per_cu > by_lds && by_lds >= 1) per_cu = (int)by_lds;
-    uint32_t max_waves = (uint32_t)cus * (uint32_t)(per_cu > 16 ? 16 : per_cu);   // 16/CU measured best on MI355X
-    if (max_waves > P1_MAX_WAVES) max_waves = P1_MAX_WAVES;
-    if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_waves = (uint32_t)cus * (uint32_t)atoi(e);   // tuning experiments
-    const uint32_t grid = a.nspans < max_waves ? a.nspans : max_waves;
-    hipLaunchKernelGGL(k_pass1, dim3(grid), dim3(64), lds, s, a);
+    if (per_cu > 16) per_cu = 16;                                               // workgroup slots per CU
+    uint32_t max_blocks = (uint32_t)cus * (uint32_t)per_cu;
+    if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / P1_WPB;   // tuning experiments
+    const uint32_t want_blocks = (a.nspans + P1_WPB - 1) / P1_WPB;
+    const uint32_t grid = want_blocks < max_blocks ? want_blocks : (max_blocks ? max_blocks : 1u);
+    hipLaunchKernelGGL(k_pass1, dim3(grid), dim3(64 * P1_WPB), lds, s, a, (uint32_t)lds_wave);
 }
 
 }  // namespace zdw

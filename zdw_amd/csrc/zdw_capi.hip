@@ -574,7 +574,8 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     c->is_last = !tripped;
 
     // ---- pass 1 proper (also runs for zero rows when a partial row pollutes the block) ----
-    const bool lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) <= 20 * 1024;
+    // column facts and ranges live in per-wave LDS when they fit there (and in the packed 14 + 16 bit form)
+    const bool lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) <= 20 * 1024 && c->nnum < 16384 && c->rec_stride < 65536;
     // dictionary table: one slot per 16 input bytes (load factor limit 1/2 => up to one new string per
     // 32 bytes of TSV before a retry), within [2^16, 2^27]; a context remembers what its last block needed
     uint64_t nslots = c->slots_opt;

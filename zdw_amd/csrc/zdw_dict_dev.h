@@ -28,6 +28,40 @@ __device__ __forceinline__ uint64_t load_upto8(const uint8_t *p, uint32_t want, 
     return w;
 }
 
+// The dynamic LDS of the launching kernel (pass 1 keeps, per wave, a ring of the last two input rounds there).
+extern __shared__ __attribute__((aligned(16))) uint8_t zdw_lds[];
+constexpr uint32_t BYTE_RING = 2048;     // two 1 KiB rounds; 8 mirror bytes follow so that 8-byte reads may straddle the wrap
+
+// Where the bytes of one field are read from: the wave's LDS byte ring when the whole field is still in
+// it (the common case: fields are consumed within a round or two of being tokenised), else global memory.
+// LDS reads do not go through the vector L1, whose per-lane request rate bounds the field work.
+struct FieldBytes {
+    const uint8_t *g;        // field start in global memory
+    const uint8_t *g_end;    // end of that allocation (reads never reach it)
+    uint32_t ring;           // offset of the wave's byte ring in zdw_lds
+    uint32_t at;             // (absolute field start) mod BYTE_RING
+    bool in_lds;
+    // bytes [i, i + want) of the field as a little-endian word, upper bytes zero (want in 1..8)
+    __device__ __forceinline__ uint64_t word(uint32_t i, uint32_t want) const
+    {
+        if (in_lds) {
+            const uint64_t w = reinterpret_cast<const PackedU64 *>(zdw_lds + ring + ((at + i) & (BYTE_RING - 1)))->v;
+            return want >= 8 ? w : (w & ((1ull << (8 * want)) - 1ull));
+        }
+        return load_upto8(g + i, want, g_end);
+    }
+    __device__ __forceinline__ uint32_t byte(uint32_t i) const
+    {
+        return in_lds ? zdw_lds[ring + ((at + i) & (BYTE_RING - 1))] : g[i];
+    }
+};
+__device__ __forceinline__ FieldBytes global_bytes(const uint8_t *p, const uint8_t *end)
+{
+    FieldBytes f;
+    f.g = p; f.g_end = end; f.ring = 0; f.at = 0; f.in_lds = false;
+    return f;
+}
+
 // Does the stored occurrence at image position `pos` (same first `len` bytes as the candidate) END
 // after `len` bytes?  The next byte must be the field's separator; it is a separator iff the run of
 // backslashes before it is even, and that run is the candidate's own trailing run (identical bytes),
@@ -51,17 +85,17 @@ struct StrKey {
     bool tail_bs_odd;
 };
 
-__device__ inline void make_key(const uint8_t *p, const uint8_t *p_end, uint32_t len, StrKey &k)
+__device__ inline void make_key(const FieldBytes &f, uint32_t len, StrKey &k)
 {
-    k.c0 = load_upto8(p, len < 8 ? len : 8u, p_end);
-    k.c1 = len > 8 ? load_upto8(p + 8, len - 8 < 8 ? len - 8 : 8u, p_end) : 0ull;
+    k.c0 = f.word(0, len < 8 ? len : 8u);
+    k.c1 = len > 8 ? f.word(8, len - 8 < 8 ? len - 8 : 8u) : 0ull;
     k.c2 = 0;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
     h = (h ^ k.c0) * 0xff51afd7ed558ccdull; h ^= h >> 32;
     uint64_t last = k.c0;
     if (len > 8) { h = (h ^ k.c1) * 0xff51afd7ed558ccdull; h ^= h >> 32; last = k.c1; }
     for (uint32_t i = 16; i < len; i += 8) {
-        last = load_upto8(p + i, len - i < 8 ? len - i : 8u, p_end);
+        last = f.word(i, len - i < 8 ? len - i : 8u);
         if (i == 16) k.c2 = last;
         h = (h ^ last) * 0xff51afd7ed558ccdull;
         h ^= h >> 32;
@@ -70,7 +104,7 @@ __device__ inline void make_key(const uint8_t *p, const uint8_t *p_end, uint32_t
     k.tail_bs_odd = false;
     if (((last >> (8 * ((len - 1) & 7u))) & 0xffu) == '\\') {
         uint32_t nbs = 1;
-        while (nbs < len && p[len - 1 - nbs] == '\\') ++nbs;
+        while (nbs < len && f.byte(len - 1 - nbs) == '\\') ++nbs;
         k.tail_bs_odd = nbs & 1u;
     }
 }
@@ -83,7 +117,7 @@ __device__ inline void make_key(const uint8_t *p, const uint8_t *p_end, uint32_t
 // returning atomic per insert on a single counter serialises the whole chip (~70 M/s).
 __device__ inline uint32_t dict_probe(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
                                       uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len, bool trim,
-                                      const StrKey &key, const uint8_t *p, const uint8_t *p_end, bool &is_new)
+                                      const StrKey &key, const FieldBytes &f, bool &is_new)
 {
     const uint64_t h = key.h, c0 = key.c0, c1 = key.c1;
     const bool tail_bs_odd = key.tail_bs_odd;
@@ -114,7 +148,7 @@ __device__ inline uint32_t dict_probe(const uint8_t *in, uint64_t n, const uint8
                 for (uint32_t k = 0; k < len && same; k += 8) {
                     const uint32_t want = len - k < 8 ? len - k : 8u;
                     const uint64_t m = want >= 8 ? ~0ull : ((1ull << (8 * want)) - 1ull);
-                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : load_upto8(p + k, want, p_end));
+                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : f.word(k, want));
                     same = (load8(q + k) & m) == cw;
                 }
                 if (same && q[len] == 0) return (uint32_t)i + 1;
@@ -125,7 +159,7 @@ __device__ inline uint32_t dict_probe(const uint8_t *in, uint64_t n, const uint8
                 int next = -1;                              // the stored byte right after the compared bytes, when it came along
                 for (uint32_t k = 0; k < len && same; k += 8) {
                     const uint32_t want = len - k < 8 ? len - k : 8u;
-                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : load_upto8(p + k, want, p_end));
+                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : f.word(k, want));
                     if (q + k + 8 <= q_end) {
                         const uint64_t sw = load8(q + k);
                         if (want < 8) { same = (sw & ((1ull << (8 * want)) - 1ull)) == cw; next = (int)((sw >> (8 * want)) & 0xffu); }
@@ -143,15 +177,13 @@ __device__ inline uint32_t dict_probe(const uint8_t *in, uint64_t n, const uint8
     return 0;
 }
 
-__device__ inline uint32_t dict_insert(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
-                                       uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len, bool trim,
-                                       bool &is_new)
+__device__ inline uint32_t dict_insert(const FieldBytes &f, const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi,
+                                       uint64_t *slots, uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len,
+                                       bool trim, bool &is_new)
 {
-    const uint8_t *p = string_at(in, extra, pos);
-    const uint8_t *p_end = pos >= EXTRA_BASE ? p + len + 16 : in + n;
     StrKey key;
-    make_key(p, p_end, len, key);
-    return dict_probe(in, n, extra, hi, slots, slot_len, slot_mask, st, pos, len, trim, key, p, p_end, is_new);
+    make_key(f, len, key);
+    return dict_probe(in, n, extra, hi, slots, slot_len, slot_mask, st, pos, len, trim, key, f, is_new);
 }
 
 // big-endian 8-byte sort key of bytes [8*depth, 8*depth+8) of a string, zero padded.  Strings hold

@@ -13,13 +13,13 @@ namespace zdw {
 // ------------------------------------------------------------------------------------------
 // C-locale strtoull(s, NULL, 10) on a byte range (ConvertToZDW.cpp:385,564): the
 // general form, one 8-byte window load per 8 characters.
-__device__ inline uint64_t parse_u64_general(const uint8_t *p, uint32_t len, const uint8_t *end)
+__device__ inline uint64_t parse_u64_general(const FieldBytes &f, uint32_t len)
 {
     uint64_t win = 0, v = 0;
     bool neg = false, any = false, ovf = false;
     uint32_t state = 0;     // 0 leading space, 1 digits
     for (uint32_t i = 0; i < len; ++i) {
-        if ((i & 7u) == 0) win = load_upto8(p + i, len - i < 8 ? len - i : 8u, end);
+        if ((i & 7u) == 0) win = f.word(i, len - i < 8 ? len - i : 8u);
         const uint32_t b = (uint32_t)(win >> (8 * (i & 7u))) & 0xffu;
         if (state == 0) {
             if (b == ' ' || (b >= 9 && b <= 13)) continue;
@@ -57,49 +57,70 @@ __device__ __forceinline__ uint64_t pad_digits(uint64_t w, uint32_t len)
 
 // 1..16 plain digits take the SWAR route (two window loads, no per-character loop); anything else
 // (sign, blanks, junk, 17+ characters) goes through the general parser.  Same result either way.
-__device__ inline uint64_t parse_u64(const uint8_t *p, uint32_t len, const uint8_t *end)
+__device__ inline uint64_t parse_u64(const FieldBytes &f, uint32_t len)
 {
     if (len <= 8) {
-        const uint64_t w = pad_digits(load_upto8(p, len, end), len);
+        const uint64_t w = pad_digits(f.word(0, len), len);
         if (all_digits(w)) return eight_digits(w);
     } else if (len <= 16) {
-        const uint64_t w1 = pad_digits(load_upto8(p, len - 8, end), len - 8);
-        const uint64_t w2 = load_upto8(p + len - 8, 8, end);
+        const uint64_t w1 = pad_digits(f.word(0, len - 8), len - 8);
+        const uint64_t w2 = f.word(len - 8, 8);
         if (all_digits(w1) && all_digits(w2)) return (uint64_t)eight_digits(w1) * 100000000ull + eight_digits(w2);
     }
-    return parse_u64_general(p, len, end);
+    return parse_u64_general(f, len);
 }
 
-struct RangeSink {           // where per-column ranges of this wave accumulate
-    uint64_t *mn, *mx;       // indexed by numeric index (LDS) or column (global)
-    uint8_t *seen;           // indexed by column
-    bool lds;
+// Per-wave working set in LDS (offsets into zdw_lds) and where column facts live.
+struct WaveCtx {
+    uint32_t ring;        // descriptor ring
+    uint32_t bytes;       // byte ring (BYTE_RING + 8)
+    uint32_t meta;        // u32 per column: kind | numeric index << 2 | record offset << 16   (cols_in_lds)
+    uint32_t mn, mx;      // u64 per numeric column                                              (cols_in_lds)
+    uint32_t seen;        // u8 per column                                                       (cols_in_lds)
+    bool cols_in_lds;     // else: column facts and ranges are read / updated in global memory
+    uint64_t lds_lo, lds_hi;   // absolute positions currently held by the byte ring
 };
 
-__device__ __forceinline__ void range_update(const RangeSink &r, uint32_t idx, uint64_t v)
+__device__ __forceinline__ uint32_t pack_col_meta(uint32_t kind, uint32_t numidx, uint32_t recoff)
 {
-    // unsigned 64-bit compare like the reference (ConvertToZDW.cpp:362-373,386-397).  The plain reads
-    // only filter: min only falls and max only rises, so a stale value can cost a needless atomic,
-    // never lose an update.
-    if (v < r.mn[idx]) atomicMin(reinterpret_cast<unsigned long long *>(&r.mn[idx]), (unsigned long long)v);
-    if (v > r.mx[idx]) atomicMax(reinterpret_cast<unsigned long long *>(&r.mx[idx]), (unsigned long long)v);
+    return kind | (numidx << 2) | (recoff << 16);
 }
 
-__device__ inline void process_field(const Pass1Args &a, const RangeSink &rs, uint64_t fs, uint32_t len, uint32_t col, uint32_t row,
+// unsigned 64-bit min / max like the reference (ConvertToZDW.cpp:362-373,386-397).  The plain reads only
+// filter: min only falls and max only rises, so a stale value can cost a needless atomic, never lose an update.
+__device__ __forceinline__ void range_update(const Pass1Args &a, const WaveCtx &w, uint32_t col, uint32_t numidx, uint64_t v)
+{
+    if (w.cols_in_lds) {
+        unsigned long long *mn = reinterpret_cast<unsigned long long *>(zdw_lds + w.mn) + numidx;
+        unsigned long long *mx = reinterpret_cast<unsigned long long *>(zdw_lds + w.mx) + numidx;
+        if (v < *mn) atomicMin(mn, (unsigned long long)v);
+        if (v > *mx) atomicMax(mx, (unsigned long long)v);
+    } else {
+        if (v < a.col_min[col]) atomicMin(reinterpret_cast<unsigned long long *>(&a.col_min[col]), (unsigned long long)v);
+        if (v > a.col_max[col]) atomicMax(reinterpret_cast<unsigned long long *>(&a.col_max[col]), (unsigned long long)v);
+    }
+}
+
+__device__ inline void process_field(const Pass1Args &a, const WaveCtx &w, uint64_t fs, uint32_t len, uint32_t col, uint32_t row,
                                      bool &is_new)
 {
     const bool in_block = row < a.row_limit;
     if (!in_block && !(row == a.row_limit && col < a.partial_fields)) return;
-    const uint8_t *p = a.in + fs;
-    if (a.trim) while (len > 0 && p[len - 1] == ' ') --len;          // ConvertToZDW.cpp:295-313
-    const uint8_t kind = a.col_kind[col];
-    uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + a.col_recoff[col];
+    FieldBytes f;
+    f.g = a.in + fs; f.g_end = a.in + a.n; f.ring = w.bytes; f.at = (uint32_t)fs & (BYTE_RING - 1);
+    f.in_lds = fs >= w.lds_lo && fs + len <= w.lds_hi;
+    if (a.trim) while (len > 0 && f.byte(len - 1) == ' ') --len;          // ConvertToZDW.cpp:295-313
+    const uint32_t meta = w.cols_in_lds ? *reinterpret_cast<const uint32_t *>(zdw_lds + w.meta + 4 * col)
+                                        : pack_col_meta(a.col_kind[col], (uint32_t)a.col_numidx[col] & 0x3fffu, a.col_recoff[col]);
+    const uint32_t kind = meta & 3u;
+    uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + (meta >> 16);
     if (kind == K_TEXT) {
         uint32_t id = 0;
         if (len) {                                                    // empty fields are skipped (:340-341)
-            if (!rs.seen[col]) rs.seen[col] = 1;
+            if (w.cols_in_lds) { if (!zdw_lds[w.seen + col]) zdw_lds[w.seen + col] = 1; }
+            else if (!a.col_seen[col]) a.col_seen[col] = 1;
             if (!(a.debug_skip & 2u))
-                id = dict_insert(a.in, a.n, a.extra, a.hi, a.slots, a.slot_len, a.slot_mask, a.st, fs, len, a.trim, is_new);
+                id = dict_insert(f, a.in, a.n, a.extra, a.hi, a.slots, a.slot_len, a.slot_mask, a.st, fs, len, a.trim, is_new);
         }
         if (in_block && !(a.debug_skip & 8u)) *reinterpret_cast<uint32_t *>(recp) = id;
         return;
@@ -107,14 +128,15 @@ __device__ inline void process_field(const Pass1Args &a, const RangeSink &rs, ui
     uint64_t v_range = 0, v_rec = 0;
     if (len) {
         if (kind == K_INT) {
-            v_range = v_rec = (a.debug_skip & 4u) ? 1 : parse_u64(p, len, a.in + a.n);
+            v_range = v_rec = (a.debug_skip & 4u) ? 1 : parse_u64(f, len);
         } else {   // char(1): pass 1 adds byte 1 only after a backslash (:358-361), pass 2 always (:543-547)
-            const int64_t c0 = (int8_t)p[0];
-            const int64_t hi8 = (int64_t)((int)(int8_t)(len >= 2 ? p[1] : 0) * 256);
-            v_range = (uint64_t)(p[0] == '\\' ? c0 + hi8 : c0);
+            const uint32_t b0 = f.byte(0);
+            const int64_t c0 = (int8_t)b0;
+            const int64_t hi8 = (int64_t)((int)(int8_t)(len >= 2 ? f.byte(1) : 0) * 256);
+            v_range = (uint64_t)(b0 == '\\' ? c0 + hi8 : c0);
             v_rec = (uint64_t)(c0 + hi8);
         }
-        if (v_range > 0) range_update(rs, rs.lds ? (uint32_t)a.col_numidx[col] : col, v_range);
+        if (v_range > 0) range_update(a, w, col, (meta >> 2) & 0x3fffu, v_range);
     }
     if (in_block && !(a.debug_skip & 8u)) *reinterpret_cast<uint64_t *>(recp) = v_rec;
 }
