@@ -201,22 +201,29 @@ __global__ __launch_bounds__(256) void k_sort_ties(const uint8_t *__restrict__ i
                                                     const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
                                                     uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     const uint32_t *__restrict__ group, const uint32_t *__restrict__ tmp,
-                                                    uint32_t m, uint32_t depth, uint32_t *__restrict__ head,
-                                                    uint32_t *__restrict__ still)
+                                                    const uint64_t *__restrict__ sorted_keys, uint32_t m, uint32_t depth,
+                                                    uint32_t *__restrict__ head, uint32_t *__restrict__ still)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t u = tmp[j];
     order[active[j]] = u;
-    const uint64_t k = sort_key8(string_at(in, extra, uniq_pos[u]), uniq_len[u], depth);
     bool tie_prev = false, tie_next = false;
-    if (j > 0 && group[j - 1] == group[j]) {
-        const uint32_t v = tmp[j - 1];
-        tie_prev = sort_key8(string_at(in, extra, uniq_pos[v]), uniq_len[v], depth) == k;
-    }
-    if (j + 1 < m && group[j + 1] == group[j]) {
-        const uint32_t v = tmp[j + 1];
-        tie_next = sort_key8(string_at(in, extra, uniq_pos[v]), uniq_len[v], depth) == k;
+    if (sorted_keys) {
+        // the radix sort's key array is still aligned with the result (no tie-group pass ran): no string reads
+        const uint64_t k = sorted_keys[j];
+        tie_prev = j > 0 && group[j - 1] == group[j] && sorted_keys[j - 1] == k;
+        tie_next = j + 1 < m && group[j + 1] == group[j] && sorted_keys[j + 1] == k;
+    } else {
+        const uint64_t k = sort_key8(string_at(in, extra, uniq_pos[u]), uniq_len[u], depth);
+        if (j > 0 && group[j - 1] == group[j]) {
+            const uint32_t v = tmp[j - 1];
+            tie_prev = sort_key8(string_at(in, extra, uniq_pos[v]), uniq_len[v], depth) == k;
+        }
+        if (j + 1 < m && group[j + 1] == group[j]) {
+            const uint32_t v = tmp[j + 1];
+            tie_next = sort_key8(string_at(in, extra, uniq_pos[v]), uniq_len[v], depth) == k;
+        }
     }
     // run labels must stay dense (1..#runs) because the next round radix-sorts them on as few bits
     // as the number of still-tied strings needs: count a head only for runs that stay in the working set
@@ -271,8 +278,8 @@ int dict_sort(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos,
             radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
         }
         hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, b.order, active, vals, m, tmp);
-        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, b.order, active, group, tmp, m, depth,
-                           head, still);
+        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, b.order, active, group, tmp,
+                           depth == 0 ? (const uint64_t *)keys : (const uint64_t *)nullptr, m, depth, head, still);
         launch_scan_u32_to_u32(head, head_scan, m, b.scan_tmp, nullptr, s);
         launch_scan_u32_to_u32(still, still_scan, m, b.scan_tmp, nullptr, s);
         hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active, head, still, head_scan, still_scan, m, active_alt,

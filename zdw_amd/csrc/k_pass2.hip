@@ -15,6 +15,10 @@
 
 namespace zdw {
 
+struct __attribute__((packed)) PackedW64 { uint64_t v; };
+struct __attribute__((packed)) PackedW32 { uint32_t v; };
+struct __attribute__((packed)) PackedW16 { uint16_t v; };
+
 // what pass 1 left for (row, used column u): table slot id + 1 (text) or the parsed value (numeric)
 __device__ __forceinline__ uint64_t raw_value(const Pass2Args &a, uint32_t row, uint32_t off, bool text)
 {
@@ -82,8 +86,15 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
                 a.out[out_row + (u0 >> 3) + sub] = (uint8_t)(bits >> (8 * sub));
             if (flag) {
                 const uint64_t v = stored_from_raw(a, cur, u, text);
+                // little-endian truncating store in at most three pieces (4 + 2 + 1 bytes; gfx950 stores unaligned)
                 uint8_t *q = a.out + out_row + nflag + running + (inc - mine);
-                for (uint32_t j = 0; j < sz; ++j) q[j] = (uint8_t)(v >> (8 * j));     // little-endian truncating store
+                if (sz == 8) { reinterpret_cast<PackedW64 *>(q)->v = v; }
+                else {
+                    uint64_t r = v;
+                    if (sz & 4u) { reinterpret_cast<PackedW32 *>(q)->v = (uint32_t)r; q += 4; r >>= 32; }
+                    if (sz & 2u) { reinterpret_cast<PackedW16 *>(q)->v = (uint16_t)r; q += 2; r >>= 16; }
+                    if (sz & 1u) *q = (uint8_t)r;
+                }
             }
         }
         running += tot;
