@@ -110,8 +110,8 @@ def main():
     torch.cuda.synchronize()
 
     # N > 1: every rank's table must hold the union of all ranks' strings (record ids are slot indices, so it
-    # cannot be regrown after pass 1): 2^27 slots = 1.6 GB, room for 67 M distinct strings
-    enc = capi.Encoder(table.types, device=local, dict_slots=(1 << 27) if world > 1 and args.gb >= 2 else ((1 << 23) if world > 1 else 0))
+    # cannot be regrown after pass 1): 2^26 slots of 32 B = 2 GiB, room for 42 M distinct strings
+    enc = capi.Encoder(table.types, device=local, dict_slots=(1 << 26) if world > 1 and args.gb >= 2 else ((1 << 22) if world > 1 else 0))
     enc.set_input_device(buf.data_ptr(), nbytes, keepalive=buf)
     enc.enable_timing(True)
 

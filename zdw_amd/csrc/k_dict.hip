@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_dict_compact(const uint64_t *__restrict
     const uint64_t end = beg + per_block < nslots ? beg + per_block : nslots;
     uint32_t mine = 0, ml = 0;
     for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
-        if (slots[i] != 0) { ++mine; const uint32_t l = slot_len[i]; ml = l > ml ? l : ml; }
+        if (slots[4 * i] != 0) { ++mine; const uint32_t l = slot_len[i]; ml = l > ml ? l : ml; }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_dict_compact(const uint64_t *__restrict
         uint64_t my_mask = 0; uint64_t my_w = 0; uint64_t my_i = 0;
         for (uint32_t g = 0; g < 4; ++g) {
             const uint64_t i = r0 + 64ull * g + lane;
-            const uint64_t w = i < end ? slots[i] : 0ull;
+            const uint64_t w = i < end ? slots[4 * i] : 0ull;
             const uint64_t m = __ballot(w != 0);
             if (g < wv) before += popc64(m);
             if (g == wv) { my_mask = m; my_w = w; my_i = i; }
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_dict_compact(const uint64_t *__restrict
 void launch_dict_compact(const uint64_t *slots, const uint32_t *slot_len, uint64_t nslots, uint64_t *uniq_pos, uint32_t *uniq_len,
                          uint32_t *uniq_slot, uint32_t *count, hipStream_t s)
 {
-    uint64_t per_block = 256ull * 16;                      // 4096 slots (32 KiB of table) per workgroup
+    uint64_t per_block = 256ull * 16;                      // 4096 slots (128 KiB of table) per workgroup
     while ((nslots + per_block - 1) / per_block > 65536) per_block *= 2;
     const uint32_t grid = (uint32_t)((nslots + per_block - 1) / per_block);
     hipLaunchKernelGGL(k_dict_compact, dim3(grid ? grid : 1), dim3(256), 0, s, slots, slot_len, nslots, per_block, uniq_pos, uniq_len,

@@ -576,14 +576,14 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     // ---- pass 1 proper (also runs for zero rows when a partial row pollutes the block) ----
     // column facts and ranges live in per-wave LDS when they fit there (and in the packed 14 + 16 bit form)
     const bool lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) <= 20 * 1024 && c->nnum < 16384 && c->rec_stride < 65536;
-    // dictionary table: one slot per 16 input bytes (load factor limit 1/2 => up to one new string per
-    // 32 bytes of TSV before a retry), within [2^16, 2^27]; a context remembers what its last block needed
+    // dictionary table (32-byte slots): one slot per 32 input bytes, within [2^14, 2^25] (1 GiB); load factor
+    // limit 5/8; a context remembers what its last block needed
     uint64_t nslots = c->slots_opt;
     if (const char *e = getenv("ZDW_DICT_SLOTS")) nslots = strtoull(e, nullptr, 10);   // experiments
     if (!nslots) {
-        nslots = 1ull << 16;
-        const uint64_t want = (hi > lo ? hi - lo : 0) / 16;
-        while (nslots < want && nslots < (1ull << 27)) nslots <<= 1;
+        nslots = 1ull << 14;
+        const uint64_t want = (hi > lo ? hi - lo : 0) / 32;
+        while (nslots < want && nslots < (1ull << 25)) nslots <<= 1;
         if (c->slots_learned > nslots) nslots = c->slots_learned;
     }
     { uint64_t p2 = 1; while (p2 < nslots) p2 <<= 1; nslots = p2; }
@@ -594,16 +594,16 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     HIP_TRY(c, c->long_rows.ensure((uint64_t)long_cap * sizeof(LongRow)));
     P1Status st{};
     for (int attempt = 0;; ++attempt) {
-        if (nslots > (1ull << 32)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary needs more than 2^32 table slots; split the block");
-        HIP_TRY(c, c->slots.ensure(nslots * 8));
+        if (nslots > (1ull << 31)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary needs more than 2^31 table slots; split the block");
+        HIP_TRY(c, c->slots.ensure(nslots * 32));
         HIP_TRY(c, c->slot_len.ensure(nslots * 4));
-        HIP_TRY(c, hipMemsetAsync(c->slots.p, 0, nslots * 8, s));
+        HIP_TRY(c, hipMemsetAsync(c->slots.p, 0, nslots * 32, s));
         HIP_TRY(c, hipMemsetAsync(c->col_min.p, 0xFF, c->ncols * 8 + 8, s));
         HIP_TRY(c, hipMemsetAsync(c->col_max.p, 0, c->ncols * 8 + 8, s));
         HIP_TRY(c, hipMemsetAsync(c->col_seen.p, 0, c->ncols + 8, s));
         P1Status init{};
         init.bad_row = 0xFFFFFFFFu; init.split_pos = c->n;
-        if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) init.pad = (uint32_t)atoi(dbg) & 16u;
+        if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) init.pad = (uint32_t)atoi(dbg) & 48u;
         HIP_TRY(c, hipMemcpyAsync(c->status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
         c->nslots = nslots;
         if (hi > lo && total_rows) {
@@ -617,7 +617,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             a.rec_stride = c->rec_stride; a.rec = c->rec.as<uint8_t>();
             a.row_limit = row_limit; a.partial_fields = partial; a.trim = c->trim ? 1u : 0u;
             a.slots = c->slots.as<uint64_t>(); a.slot_len = c->slot_len.as<uint32_t>(); a.slot_mask = nslots - 1;
-            a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 2, 0xFFFFFFF0ull);
+            a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 8 * 5, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;

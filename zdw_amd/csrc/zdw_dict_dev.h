@@ -109,66 +109,111 @@ __device__ inline void make_key(const FieldBytes &f, uint32_t len, StrKey &k)
     }
 }
 
-// Insert-or-find in the block dictionary table.  slot word = tag(24) | position+1 (40); 0 = empty.
+// Insert-or-find in the block dictionary table.
+//
+// A slot is 32 bytes, 32-byte aligned (one L2 sector pair):
+//     word 0   key = tag(24) | first-occurrence position + 1 (40); 0 = empty.  Claimed with a 64-bit CAS.
+//     word 1-3 the string's first 24 bytes, zero padded, written by the claimer AFTER the CAS:
+//              words 3, 2 first, then (every earlier store drained) word 1.  Strings hold no NUL and
+//              are never empty, so word 1 != 0 means "words 1-3 are complete".
+// A lookup reads the whole slot with two 16-byte L2-coherent loads issued in order (key + word 1 first).
+// When word 1 is set, strings of <= 24 bytes are decided from the slot alone -- one random memory access
+// per lookup instead of two (the second one, into the image at the first occurrence, was the largest
+// single cost of pass 1).  While word 1 is still zero, or for longer strings, the bytes are compared
+// against the first occurrence in the image (or the imported-string buffer): always exact.
 // Returns slot index + 1, or 0 when the table is too full (caller retries with more slots).
-// `n` = allocation size of the TSV image (reads never reach it); imported strings sit in a buffer
-// with >= 16 bytes of slack.  Memory round trips: the slot word, then the stored string's words.
-// The caller counts new entries per wave (is_new) and adds them to st->entries in bulk: one
-// returning atomic per insert on a single counter serialises the whole chip (~70 M/s).
+// `n` = allocation size of the TSV image (reads never reach it); imported strings sit in a buffer with
+// >= 16 bytes of slack.  The caller counts new entries per wave (is_new) and adds them to st->entries in
+// bulk: one returning atomic per insert on a single counter serialises the whole chip (~70 M/s).
+struct SlotWords { uint64_t key, s0, s1, s2; };
+
+__device__ __forceinline__ SlotWords load_slot(const uint64_t *slot)
+{
+    // one asm block: the two loads issue in program order and return in order; sc1 = served by the L2
+    // (coherent across CUs), so a set word 1 implies words 2-3 stored before it are seen as well
+    uint4 lo, hi;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(slot) : "memory");
+    SlotWords w;
+    w.key = ((uint64_t)lo.y << 32) | lo.x; w.s0 = ((uint64_t)lo.w << 32) | lo.z;
+    w.s1 = ((uint64_t)hi.y << 32) | hi.x; w.s2 = ((uint64_t)hi.w << 32) | hi.z;
+    return w;
+}
+
 __device__ inline uint32_t dict_probe(const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi, uint64_t *slots,
                                       uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len, bool trim,
                                       const StrKey &key, const FieldBytes &f, bool &is_new)
 {
-    const uint64_t h = key.h, c0 = key.c0, c1 = key.c1;
+    const uint64_t h = key.h, c0 = key.c0, c1 = key.c1, c2 = key.c2;
     const bool tail_bs_odd = key.tail_bs_odd;
     if (st->pad == 16u) return (uint32_t)(h & slot_mask) + 1;   // profiling only (ZDW_DEBUG_SKIP=16): no table access
+    const bool trust_tag = st->pad == 32u;                        // profiling only (ZDW_DEBUG_SKIP=32): no string compare
     const uint64_t tag = h >> POS_BITS;
     const uint64_t mine = (tag << POS_BITS) | (pos + 1);
     uint64_t i = h & slot_mask;
     const uint32_t max_probe = slot_mask + 1 < 8192 ? (uint32_t)(slot_mask + 1) : 8192u;
     for (uint32_t probe = 0; probe < max_probe; ++probe) {
-        uint64_t w = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w == 0) {
-            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[i]), 0ull, (unsigned long long)mine);
+        uint64_t *slot = slots + 4 * i;
+        SlotWords w = load_slot(slot);
+        if (w.key == 0) {
+            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), 0ull, (unsigned long long)mine);
             if (old == 0) {
                 slot_len[i] = len;
+                // publish the inline copy: words 3 and 2, drain, then word 1
+                if (c2) __hip_atomic_store(slot + 3, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c1) __hip_atomic_store(slot + 2, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(slot + 1, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 is_new = true;
                 return (uint32_t)i + 1;
             }
-            w = old;
+            w.key = old; w.s0 = 0;                        // somebody else just claimed it: its inline copy is not trusted yet
         }
-        if ((w >> POS_BITS) == tag) {
-            const uint64_t sp = (w & POS_MASK) - 1;
-            if (sp == pos) return (uint32_t)i + 1;
-            if (sp >= EXTRA_BASE) {
+        if ((w.key >> POS_BITS) == tag) {
+            const uint64_t sp = (w.key & POS_MASK) - 1;
+            if (sp == pos || trust_tag) return (uint32_t)i + 1;
+            bool decided = false, same = false;
+            if (w.s0 != 0) {
+                // inline copy complete: it IS the stored string when that is <= 24 bytes long, else its first 24 bytes
+                same = w.s0 == c0 && w.s1 == c1 && w.s2 == c2;
+                decided = !same || len <= 24;
+                // (same && len <= 24): equal padded words => equal strings, because neither holds a NUL;
+                // a stored string longer than 24 bytes has a non-zero byte 24.. but then c2's padding would differ
+                // only if len < 24 -- for len == 24 exactly the stored one may continue: check below
+                if (same && len == 24) decided = false;
+            }
+            if (decided) { if (same) return (uint32_t)i + 1; }
+            else if (sp >= EXTRA_BASE) {
                 // imported string (NUL terminated, >= 16 bytes of slack behind it): a shorter one shows
                 // its NUL inside the compared window, so the walk stops before leaving it
                 const uint8_t *q = extra + (sp - EXTRA_BASE);
-                bool same = true;
-                for (uint32_t k = 0; k < len && same; k += 8) {
+                bool eq = true;
+                for (uint32_t k = 0; k < len && eq; k += 8) {
                     const uint32_t want = len - k < 8 ? len - k : 8u;
                     const uint64_t m = want >= 8 ? ~0ull : ((1ull << (8 * want)) - 1ull);
-                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : f.word(k, want));
-                    same = (load8(q + k) & m) == cw;
+                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : (k == 16 ? c2 : f.word(k, want)));
+                    eq = (load8(q + k) & m) == cw;
                 }
-                if (same && q[len] == 0) return (uint32_t)i + 1;
+                if (eq && q[len] == 0) return (uint32_t)i + 1;
             } else if (sp + len < hi) {
                 const uint8_t *q = in + sp;
                 const uint8_t *q_end = in + n;
-                bool same = true;
+                bool eq = true;
                 int next = -1;                              // the stored byte right after the compared bytes, when it came along
-                for (uint32_t k = 0; k < len && same; k += 8) {
+                for (uint32_t k = 0; k < len && eq; k += 8) {
                     const uint32_t want = len - k < 8 ? len - k : 8u;
-                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : f.word(k, want));
+                    const uint64_t cw = k == 0 ? c0 : (k == 8 ? c1 : (k == 16 ? c2 : f.word(k, want)));
                     if (q + k + 8 <= q_end) {
                         const uint64_t sw = load8(q + k);
-                        if (want < 8) { same = (sw & ((1ull << (8 * want)) - 1ull)) == cw; next = (int)((sw >> (8 * want)) & 0xffu); }
-                        else same = sw == cw;
+                        if (want < 8) { eq = (sw & ((1ull << (8 * want)) - 1ull)) == cw; next = (int)((sw >> (8 * want)) & 0xffu); }
+                        else eq = sw == cw;
                     } else {
-                        same = load_upto8(q + k, want, q_end) == cw;
+                        eq = load_upto8(q + k, want, q_end) == cw;
                     }
                 }
-                if (same && stored_ends_here(in, sp, len, hi, trim, tail_bs_odd, next)) return (uint32_t)i + 1;
+                if (eq && stored_ends_here(in, sp, len, hi, trim, tail_bs_odd, next)) return (uint32_t)i + 1;
             }
         }
         i = (i + 1) & slot_mask;
