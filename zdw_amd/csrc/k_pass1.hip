@@ -86,9 +86,9 @@ __device__ __forceinline__ void classify16(const uint8_t *in, uint64_t lo, uint6
     const uint32_t bs = eq16(v, 0x5c5c5c5cu);
     m.nl = eq16(v, 0x0a0a0a0au);
     m.tab = want_tabs ? eq16(v, 0x09090909u) : 0u;
-    uint32_t prev = (uint32_t)__shfl_up((int)(bs >> 15), 1, 64);
+    uint32_t prev = wave_shr1(bs >> 15);
     if (lane == 0) prev = bs_carry;
-    bs_carry = bcast32(bs >> 15, 63);
+    bs_carry = lane_value(bs >> 15, 63);
     const uint32_t cand = (m.tab | m.nl) & ((bs << 1) | prev) & 0xffffu;
     if (__ballot(cand != 0)) {          // rare: count the run exactly (bounded by the block start)
         uint32_t c = cand, esc = 0;
@@ -105,13 +105,9 @@ __device__ __forceinline__ void classify16(const uint8_t *in, uint64_t lo, uint6
 
 __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane, uint32_t &total)
 {
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)inc, d, 64);
-        if (lane >= (uint32_t)d) inc += t;
-    }
-    total = bcast32(inc, 63);
+    (void)lane;
+    const uint32_t inc = wave_incl_sum(v);
+    total = lane_value(inc, 63);
     return inc - v;
 }
 
@@ -135,7 +131,7 @@ __global__ __launch_bounds__(64) void k_find_effective_end(const uint8_t *in, ui
             const uint64_t b = __ballot(nl != 0);
             if (b) {
                 const int hl = highest_bit(b);
-                const uint32_t hb = bcast32(31u - (uint32_t)__builtin_clz(nl | 1u), hl);
+                const uint32_t hb = lane_value(31u - (uint32_t)__builtin_clz(nl | 1u), hl);
                 result = pos + 16ull * (uint32_t)hl + hb + 1;
                 break;
             }
@@ -181,9 +177,7 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
                 uint32_t vm = 0xffffu;
                 if (pos < ss || pos + WROUND > se) vm = valid16(lp, ss, se);      // first / last round of the span
                 const uint32_t nl = m.nl & vm;
-                uint32_t pt = (uint32_t)__shfl_up((int)(nl >> 15), 1, 64);
-                if (lane == 0) pt = 0;
-                pt |= (nl << 1) & 0xffffu;
+                uint32_t pt = wave_shr1(nl >> 15) | ((nl << 1) & 0xffffu);
                 // the byte before the first position of the span (or before this round) terminated a row
                 if (prev_term) {
                     const uint64_t first = pos > ss ? pos : ss;
@@ -191,7 +185,7 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
                 }
                 mine += (uint32_t)__builtin_popcount(pt & ~nl & vm);
                 nul |= eq16(v, 0u) & vm;
-                prev_term = bcast32(nl >> 15, 63);
+                prev_term = lane_value(nl >> 15, 63);
             }
         }
         uint32_t total;
@@ -250,7 +244,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const WaveCtx &w
         }
     }
     // lanes past `count` hold no descriptor, so lane 63 sees the state after the last live one
-    row_cur = bcast32(row + (ends_row ? 1u : 0u), 63);
+    row_cur = lane_value(row + (ends_row ? 1u : 0u), 63);
     return popc64(__ballot(is_new));
 }
 
@@ -356,7 +350,7 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
                 const uint64_t lb = __ballot(late != 0);
                 if (lb) {
                     const int fl = lowest_bit(lb);
-                    const uint32_t fb = bcast32((uint32_t)__builtin_ctz(late | 0x10000u), fl);
+                    const uint32_t fb = lane_value((uint32_t)__builtin_ctz(late | 0x10000u), fl);
                     done = true;
                     if (lane > (uint32_t)fl) vm = 0;
                     else if (lane == (uint32_t)fl) vm &= (2u << fb) - 1u;
@@ -365,9 +359,7 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
             const uint32_t nl = m.nl & vm, tab = m.tab & vm;
 
             // "previous byte terminated a row" for each of my bytes
-            uint32_t pt = (uint32_t)__shfl_up((int)(nl >> 15), 1, 64);
-            if (lane == 0) pt = 0;
-            pt |= (nl << 1) & 0xffffu;
+            uint32_t pt = wave_shr1(nl >> 15) | ((nl << 1) & 0xffffu);
             if (prev_term) {
                 const uint64_t first = pos > ss ? pos : ss;
                 if (first >= lp && first < lp + 16) pt |= 1u << (uint32_t)(first - lp);
@@ -383,15 +375,19 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
             const uint32_t tail = has_nl ? (uint32_t)__builtin_popcount(tab & ~((2u << (31u - (uint32_t)__builtin_clz(nl | 1u))) - 1u))
                                          : (uint32_t)__builtin_popcount(tab);
             uint32_t seg = (has_nl ? 0x80000000u : 0u) | tail;          // inclusive segmented sum, reset flag in bit 31
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)seg, d, 64);
-                if (lane >= (uint32_t)d && !(seg & 0x80000000u)) seg = (o & 0x80000000u) | ((o & 0x7fffffffu) + seg);
+            {
+                // same step structure as wave_incl_sum; (flag, count) pairs combine as: a set flag stops the carry
+                auto fold = [&](uint32_t o) { if (!(seg & 0x80000000u)) seg = (o & 0x80000000u) | ((o & 0x7fffffffu) + seg); };
+                fold(dpp_or_zero<DPP_ROW_SHR1, 0xf>(seg));
+                fold(dpp_or_zero<DPP_ROW_SHR2, 0xf>(seg));
+                fold(dpp_or_zero<DPP_ROW_SHR4, 0xf>(seg));
+                fold(dpp_or_zero<DPP_ROW_SHR8, 0xf>(seg));
+                fold(dpp_or_zero<DPP_ROW_BCAST15, 0xa>(seg));
+                fold(dpp_or_zero<DPP_ROW_BCAST31, 0xc>(seg));
             }
-            uint32_t segx = (uint32_t)__shfl_up((int)seg, 1, 64);        // exclusive
-            if (lane == 0) segx = 0;
+            const uint32_t segx = wave_shr1(seg);                        // exclusive
             uint32_t col = (segx & 0x80000000u) ? (segx & 0x7fffffffu) : st_tabs + segx;
-            const uint32_t end_tabs = bcast32((seg & 0x80000000u) ? (seg & 0x7fffffffu) : st_tabs + seg, 63);
+            const uint32_t end_tabs = lane_value((seg & 0x80000000u) ? (seg & 0x7fffffffu) : st_tabs + seg, 63);
 
             // first terminator of the round (wave-uniform): only the row that was open when the round
             // began can be long enough to grow m_LongestLine
@@ -400,8 +396,8 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
             uint32_t ft_bit = 0;
             if (tb) {
                 ft_lane = lowest_bit(tb);
-                ft_bit = bcast32((uint32_t)__builtin_ctz(nl | 0x10000u), ft_lane);
-                const uint32_t ft_blank = bcast32((blank >> ft_bit) & 1u, ft_lane);
+                ft_bit = lane_value((uint32_t)__builtin_ctz(nl | 0x10000u), ft_lane);
+                const uint32_t ft_blank = lane_value((blank >> ft_bit) & 1u, ft_lane);
                 const uint64_t ft_pos = pos + 16ull * (uint32_t)ft_lane + ft_bit;
                 const uint64_t rl = ft_pos - st_row_start + 1;
                 if (!ft_blank && !st_ignore && rl >= FIRST_ROW_CAP - 1 && lane == 0) {
@@ -417,7 +413,7 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
             const uint32_t lp_lo = (uint32_t)pos + 16u * lane, pos_hi8 = (uint32_t)(pos >> 32) & 0xffu;
             const bool lane_ign = st_ignore && (ft_lane < 0 || lane <= (uint32_t)ft_lane);
             const bool whole = q_count + nb_total <= QCAP - 1;
-            const uint32_t b16 = bcast32(nb_before, 16), b32 = bcast32(nb_before, 32), b48 = bcast32(nb_before, 48);
+            const uint32_t b16 = lane_value(nb_before, 16), b32 = lane_value(nb_before, 32), b48 = lane_value(nb_before, 48);
             for (uint32_t piece = 0; piece < (whole ? 1u : 4u); ++piece) {
                 if (!whole) {
                     __builtin_amdgcn_wave_barrier();
@@ -460,10 +456,10 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
             if (tb) {
                 st_ignore = false;
                 const int lt_lane = highest_bit(tb);
-                const uint32_t lt_bit = bcast32(31u - (uint32_t)__builtin_clz(nl | 1u), lt_lane);
+                const uint32_t lt_bit = lane_value(31u - (uint32_t)__builtin_clz(nl | 1u), lt_lane);
                 st_row_start = pos + 16ull * (uint32_t)lt_lane + lt_bit + 1;
             }
-            prev_term = bcast32(nl >> 15, 63);
+            prev_term = lane_value(nl >> 15, 63);
 
             __builtin_amdgcn_wave_barrier();      // one wave per workgroup: LDS operations of a wave execute in order
             while (q_count >= 64) {

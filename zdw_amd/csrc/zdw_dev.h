@@ -55,6 +55,29 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane)
     uint32_t lo = bcast32((uint32_t)v, src_lane), hi = bcast32((uint32_t)(v >> 32), src_lane);
     return ((uint64_t)hi << 32) | lo;
 }
+// ---- cross-lane data movement on the vector ALU (DPP): one v_*_dpp per step instead of an LDS-crossbar
+// ---- permute; the scans below are dependent chains, so the latency of each step is what counts
+// value of `v` in the lane selected by a DPP control; lanes without a source (or masked rows) get 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
+// inclusive prefix sum over the 64 lanes: Kogge-Stone inside each row of 16, then row totals forwarded
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
+{
+    v += dpp_or_zero<DPP_ROW_SHR1, 0xf>(v);
+    v += dpp_or_zero<DPP_ROW_SHR2, 0xf>(v);
+    v += dpp_or_zero<DPP_ROW_SHR4, 0xf>(v);
+    v += dpp_or_zero<DPP_ROW_SHR8, 0xf>(v);
+    v += dpp_or_zero<DPP_ROW_BCAST15, 0xa>(v);      // lane 15 of rows 0 / 2 into rows 1 / 3
+    v += dpp_or_zero<DPP_ROW_BCAST31, 0xc>(v);      // lane 31 into rows 2 and 3
+    return v;
+}
+// the value held by lane - 1 (0 in lane 0)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return dpp_or_zero<DPP_WAVE_SHR1, 0xf>(v); }
+// wave-uniform read of one lane's value (v_readlane_b32; the lane index must be wave-uniform)
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+
 __device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 {
