@@ -18,6 +18,10 @@
  * Return values are the reference's ERR_CODE numbers (cplusplus/ConvertToZDW.h:44-70):
  * 0 OK, 7 OUT_OF_MEMORY, 15 WRONG_NUM_OF_COLUMNS_ON_A_ROW, 20 UNKNOWN_ERROR (HIP failures,
  * unsupported input); zdw_last_error() has the text.  No exception crosses this boundary.
+ * zdw_block_dict returns 7 when the block's dictionary would exceed zdw_opts.max_dict_bytes (or the
+ * format's 32-bit offsets): the caller re-runs zdw_block_pass1 for the same block with a smaller
+ * zdw_split_hint.max_rows (the reference closes a block for the same reason, memory, at an
+ * environment-dependent point).
  *
  * Threading: one context per input file; calls on one context must be serialised.
  * Ownership: the library owns all device memory and every buffer it returns (valid until the
@@ -58,7 +62,8 @@ typedef struct zdw_opts {
     uint32_t trim_trailing_spaces; /* convertDWfile -t (ConvertToZDW.cpp:295-313) */
     uint32_t first_row_capacity;   /* initial m_LongestLine; 0 = 16384 (ConvertToZDW.cpp:965) */
     uint64_t dict_slots;           /* initial hash-table slots for the string dictionary; 0 = automatic */
-    uint64_t reserved[4];
+    uint64_t max_dict_bytes;       /* a block's dictionary may not exceed this; 0 = the format's limit (2^32 - 1) */
+    uint64_t reserved[3];
 } zdw_opts;
 
 /* Where a block must end when it cannot hold the whole remaining input (reference: memory-driven,

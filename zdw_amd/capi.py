@@ -12,7 +12,7 @@ STAGE_NAMES = ["scan_rows", "pass1", "dict_compact", "dict_sort", "dict_emit", "
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("trim_trailing_spaces", C.c_uint32),
-                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("max_dict_bytes", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 
 class SplitHint(C.Structure):
@@ -89,7 +89,7 @@ class Block:
 class Encoder:
     """One zdw_ctx: the per-block seam of ConvertToZDW::processFile (cplusplus/ConvertToZDW.cpp:805-872)."""
 
-    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0):
+    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0, max_dict_bytes=0):
         self.L = lib()
         self.ncols = len(col_types)
         types = (C.c_uint8 * max(1, self.ncols))(*col_types)
@@ -99,6 +99,7 @@ class Encoder:
         o.trim_trailing_spaces = 1 if trim else 0
         o.first_row_capacity = first_row_capacity
         o.dict_slots = dict_slots
+        o.max_dict_bytes = max_dict_bytes
         h = C.c_void_p()
         rc = self.L.zdw_ctx_create(types, self.ncols, C.byref(o), C.byref(h))
         if rc:

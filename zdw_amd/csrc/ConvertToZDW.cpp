@@ -239,6 +239,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         opts.device = device;
         opts.trim_trailing_spaces = bTrimTrailingSpaces ? 1u : 0u;
         if (const char *e = getenv("ZDW_DICT_SLOTS")) opts.dict_slots = strtoull(e, NULL, 10);
+        if (const char *e = getenv("ZDW_MAX_DICT_BYTES")) opts.max_dict_bytes = strtoull(e, NULL, 10);
         const int rc = zdw_ctx_create(schema.types.data(), static_cast<uint32_t>(numColumns), &opts, &guard.ctx);
         if (rc != ZDW_OK) {
             libError = zdw_last_error(NULL);
@@ -297,10 +298,23 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
             statusOutput(INFO, "Compiling unique values\n");
         }
         zdw_split_hint hint = {0xFFFFFFFFu, 0};
-        const bool forced = static_cast<size_t>(blocks - 1) < splitRows.size();
+        bool forced = static_cast<size_t>(blocks - 1) < splitRows.size();
         if (forced) { hint.max_rows = splitRows[blocks - 1]; hint.partial_fields = splitFields[blocks - 1]; }
         zdw_pass1_result p1;
-        int rc = zdw_block_pass1(ctx, forced ? &hint : NULL, &p1);
+        const uint8_t *section = NULL; uint64_t sectionLen = 0; uint8_t indexSize = 0;
+        int rc;
+        // A block whose dictionary outgrows its limit is redone with half the rows (the reference ends a
+        // block for the same reason -- memory -- at a point that depends on the machine).
+        for (;;) {
+            rc = zdw_block_pass1(ctx, forced ? &hint : NULL, &p1);
+            if (rc != ZDW_OK || p1.num_rows == 0) break;
+            rc = zdw_block_dict(ctx, &section, &sectionLen, &indexSize);
+            if (rc != ZDW_OUT_OF_MEMORY || p1.num_rows < 2) break;
+            forced = true;
+            hint.max_rows = p1.num_rows / 2;
+            hint.partial_fields = 0;
+            if (!bQuiet) statusOutput(INFO, "\nDictionary too large for one block: retrying with %u rows\n", hint.max_rows);
+        }
         if (rc == ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW) {
             statusOutput(ERROR, "\nRow %u had the problem\n", p1.bad_row);
             res = WRONG_NUM_OF_COLUMNS_ON_A_ROW;
@@ -321,8 +335,6 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         }
         ok = ok && out.le(p1.num_rows, 4) && out.le(p1.longest_line, 4) && out.le(p1.is_last_block ? 1 : 0, 1);
 
-        const uint8_t *section = NULL; uint64_t sectionLen = 0; uint8_t indexSize = 0;
-        rc = zdw_block_dict(ctx, &section, &sectionLen, &indexSize);
         if (rc == ZDW_OK) {
             if (!bQuiet) {
                 const uint64_t dictSize = indexSize ? sectionLen - 1 - indexSize : 1;

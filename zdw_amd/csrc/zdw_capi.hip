@@ -74,7 +74,7 @@ struct zdw_ctx {
     DevBuf d_kind, d_recoff, d_numidx;
     bool trim = false;
     uint32_t row_cap = FIRST_ROW_CAP;      // emulated m_LongestLine, persists across blocks
-    uint64_t slots_opt = 0, slots_learned = 0;
+    uint64_t slots_opt = 0, slots_learned = 0, max_dict_bytes = 0;
     // input image
     const uint8_t *d_in = nullptr;
     uint64_t n = 0;
@@ -287,9 +287,12 @@ int ensure_dict(zdw_ctx *c)
         HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         c->dict_size = total + 1;                       // Dictionary::getSize(): origin byte included
-        if (c->dict_size >= (1ull << 32))
-            return fail(c, ZDW_OUT_OF_MEMORY, "dictionary of %llu bytes exceeds the format's 32-bit offsets; split the block",
-                        (unsigned long long)c->dict_size);
+        {
+            const uint64_t limit = c->max_dict_bytes && c->max_dict_bytes < (1ull << 32) ? c->max_dict_bytes : (1ull << 32) - 1;
+            if (c->dict_size > limit)
+                return fail(c, ZDW_OUT_OF_MEMORY, "dictionary of %llu bytes exceeds the limit of %llu: split the block (smaller zdw_split_hint.max_rows)",
+                            (unsigned long long)c->dict_size, (unsigned long long)limit);
+        }
         c->index_size = (uint8_t)bytes_for(c->dict_size);
         HIP_TRY(c, c->dict_sec.ensure(16 + c->dict_size));
         HIP_TRY(c, c->slot_off.ensure(c->nslots * 4));
@@ -452,6 +455,7 @@ int zdw_ctx_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opt
         c->trim = opts->trim_trailing_spaces != 0;
         c->row_cap = opts->first_row_capacity ? opts->first_row_capacity : FIRST_ROW_CAP;
         c->slots_opt = opts->dict_slots;
+        c->max_dict_bytes = opts->max_dict_bytes;
     }
     int rc = upload_schema(c);
     if (rc) { g_create_error = c->err; zdw_ctx_destroy(c); return rc; }
