@@ -414,18 +414,22 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
             const bool lane_ign = st_ignore && (ft_lane < 0 || lane <= (uint32_t)ft_lane);
             const bool whole = q_count + nb_total <= QCAP - 1;
             const uint32_t b16 = lane_value(nb_before, 16), b32 = lane_value(nb_before, 32), b48 = lane_value(nb_before, 48);
-            for (uint32_t piece = 0; piece < (whole ? 1u : 4u); ++piece) {
-                if (!whole) {
-                    __builtin_amdgcn_wave_barrier();
-                    while (q_count) {                                         // drain: batches of 64, then the rest
-                        const uint32_t cnt = q_count < 64 ? q_count : 64u;
-                        new_entries += consume(a, w, q_head, cnt, lane, row_cur);
-                        q_head += cnt;
-                        if (q_head >= QCAP) q_head -= QCAP;
-                        q_count -= cnt;
-                    }
-                    __builtin_amdgcn_wave_barrier();
+            const uint32_t npieces = whole ? 1u : 4u;
+            // One loop does both the emission (piece by piece) and the field work, so that the (large) field
+            // code exists once: before a piece of a split round the ring is drained completely, otherwise
+            // descriptors are taken 64 at a time.
+            for (uint32_t piece = 0;; ++piece) {
+                const bool drain = !whole && piece < npieces;
+                __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
+                while (drain ? q_count > 0 : q_count >= 64) {
+                    const uint32_t cnt = q_count < 64 ? q_count : 64u;
+                    new_entries += consume(a, w, q_head, cnt, lane, row_cur);
+                    q_head += cnt;
+                    if (q_head >= QCAP) q_head -= QCAP;
+                    q_count -= cnt;
                 }
+                __builtin_amdgcn_wave_barrier();
+                if (piece >= npieces) break;
                 const bool active = whole || (lane >> 4) == piece;
                 const uint32_t piece_base = whole ? 0u : (piece == 0 ? 0u : (piece == 1 ? b16 : (piece == 2 ? b32 : b48)));
                 const uint32_t piece_end = whole ? nb_total : (piece == 0 ? b16 : (piece == 1 ? b32 : (piece == 2 ? b48 : nb_total)));
@@ -460,15 +464,6 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
                 st_row_start = pos + 16ull * (uint32_t)lt_lane + lt_bit + 1;
             }
             prev_term = lane_value(nl >> 15, 63);
-
-            __builtin_amdgcn_wave_barrier();      // one wave per workgroup: LDS operations of a wave execute in order
-            while (q_count >= 64) {
-                new_entries += consume(a, w, q_head, 64, lane, row_cur);
-                q_head += 64;
-                if (q_head >= QCAP) q_head -= QCAP;
-                q_count -= 64;
-            }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     __builtin_amdgcn_wave_barrier();
