@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint6
     bool is_new = false;
     if (i < count) {
         const uint8_t *p = extra + offs[i];
-        dict_insert(global_bytes(p, p + lens[i] + 16), in, n, extra, hi, slots, slot_len, slot_mask, st, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
+        dict_insert(p, p + lens[i] + 16, in, n, extra, hi, slots, slot_len, slot_mask, st, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
     }
     const uint64_t m = __ballot(is_new);
     if (m && lane_id() == 0) {

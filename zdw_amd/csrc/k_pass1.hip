@@ -5,20 +5,24 @@
 // together with GetNextRow (getnextrow.cpp:26-84), GetDataRow/get_next_column
 // (ConvertToZDW.cpp:265-323,1048-1067) and Dictionary::insert (dictionary.cpp:31-51).
 //
-// Work decomposition (wave64, one wave per workgroup):
+// The kernel is bound by vector-ALU issue (one wave64 instruction per cycle and CU), so the design
+// goal is few instructions per input byte at full lane occupancy:
 //   * the TSV image is cut into 16 KiB spans; a wave visit owns every row that STARTS in its span
 //     and follows the last of them past the span end (no row-length limit);
-//   * the wave streams 1 KiB rounds: one coalesced 16-byte load per lane, the next round requested
-//     before the current one is looked at.  Each lane turns its 16 bytes into 16-bit tab / newline /
-//     backslash sets with SWAR compares (vector ALU only: the scalar unit is one per CU and was the
-//     bottleneck of an earlier ballot-mask formulation);
-//   * two wave prefix scans per round place every boundary: boundaries before the lane (ring slot)
-//     and tabs since the last row terminator (column);
-//   * every boundary becomes an 8-byte descriptor {end position, column, ends-a-row} in a per-wave
-//     LDS ring; a field begins one byte after the previous descriptor's end and its row is the number
-//     of row-ending descriptors before it.  Whenever 64 descriptors are pending the wave processes
-//     them one per lane (zdw_field_dev.h), so field work runs at full lane occupancy whatever the
-//     field-length distribution is;
+//   * the wave streams 1 KiB rounds: one coalesced 16-byte load per lane (next round requested
+//     before the current one is looked at), kept in a two-round LDS byte ring.  Each lane finds the
+//     tabs / newlines among its 16 bytes with exact SWAR compares; backslash escapes (rare) take a
+//     wave-uniform side path;
+//   * one wave prefix sum per round places every boundary in a per-wave LDS ring of 4-byte
+//     descriptors {end position relative to the visit, ends-a-line}.  Column and row numbers are NOT
+//     computed per byte: a field is the gap between two consecutive descriptors, its column is its
+//     distance to the last line end before it and its row the number of line ends before it -- two
+//     ballots per 64 fields;
+//   * whenever 64 descriptors are pending the wave handles them one per lane, so field work runs
+//     at full lane occupancy whatever the field-length distribution is.  Strings of <= 24 bytes and
+//     plain integers of <= 16 digits are served from the LDS byte ring in registers (NH hash with
+//     three multiplies, one 32-byte table slot decides a lookup, 24-bit SWAR digit arithmetic);
+//     everything else goes through the general form in zdw_field_dev.h / zdw_dict_dev.h;
 //   * pass 2 never re-reads the text: each field leaves a fixed-width record (u32 table slot id
 //     or u64 parsed value) in rec[row][column].
 #include "zdw_dev.h"
@@ -31,11 +35,12 @@
 namespace zdw {
 
 constexpr uint32_t WROUND = 1024;                 // bytes per wave round (16 per lane)
-constexpr uint32_t QCAP = 384;                    // ring entries per wave; a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
-constexpr uint32_t P1_WPB = 2;                    // independent waves per workgroup (the CU takes 16 workgroups; 32 waves need 2 each)
-constexpr uint32_t COL_FIELD_MASK = 0x7FFFFFu;    // descriptor: y = pos[39:32] | col << 8 | ends_row << 31
-constexpr uint32_t COL_NONE = 0x7FFFFFu;          // boundary only (blank line, foreign row, anchor position)
-constexpr uint32_t COL_ANCHOR = 0x7FFFFEu;        // x = row index of the rows that follow
+constexpr uint32_t QCAP = 512;                    // descriptor ring entries per wave (u32 each); a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
+constexpr uint32_t BYTE_RING = 2048;              // two rounds of input bytes per wave
+constexpr uint32_t RING_TAIL = 32;                // copy of the byte ring's first bytes behind its end: 24-byte reads never wrap
+constexpr uint32_t P1_WPB = 4;                    // independent waves per workgroup; they share the column tables
+constexpr uint32_t DESC_NL = 0x80000000u;         // descriptor = end position relative to the visit base | line end << 31
+constexpr uint32_t LUT_ROWS = 25;                 // byte masks "first L bytes" for L = 0..24, 32 bytes per row
 
 // ------------------------------------------------------------------------------------------
 // per-lane byte classes of 16 bytes
@@ -207,86 +212,214 @@ void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_
 }
 
 // ------------------------------------------------------------------------------------------
-// descriptor ring
+// pass 1
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ring_next(uint32_t i) { return i + 1 == QCAP ? 0u : i + 1; }
-__device__ __forceinline__ uint64_t entry_pos(const uint2 &e) { return ((uint64_t)(e.y & 0xffu) << 32) | e.x; }
+// LDS of one workgroup (byte offsets into zdw_lds):
+//   desc   P1_WPB x 2 KiB   descriptor rings (2 KiB aligned: ring addressing is one and-or)
+//   bytes  P1_WPB x (2 KiB + 32)   byte rings, each followed by a copy of its first 32 bytes
+//   lut    25 x 32 B        byte masks "first L bytes are 0xff" for L = 0..24
+//   meta / mn / mx / seen   column tables shared by the waves of the workgroup (cols_in_lds)
+struct P1Lds { uint32_t desc, bytes, lut, meta, mn, mx, seen, total; };
 
-// Processes `count` (<= 64) descriptors starting at ring index `head`, one per lane.  row_cur = row
-// index that applies at `head` (updated).  Returns how many new dictionary entries were created.
-__device__ __forceinline__ uint32_t consume(const Pass1Args &a, const WaveCtx &w, uint32_t head, uint32_t count, uint32_t lane,
-                                            uint32_t &row_cur)
+__host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool cols_in_lds)
 {
-    const uint2 *ring = reinterpret_cast<const uint2 *>(zdw_lds + w.ring);
-    const bool live = lane < count;
-    uint2 e = make_uint2(0u, COL_NONE << 8);
-    uint32_t idx = head + lane;
-    if (idx >= QCAP) idx -= QCAP;
-    if (live) e = ring[idx];
-    const uint32_t col = (e.y >> 8) & COL_FIELD_MASK;
-    const bool ends_row = (e.y >> 31) != 0;
-    // row index: the last anchor at or before this lane sets the base, row-ending descriptors after it count up
-    const uint64_t am = __ballot(live && col == COL_ANCHOR);
-    const uint64_t rm = __ballot(live && ends_row);
-    const int an = highest_bit(am & mask_le((int)lane));
-    const uint32_t anchored = (uint32_t)__shfl((int)e.x, an < 0 ? 0 : an, 64);
-    const uint32_t row = (an >= 0 ? anchored : row_cur) + popc64(rm & mask_lt((int)lane) & ~mask_le(an));
-    bool is_new = false;
-    if (live && col < COL_ANCHOR) {
+    P1Lds L;
+    L.desc = 0;
+    L.bytes = P1_WPB * QCAP * 4u;
+    L.lut = L.bytes + P1_WPB * (BYTE_RING + RING_TAIL);
+    L.meta = L.lut + LUT_ROWS * 32u;
+    uint32_t end = L.meta;
+    L.mn = L.mx = L.seen = end;
+    if (cols_in_lds) {
+        L.mn = (L.meta + 4u * ncols + 7u) & ~7u;          // 64-bit LDS atomics need 8-byte alignment
+        L.mx = L.mn + 8u * nnum;
+        L.seen = L.mx + 8u * nnum;
+        end = L.seen + ncols;
+    }
+    L.total = (end + 15u) & ~15u;
+    return L;
+}
+
+size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds) { return p1_layout(ncols, nnum, use_lds).total; }
+
+__device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *reinterpret_cast<const uint32_t *>(zdw_lds + off); }
+__device__ __forceinline__ uint64_t lds_u64(uint32_t off) { return reinterpret_cast<const PackedU64 *>(zdw_lds + off)->v; }     // any alignment
+
+// bit 7 of each byte: set iff the byte of x is non-zero (exact, no carries between bytes)
+__device__ __forceinline__ uint32_t nz7(uint32_t x) { return ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x; }
+// bits 7, 15, 23, 31 -> bits 0..3 (one 24-bit multiply)
+__device__ __forceinline__ uint32_t pack4(uint32_t m7) { return ((__umul24(m7 >> 7, 0x4081u) >> 14) & 7u) | ((m7 >> 28) & 8u); }
+__device__ __forceinline__ uint32_t pack16(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    return pack4(a) | (pack4(b) << 4) | (pack4(c) << 8) | (pack4(d) << 12);
+}
+
+// wave-uniform state of one worker wave
+struct WaveState {
+    uint32_t desc, bytes;        // LDS offsets of this wave's rings
+    uint32_t q_head, q_count;    // pending descriptors: ring indices q_head .. q_head + q_count - 1 (mod QCAP)
+    uint32_t row_cur, col_cur;   // row / column of the field that ends at the head descriptor
+    uint32_t ring_lo;            // smallest relative position the byte ring still holds
+    bool first_pending;          // the head descriptor is the visit's sentinel: the line end before the first owned row
+    uint64_t vbase;              // visit base: absolute position = vbase + relative position (multiple of BYTE_RING)
+};
+
+// Handles `cnt` (1..64) descriptors from the ring head, one per lane.  Returns how many new dictionary
+// entries were created.
+__device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const P1Lds &L, WaveState &ws, uint32_t cnt, uint32_t lane)
+{
+    const bool live = lane < cnt;
+    const uint32_t di = ws.q_head + lane;
+    const uint32_t e = lds_u32(ws.desc | ((di << 2) & (QCAP * 4u - 1u)));
+    const uint32_t pe = lds_u32(ws.desc | (((di - 1u) << 2) & (QCAP * 4u - 1u)));
+    const bool e_nl = live && (e >> 31) != 0;
+    const uint32_t e_pos = e & ~DESC_NL, fs = (pe & ~DESC_NL) + 1u;      // a field begins one byte after its predecessor's end
+    const uint32_t len = e_pos - fs;
+    const bool sentinel = ws.first_pending && lane == 0;
+    const bool blank = e_nl && (pe >> 31) != 0 && len == 0;              // line end right after a line end: no row (getnextrow.cpp:38-43)
+    const bool ends_row = e_nl && !blank && !sentinel;
+    const uint64_t nlm = __ballot(e_nl);
+    uint32_t row = ws.row_cur, col = ws.col_cur + lane;
+    uint64_t rm = 0;
+    if (nlm) {
+        rm = __ballot(ends_row);
+        row += mbcnt64(rm);
+        const uint64_t prev = nlm & mask_lt((int)lane);
+        if (prev) col = lane - 1u - (uint32_t)highest_bit(prev);
+    }
+    if (rm) {
         if (ends_row && row <= a.row_limit) {
             if (col + 1 != a.ncols) atomicMin(&a.st->bad_row, row);              // ConvertToZDW.cpp:336-337
-            if (row + 1 == a.row_limit) a.st->split_pos = entry_pos(e) + 1;      // the next block starts after this row
-        }
-        if (col < a.ncols && !(a.debug_skip & 1u)) {
-            const uint2 pe = ring[idx ? idx - 1 : QCAP - 1];
-            const uint64_t fs = (entry_pos(pe) + 1) & POS_MASK;                  // a field begins after its predecessor's end
-            process_field(a, w, fs, (uint32_t)(entry_pos(e) - fs), col, row, is_new);
+            if (row + 1 == a.row_limit) a.st->split_pos = ws.vbase + e_pos + 1;  // the next block starts after this row
         }
     }
-    // lanes past `count` hold no descriptor, so lane 63 sees the state after the last live one
-    row_cur = lane_value(row + (ends_row ? 1u : 0u), 63);
+    const bool in_block = row < a.row_limit;
+    const bool is_field = live && !sentinel && !blank && col < a.ncols && (in_block || (row == a.row_limit && col < a.partial_fields)) &&
+                          !(a.debug_skip & 1u);
+    // state for the next call
+    ws.row_cur += popc64(rm);
+    ws.col_cur = nlm ? cnt - 1u - (uint32_t)highest_bit(nlm) : ws.col_cur + cnt;
+    ws.first_pending = false;
+
+    uint32_t meta = 0;
+    if (is_field && t.cols_in_lds) meta = lds_u32(t.meta + 4u * col);
+    const uint32_t kind = meta & 3u;
+    bool slow = is_field && (!t.cols_in_lds || a.trim != 0 || fs < ws.ring_lo);
+    const bool fast = is_field && !slow;
+    const uint32_t ra = ws.bytes + (fs & (BYTE_RING - 1u));
+    uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + (meta >> 16);
+    bool is_new = false;
+
+    // ---- text-like columns, <= 24 bytes: decided by one table slot ----
+    bool ft = fast && kind == K_TEXT;
+    if (ft && len > 24u) { slow = true; ft = false; }
+    if (__ballot(ft)) {
+        if (ft) {
+            uint32_t id = 0;
+            if (len) {                                                            // empty fields are skipped (:340-341)
+                if (!zdw_lds[t.seen + col]) zdw_lds[t.seen + col] = 1;
+                const uint32_t lo = L.lut + 32u * len;
+                const uint64_t c0 = lds_u64(ra) & lds_u64(lo), c1 = lds_u64(ra + 8) & lds_u64(lo + 8), c2 = lds_u64(ra + 16) & lds_u64(lo + 16);
+                if (!(a.debug_skip & 2u)) {
+                    const uint64_t acc = nh24(c0, c1, c2);
+                    uint64_t i = hash_place(acc) & a.slot_mask;
+                    bool pending = true;
+                    for (uint32_t probe = 0; probe < 4 && pending; ++probe) {
+                        uint64_t *slot = a.slots + 4 * i;
+                        const SlotWords w = load_slot(slot);
+                        if (w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len) {
+                            id = (uint32_t)i + 1; pending = false;
+                        } else if (w.key == 0) {
+                            const uint64_t old = claim_slot(slot, a.slot_len, i, make_slot_key(hash_tag(acc), len, ws.vbase + fs), len, c0, c1, c2);
+                            if (old == 0) { is_new = true; id = (uint32_t)i + 1; } else slow = true;      // lost the race: general form
+                            pending = false;
+                        } else if (w.s0 == 0) {
+                            slow = true; pending = false;                         // claimed, inline copy not complete yet
+                        } else {
+                            i = (i + 1) & a.slot_mask;
+                        }
+                    }
+                    if (pending) slow = true;
+                }
+            }
+            if (!slow && in_block) *reinterpret_cast<uint32_t *>(recp) = id;
+        }
+    }
+
+    // ---- integers of <= 16 plain digits, char(1) ----
+    bool fn = fast && kind != K_TEXT;
+    if (fn && kind == K_INT && len > 16u) { slow = true; fn = false; }
+    if (__ballot(fn)) {
+        if (fn) {
+            uint64_t v_rec = 0, v_range = 0;
+            bool ok = true;
+            if (kind == K_INT) {
+                // the last min(len, 8) characters and the (len - 8) before them, each right-aligned in 8 with '0' in front
+                const uint32_t k = len > 8u ? len - 8u : 0u;
+                const uint64_t m2 = lds_u64(L.lut + 32u * (8u + k - len)), m1 = lds_u64(L.lut + 32u * (8u - k));
+                const uint64_t Z = 0x3030303030303030ull;
+                const uint64_t w2 = (lds_u64(ra + len - 8u) & ~m2) | (Z & m2);
+                const uint64_t w1 = (lds_u64(ra + k - 8u) & ~m1) | (Z & m1);
+                const uint32_t r0 = (uint32_t)w1, r1 = (uint32_t)(w1 >> 32), r2 = (uint32_t)w2, r3 = (uint32_t)(w2 >> 32);
+                const uint32_t t0 = r0 - 0x30303030u, t1 = r1 - 0x30303030u, t2 = r2 - 0x30303030u, t3 = r3 - 0x30303030u;
+                ok = (nondigit_bits(r0, t0) | nondigit_bits(r1, t1) | nondigit_bits(r2, t2) | nondigit_bits(r3, t3)) == 0u;
+                const uint32_t lo8 = __umul24(four_digits(t2), 10000u) + four_digits(t3);
+                const uint32_t hi8 = __umul24(four_digits(t0), 10000u) + four_digits(t1);
+                v_rec = v_range = (uint64_t)hi8 * 100000000ull + lo8;
+            } else {   // char(1): pass 1 adds byte 1 only after a backslash (:358-361), pass 2 always (:543-547)
+                const uint32_t w = (uint32_t)lds_u64(ra);
+                const uint32_t b0 = len ? (w & 0xffu) : 0u, b1 = len >= 2u ? ((w >> 8) & 0xffu) : 0u;
+                const int64_t c0 = (int8_t)b0;
+                const int64_t hi8 = (int64_t)((int)(int8_t)b1 * 256);
+                v_range = (uint64_t)(b0 == '\\' ? c0 + hi8 : c0);
+                v_rec = (uint64_t)(c0 + hi8);
+            }
+            if (!ok) slow = true;
+            else {
+                if (v_range > 0) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
+                if (in_block) *reinterpret_cast<uint64_t *>(recp) = v_rec;
+            }
+        }
+    }
+
+    // ---- everything else: the general form, from global memory ----
+    if (__ballot(slow)) {
+        if (slow) process_field_general(a, t, ws.vbase + fs, len, col, row, in_block, is_new);
+    }
     return popc64(__ballot(is_new));
 }
 
-// per-wave LDS: descriptor ring | byte ring + mirror | [column meta | min | max | seen]
-size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds)
+__global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a)
 {
-    size_t b = QCAP * sizeof(uint2) + BYTE_RING + 16;
-    if (use_lds) b += (((size_t)ncols * 4 + 7) & ~(size_t)7) + (size_t)nnum * 16 + ((ncols + 15) & ~15u);
-    return (b + 15) & ~(size_t)15;
-}
-
-__global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32_t lds_per_wave)
-{
-    // every wave of the workgroup is an independent worker with its own slice of the LDS
-    const uint32_t wb = (threadIdx.x >> 6) * lds_per_wave;
-    const uint32_t wave_id = blockIdx.x * P1_WPB + (threadIdx.x >> 6), wave_count = gridDim.x * P1_WPB;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wave_id = blockIdx.x * P1_WPB + wv, wave_count = gridDim.x * P1_WPB;
     const uint32_t lane = lane_id();
-    WaveCtx w;
-    w.ring = wb;
-    w.bytes = wb + QCAP * sizeof(uint2);
-    w.meta = w.bytes + BYTE_RING + 16;
-    w.mn = w.meta + ((4 * a.ncols + 7u) & ~7u);           // 64-bit LDS atomics need 8-byte alignment
-    w.mx = w.mn + 8 * a.nnum;
-    w.seen = w.mx + 8 * a.nnum;
-    w.cols_in_lds = a.use_lds_ranges != 0;
-    w.lds_lo = w.lds_hi = 0;
-    uint2 *ring = reinterpret_cast<uint2 *>(zdw_lds + w.ring);
-    if (w.cols_in_lds) {
-        for (uint32_t c = lane; c < a.ncols; c += 64) {
-            *reinterpret_cast<uint32_t *>(zdw_lds + w.meta + 4 * c) = pack_col_meta(a.col_kind[c], (uint32_t)a.col_numidx[c] & 0x3fffu, a.col_recoff[c]);
-            zdw_lds[w.seen + c] = 0;
+    const P1Lds L = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0);
+    ColTables t;
+    t.meta = L.meta; t.mn = L.mn; t.mx = L.mx; t.seen = L.seen; t.cols_in_lds = a.use_lds_ranges != 0;
+
+    // workgroup tables
+    for (uint32_t i = threadIdx.x; i < LUT_ROWS * 8u; i += 64 * P1_WPB) {
+        const uint32_t row = i >> 3, b0 = (i & 7u) * 4u;          // dword (i & 7) of row `row`: bytes b0 .. b0 + 3
+        const uint32_t nb = row > b0 ? (row - b0 < 4u ? row - b0 : 4u) : 0u;
+        *reinterpret_cast<uint32_t *>(zdw_lds + L.lut + 4u * i) = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+    }
+    if (t.cols_in_lds) {
+        for (uint32_t c = threadIdx.x; c < a.ncols; c += 64 * P1_WPB) {
+            *reinterpret_cast<uint32_t *>(zdw_lds + t.meta + 4 * c) = pack_col_meta(a.col_kind[c], (uint32_t)a.col_numidx[c] & 0x3fffu, a.col_recoff[c]);
+            zdw_lds[t.seen + c] = 0;
         }
-        for (uint32_t i = lane; i < a.nnum; i += 64) {
-            reinterpret_cast<uint64_t *>(zdw_lds + w.mn)[i] = ~0ull;
-            reinterpret_cast<uint64_t *>(zdw_lds + w.mx)[i] = 0;
+        for (uint32_t i = threadIdx.x; i < a.nnum; i += 64 * P1_WPB) {
+            reinterpret_cast<uint64_t *>(zdw_lds + t.mn)[i] = ~0ull;
+            reinterpret_cast<uint64_t *>(zdw_lds + t.mx)[i] = 0;
         }
     }
     __syncthreads();
 
-    uint32_t q_head = 0, q_tail = 0;   // ring indices in [0, QCAP)
-    uint32_t q_count = 0;              // pending descriptors
-    uint32_t row_cur = 0;              // row index at q_head
+    WaveState ws;
+    ws.desc = L.desc + wv * QCAP * 4u;
+    ws.bytes = L.bytes + wv * (BYTE_RING + RING_TAIL);
+    ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.first_pending = false; ws.vbase = 0;
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
     for (uint32_t si = wave_id; si < a.nspans; si += wave_count) {
@@ -304,49 +437,70 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
         const uint64_t s0 = (a.span0 + si) * (uint64_t)SPAN_BYTES;
         const uint64_t ss = s0 > a.lo ? s0 : a.lo;
         const uint64_t se = s0 + SPAN_BYTES < a.hi ? s0 + SPAN_BYTES : a.hi;
-
-        // wave-uniform state of the open row
-        const bool at_row_start = (ss == a.lo) || is_row_terminator(a.in, a.lo, ss - 1);
-        uint64_t st_row_start = ss;
-        uint32_t st_tabs = 0;
-        bool st_ignore = !at_row_start;      // the row open at ss began in an earlier span and belongs to it
-        uint32_t prev_term = at_row_start ? 1u : 0u;
         const uint64_t pos0 = ss & ~(uint64_t)(WROUND - 1);
+
+        // the visit: all descriptors of the previous one were handled, the ring is empty
+        const bool at_row_start = (ss == a.lo) || is_row_terminator(a.in, a.lo, ss - 1);
+        ws.vbase = (pos0 - WROUND) & ~(uint64_t)(BYTE_RING - 1);           // wraps below zero for the first span: only differences matter
+        ws.q_head = 0; ws.q_count = 0;
+        ws.row_cur = rowbase; ws.col_cur = 0;
+        ws.first_pending = true;
+        ws.ring_lo = (uint32_t)(pos0 - ws.vbase);
+        bool ignoring = !at_row_start;       // the row open at ss began in an earlier span and belongs to it; its line end is our sentinel
+        uint64_t st_row_start = ss;          // where the open row began (for m_LongestLine candidates)
+        if (at_row_start) {
+            if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + ws.desc) = (uint32_t)(ss - 1 - ws.vbase) | DESC_NL;
+            ws.q_count = 1;
+        }
         uint32_t bs_carry = (pos0 > a.lo && a.in[pos0 - 1] == '\\') ? 1u : 0u;
         bool done = false;
-
-        // anchor pair: the row index that applies from here on, then the position the first field starts after
-        if (lane == 0) {
-            ring[q_tail] = make_uint2(rowbase - 1u + (at_row_start ? 1u : 0u), COL_ANCHOR << 8);
-            ring[ring_next(q_tail)] = make_uint2((uint32_t)(ss - 1), ((uint32_t)((ss - 1) >> 32) & 0xffu) | (COL_NONE << 8));
-        }
-        q_tail = ring_next(ring_next(q_tail));
-        q_count += 2;
 
         uint4 nxt = load_round16(a.in, pos0, lane, a.n);
         for (uint64_t pos = pos0; !done && pos < a.hi; pos += WROUND) {
             const uint4 v = nxt;
             nxt = load_round16(a.in, pos + WROUND, lane, a.n);            // next round in flight
             const uint64_t lp = pos + 16ull * lane;
-            // keep the round in the LDS byte ring (two rounds deep): field work reads its bytes from there
-            {
+            uint32_t relb = (uint32_t)(pos - ws.vbase);                   // relative position of the round
+            {   // keep the round in the LDS byte ring (two rounds deep): field work reads its bytes from there
                 const uint32_t slot = (uint32_t)pos & (BYTE_RING - 1);            // 0 or 1024
-                *reinterpret_cast<uint4 *>(zdw_lds + w.bytes + slot + 16u * lane) = v;
-                if (slot == 0 && lane == 0) *reinterpret_cast<uint2 *>(zdw_lds + w.bytes + BYTE_RING) = make_uint2(v.x, v.y);   // mirror for reads that straddle the wrap
-                if (pos == w.lds_hi) { w.lds_hi = pos + WROUND; if (w.lds_hi - w.lds_lo > BYTE_RING) w.lds_lo = w.lds_hi - BYTE_RING; }
-                else { w.lds_lo = pos; w.lds_hi = pos + WROUND; }
-                // bytes past the end of the image are re-read filler: never trust them
-                if (w.lds_hi > a.n) w.lds_hi = a.n > w.lds_lo ? a.n : w.lds_lo;
+                *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + slot + 16u * lane) = v;
+                if (slot == 0 && lane < RING_TAIL / 16u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + BYTE_RING + 16u * lane) = v;
             }
-            Lane16 m;
-            classify16(a.in, a.lo, a.n, lp, v, lane, bs_carry, m, true);
 
-            // positions that exist for this visit: [ss, hi), cut after the first terminator at or past se - 1
-            uint32_t vm = 0xffffu;
-            const bool edge = pos < ss || pos + WROUND > se - 1;
-            if (edge) {
-                vm = valid16(lp, ss, a.hi);
-                const uint32_t late = m.nl & vm & valid16(lp, se - 1, ~0ull);
+            // ---- classify: exact tab / newline sets of my 16 bytes; escapes resolved (Q1, Q4) ----
+            uint32_t bnd, nl = 0;
+            {
+                const uint32_t tn0 = nz7(v.x ^ 0x0a0a0a0au), tn1 = nz7(v.y ^ 0x0a0a0a0au), tn2 = nz7(v.z ^ 0x0a0a0a0au), tn3 = nz7(v.w ^ 0x0a0a0a0au);
+                const uint32_t tb0 = nz7(v.x ^ 0x5c5c5c5cu), tb1 = nz7(v.y ^ 0x5c5c5c5cu), tb2 = nz7(v.z ^ 0x5c5c5c5cu), tb3 = nz7(v.w ^ 0x5c5c5c5cu);
+                const uint32_t H = 0x80808080u;
+                bnd = pack16(~(nz7(v.x ^ 0x09090909u) & tn0) & H, ~(nz7(v.y ^ 0x09090909u) & tn1) & H,
+                             ~(nz7(v.z ^ 0x09090909u) & tn2) & H, ~(nz7(v.w ^ 0x09090909u) & tn3) & H);
+                if (__ballot(((tn0 & tn1 & tn2 & tn3) & H) != H)) nl = pack16(~tn0 & H, ~tn1 & H, ~tn2 & H, ~tn3 & H);
+                if (__ballot(((tb0 & tb1 & tb2 & tb3) & H) != H) | bs_carry) {
+                    // a backslash in (or right before) this round: special iff an even number of backslashes precedes
+                    const uint32_t bs = pack16(~tb0 & H, ~tb1 & H, ~tb2 & H, ~tb3 & H);
+                    uint32_t prev = wave_shr1(bs >> 15);
+                    if (lane == 0) prev = bs_carry;
+                    bs_carry = lane_value(bs >> 15, 63);
+                    const uint32_t cand = bnd & ((bs << 1) | prev) & 0xffffu;
+                    if (__ballot(cand != 0)) {          // count the run exactly (bounded by the block start)
+                        uint32_t c = cand, esc = 0;
+                        while (c) {
+                            const uint32_t i = (uint32_t)__builtin_ctz(c);
+                            c &= c - 1;
+                            // (lanes past the end of the image hold re-read bytes: never follow those into memory)
+                            if (lp + i > a.lo && lp + i < a.n && (backslashes_before(a.in, a.lo, lp + i) & 1u)) esc |= 1u << i;
+                        }
+                        bnd &= ~esc;
+                        nl &= ~esc;
+                    }
+                }
+            }
+
+            // positions that exist for this visit: [ss, hi), cut after the first line end at or past se - 1
+            if (pos < ss || pos + WROUND > se - 1) {
+                uint32_t vm = valid16(lp, ss, a.hi);
+                const uint32_t late = nl & vm & valid16(lp, se - 1, ~0ull);
                 const uint64_t lb = __ballot(late != 0);
                 if (lb) {
                     const int fl = lowest_bit(lb);
@@ -355,132 +509,103 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
                     if (lane > (uint32_t)fl) vm = 0;
                     else if (lane == (uint32_t)fl) vm &= (2u << fb) - 1u;
                 }
+                nl &= vm; bnd &= vm;
             }
-            const uint32_t nl = m.nl & vm, tab = m.tab & vm;
 
-            // "previous byte terminated a row" for each of my bytes
-            uint32_t pt = wave_shr1(nl >> 15) | ((nl << 1) & 0xffffu);
-            if (prev_term) {
-                const uint64_t first = pos > ss ? pos : ss;
-                if (first >= lp && first < lp + 16) pt |= 1u << (uint32_t)(first - lp);
-                if (pos >= ss) st_row_start = pos;      // the open row begins with this round
-            }
-            const uint32_t blank = nl & pt;              // empty line: terminator right after a terminator
-            const uint32_t bnd = tab | nl;
-
-            // wave scans: boundaries before this lane; tabs since the last terminator before this lane
-            uint32_t nb_total;
-            const uint32_t nb_before = wave_excl_sum((uint32_t)__builtin_popcount(bnd), lane, nb_total);
-            const bool has_nl = nl != 0;
-            const uint32_t tail = has_nl ? (uint32_t)__builtin_popcount(tab & ~((2u << (31u - (uint32_t)__builtin_clz(nl | 1u))) - 1u))
-                                         : (uint32_t)__builtin_popcount(tab);
-            uint32_t seg = (has_nl ? 0x80000000u : 0u) | tail;          // inclusive segmented sum, reset flag in bit 31
-            {
-                // same step structure as wave_incl_sum; (flag, count) pairs combine as: a set flag stops the carry
-                auto fold = [&](uint32_t o) { if (!(seg & 0x80000000u)) seg = (o & 0x80000000u) | ((o & 0x7fffffffu) + seg); };
-                fold(dpp_or_zero<DPP_ROW_SHR1, 0xf>(seg));
-                fold(dpp_or_zero<DPP_ROW_SHR2, 0xf>(seg));
-                fold(dpp_or_zero<DPP_ROW_SHR4, 0xf>(seg));
-                fold(dpp_or_zero<DPP_ROW_SHR8, 0xf>(seg));
-                fold(dpp_or_zero<DPP_ROW_BCAST15, 0xa>(seg));
-                fold(dpp_or_zero<DPP_ROW_BCAST31, 0xc>(seg));
-            }
-            const uint32_t segx = wave_shr1(seg);                        // exclusive
-            uint32_t col = (segx & 0x80000000u) ? (segx & 0x7fffffffu) : st_tabs + segx;
-            const uint32_t end_tabs = lane_value((seg & 0x80000000u) ? (seg & 0x7fffffffu) : st_tabs + seg, 63);
-
-            // first terminator of the round (wave-uniform): only the row that was open when the round
-            // began can be long enough to grow m_LongestLine
-            const uint64_t tb = __ballot(has_nl);
-            int ft_lane = -1;
-            uint32_t ft_bit = 0;
+            // line ends of the round (wave-uniform bookkeeping): m_LongestLine candidates, the sentinel of a
+            // visit that starts inside a foreign row
+            const uint64_t tb = __ballot(nl != 0);
             if (tb) {
-                ft_lane = lowest_bit(tb);
-                ft_bit = lane_value((uint32_t)__builtin_ctz(nl | 0x10000u), ft_lane);
-                const uint32_t ft_blank = lane_value((blank >> ft_bit) & 1u, ft_lane);
-                const uint64_t ft_pos = pos + 16ull * (uint32_t)ft_lane + ft_bit;
-                const uint64_t rl = ft_pos - st_row_start + 1;
-                if (!ft_blank && !st_ignore && rl >= FIRST_ROW_CAP - 1 && lane == 0) {
-                    const uint32_t li = atomicAdd(&a.st->long_count, 1u);
-                    if (li < a.long_cap) { a.long_rows[li].start = st_row_start; a.long_rows[li].len = rl; }
+                const int ft_lane = lowest_bit(tb);
+                const uint32_t ft_bit = lane_value((uint32_t)__builtin_ctz(nl | 0x10000u), ft_lane);
+                if (!ignoring) {
+                    // only the row that was open when the round began can be long enough to grow m_LongestLine
+                    const uint64_t rl = pos + 16ull * (uint32_t)ft_lane + ft_bit - st_row_start + 1;
+                    if (rl >= FIRST_ROW_CAP - 1 && lane == 0) {
+                        const uint32_t li = atomicAdd(&a.st->long_count, 1u);
+                        if (li < a.long_cap) { a.long_rows[li].start = st_row_start; a.long_rows[li].len = rl; }
+                    }
+                } else {
+                    if (lane < (uint32_t)ft_lane) bnd = 0;
+                    else if (lane == (uint32_t)ft_lane) bnd &= ~((1u << ft_bit) - 1u);
+                    ignoring = false;
                 }
-            }
-
-            // emit this lane's boundaries.  The ring always keeps the head's predecessor, so it can take
-            // QCAP - 1 - pending new descriptors; a denser round is emitted as four 16-lane pieces (<= 256
-            // boundaries each, which always fit an empty ring) with the ring drained in between.
-            static_assert(QCAP >= 256 + 2, "a drained ring must take one 16-lane piece");
-            const uint32_t lp_lo = (uint32_t)pos + 16u * lane, pos_hi8 = (uint32_t)(pos >> 32) & 0xffu;
-            const bool lane_ign = st_ignore && (ft_lane < 0 || lane <= (uint32_t)ft_lane);
-            const bool whole = q_count + nb_total <= QCAP - 1;
-            const uint32_t b16 = lane_value(nb_before, 16), b32 = lane_value(nb_before, 32), b48 = lane_value(nb_before, 48);
-            const uint32_t npieces = whole ? 1u : 4u;
-            // One loop does both the emission (piece by piece) and the field work, so that the (large) field
-            // code exists once: before a piece of a split round the ring is drained completely, otherwise
-            // descriptors are taken 64 at a time.
-            for (uint32_t piece = 0;; ++piece) {
-                const bool drain = !whole && piece < npieces;
-                __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
-                while (drain ? q_count > 0 : q_count >= 64) {
-                    const uint32_t cnt = q_count < 64 ? q_count : 64u;
-                    new_entries += consume(a, w, q_head, cnt, lane, row_cur);
-                    q_head += cnt;
-                    if (q_head >= QCAP) q_head -= QCAP;
-                    q_count -= cnt;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (piece >= npieces) break;
-                const bool active = whole || (lane >> 4) == piece;
-                const uint32_t piece_base = whole ? 0u : (piece == 0 ? 0u : (piece == 1 ? b16 : (piece == 2 ? b32 : b48)));
-                const uint32_t piece_end = whole ? nb_total : (piece == 0 ? b16 : (piece == 1 ? b32 : (piece == 2 ? b48 : nb_total)));
-                const uint32_t piece_total = piece_end - piece_base;
-                uint32_t qi = q_tail + (nb_before - piece_base);
-                if (qi >= QCAP) qi -= QCAP;
-                uint32_t bits = active ? bnd : 0u;
-                while (bits) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(bits);
-                    const uint32_t bit = bits & (0u - bits);
-                    bits &= bits - 1;
-                    const bool is_term = (nl & bit) != 0;
-                    const bool ign = lane_ign && !(lane == (uint32_t)ft_lane && i > ft_bit);
-                    uint32_t c = col < COL_ANCHOR ? col : COL_ANCHOR - 1;       // absurdly wide rows still count as "wrong"
-                    uint32_t ends = is_term ? 0x80000000u : 0u;
-                    if ((blank & bit) || ign) { c = COL_NONE; if (blank & bit) ends = 0; }
-                    ring[qi] = make_uint2(lp_lo + i, pos_hi8 | (c << 8) | ends);
-                    qi = ring_next(qi);
-                    col = is_term ? 0u : col + 1;
-                }
-                q_tail += piece_total;
-                if (q_tail >= QCAP) q_tail -= QCAP;
-                q_count += piece_total;
-            }
-
-            // state at the end of the round
-            st_tabs = end_tabs;
-            if (tb) {
-                st_ignore = false;
                 const int lt_lane = highest_bit(tb);
                 const uint32_t lt_bit = lane_value(31u - (uint32_t)__builtin_clz(nl | 1u), lt_lane);
                 st_row_start = pos + 16ull * (uint32_t)lt_lane + lt_bit + 1;
+            } else if (ignoring) {
+                bnd = 0;
             }
-            prev_term = lane_value(nl >> 15, 63);
+
+            // ---- emit this lane's boundaries; handle descriptors 64 at a time ----
+            // The ring always keeps the head's predecessor, so it can take QCAP - 1 - pending new descriptors;
+            // a denser round is emitted as four 16-lane pieces (<= 256 boundaries each, which always fit an
+            // empty ring) with the ring drained in between.  One loop does both, so that the (large) field
+            // code exists once.
+            static_assert(QCAP >= 256 + 2, "a drained ring must take one 16-lane piece");
+            uint32_t nb_total;
+            const uint32_t nb_before = wave_excl_sum((uint32_t)__builtin_popcount(bnd), lane, nb_total);
+            bool rebase = relb >= a.rebase_at;                           // relative positions must stay below 2^31
+            const bool whole = !rebase && ws.q_count + nb_total <= QCAP - 1;
+            const bool end_of_visit = done || pos + WROUND >= a.hi;
+            const uint32_t b16 = lane_value(nb_before, 16), b32 = lane_value(nb_before, 32), b48 = lane_value(nb_before, 48);
+            const uint32_t npieces = whole ? 1u : 4u;
+            for (uint32_t piece = 0;; ++piece) {
+                const bool emitting = piece < npieces;
+                const bool drain = emitting ? !whole : end_of_visit;
+                __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
+                while (drain ? ws.q_count > 0 : ws.q_count >= 64) {
+                    const uint32_t cnt = ws.q_count < 64 ? ws.q_count : 64u;
+                    new_entries += consume(a, t, L, ws, cnt, lane);
+                    ws.q_head += cnt;
+                    ws.q_count -= cnt;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (!emitting) break;
+                if (rebase) {
+                    // nothing is pending: move the visit base up; the head's predecessor moves with it
+                    const uint32_t delta = (relb - 2u * BYTE_RING) & ~(BYTE_RING - 1u);
+                    if (!ws.first_pending) {
+                        const uint32_t pa = ws.desc | (((ws.q_head - 1u) << 2) & (QCAP * 4u - 1u));
+                        const uint32_t pd = lds_u32(pa);
+                        uint32_t pp = pd & ~DESC_NL;
+                        if (pp < delta) { pp = delta; if (lane == 0) a.st->nul_seen = 2; }      // a single field of 1 GiB or more
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + pa) = (pd & DESC_NL) | (pp - delta);
+                    }
+                    ws.vbase += delta; ws.ring_lo -= delta; relb -= delta;
+                    rebase = false;
+                }
+                const bool active = whole || (lane >> 4) == piece;
+                const uint32_t piece_base = whole ? 0u : (piece == 0 ? 0u : (piece == 1 ? b16 : (piece == 2 ? b32 : b48)));
+                const uint32_t piece_end = whole ? nb_total : (piece == 0 ? b16 : (piece == 1 ? b32 : (piece == 2 ? b48 : nb_total)));
+                uint32_t qoff = (ws.q_head + ws.q_count + nb_before - piece_base) << 2;
+                const uint32_t lrel = relb + 16u * lane;
+                uint32_t bits = active ? bnd : 0u;
+                while (bits) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1;
+                    *reinterpret_cast<uint32_t *>(zdw_lds + (ws.desc | (qoff & (QCAP * 4u - 1u)))) = (lrel + i) | (((nl >> i) & 1u) << 31);
+                    qoff += 4;
+                }
+                ws.q_count += piece_end - piece_base;
+            }
+            ws.ring_lo = relb;              // the next round keeps this one next to it in the byte ring
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (q_count) new_entries += consume(a, w, q_head, q_count, lane, row_cur);
     __syncthreads();
     if (new_entries && lane == 0) {
         const uint32_t total = atomicAdd(&a.st->entries, new_entries) + new_entries;
         if (total > a.max_entries) a.st->overflow = 1;
     }
 
-    if (w.cols_in_lds) {   // one flush per wave
-        for (uint32_t c = lane; c < a.ncols; c += 64) {
+    if (t.cols_in_lds) {   // one flush per workgroup
+        for (uint32_t c = threadIdx.x; c < a.ncols; c += 64 * P1_WPB) {
             if (a.col_kind[c] == K_TEXT) {
-                if (zdw_lds[w.seen + c]) a.col_seen[c] = 1;
+                if (zdw_lds[t.seen + c]) a.col_seen[c] = 1;
             } else {
                 const uint32_t i = (uint32_t)a.col_numidx[c];
-                const uint64_t mn = reinterpret_cast<const uint64_t *>(zdw_lds + w.mn)[i], mx = reinterpret_cast<const uint64_t *>(zdw_lds + w.mx)[i];
+                const uint64_t mn = reinterpret_cast<const uint64_t *>(zdw_lds + t.mn)[i], mx = reinterpret_cast<const uint64_t *>(zdw_lds + t.mx)[i];
                 if (mx != 0) {
                     atomicMin(reinterpret_cast<unsigned long long *>(&a.col_min[c]), (unsigned long long)mn);
                     atomicMax(reinterpret_cast<unsigned long long *>(&a.col_max[c]), (unsigned long long)mx);
@@ -493,14 +618,13 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a, uint32
 void launch_pass1(const Pass1Args &a, hipStream_t s)
 {
     if (!a.nspans) return;
-    const size_t lds_wave = (pass1_lds_bytes(a.ncols, a.nnum, a.use_lds_ranges != 0) + 15) & ~(size_t)15;
-    const size_t lds = lds_wave * P1_WPB;
+    const size_t lds = pass1_lds_bytes(a.ncols, a.nnum, a.use_lds_ranges != 0);
     // Waves walk the spans with a grid stride, so every wave carries the same share of the block: the grid
     // must not exceed what is resident at once, or the surplus waves run alone after the others finish.
     int per_cu = 0, dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pass1, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pass1, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
     const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules
     if ((size_t)per_cu > by_lds && by_lds >= 1) per_cu = (int)by_lds;
     if (per_cu > 16) per_cu = 16;                                               // workgroup slots per CU
@@ -508,7 +632,7 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / P1_WPB;   // tuning experiments
     const uint32_t want_blocks = (a.nspans + P1_WPB - 1) / P1_WPB;
     const uint32_t grid = want_blocks < max_blocks ? want_blocks : (max_blocks ? max_blocks : 1u);
-    hipLaunchKernelGGL(k_pass1, dim3(grid), dim3(64 * P1_WPB), lds, s, a, (uint32_t)lds_wave);
+    hipLaunchKernelGGL(k_pass1, dim3(grid), dim3(64 * P1_WPB), lds, s, a);
 }
 
 }  // namespace zdw

@@ -579,7 +579,8 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
 
     // ---- pass 1 proper (also runs for zero rows when a partial row pollutes the block) ----
     // column facts and ranges live in per-wave LDS when they fit there (and in the packed 14 + 16 bit form)
-    const bool lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) <= 20 * 1024 && c->nnum < 16384 && c->rec_stride < 65536;
+    const bool lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) - pass1_lds_bytes(c->ncols, c->nnum, false) <= 40 * 1024 &&
+                            c->nnum < 16384 && c->rec_stride < 65536;
     // dictionary table (32-byte slots): one slot per 32 input bytes, within [2^14, 2^25] (1 GiB); load factor
     // limit 5/8; a context remembers what its last block needed
     uint64_t nslots = c->slots_opt;
@@ -607,7 +608,6 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         HIP_TRY(c, hipMemsetAsync(c->col_seen.p, 0, c->ncols + 8, s));
         P1Status init{};
         init.bad_row = 0xFFFFFFFFu; init.split_pos = c->n;
-        if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) init.pad = (uint32_t)atoi(dbg) & 48u;
         HIP_TRY(c, hipMemcpyAsync(c->status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
         c->nslots = nslots;
         if (hi > lo && total_rows) {
@@ -623,6 +623,8 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             a.slots = c->slots.as<uint64_t>(); a.slot_len = c->slot_len.as<uint32_t>(); a.slot_mask = nslots - 1;
             a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 8 * 5, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
+            a.rebase_at = 1u << 30;
+            if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::max(16384u, (uint32_t)strtoul(e, nullptr, 10));   // tests
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
             launch_pass1(a, s);
@@ -631,6 +633,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         HIP_TRY(c, hipStreamSynchronize(s));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));
+        if (st.nul_seen == 2) return fail(c, ZDW_UNKNOWN_ERROR, "a single field of 1 GiB or more is not supported");
         if (!st.overflow) break;
         nslots <<= 4;                       // table too small for this block's uniques: grow and redo the pass
         if (attempt > 6) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");

@@ -17,7 +17,7 @@ struct P1Status {
     uint32_t entries;       // unique strings inserted
     uint32_t long_count;    // rows >= 16383 bytes recorded in long_rows
     uint64_t split_pos;     // start of row `row_limit` (the first row of the next block)
-    uint32_t nul_seen;      // NUL byte in the input (unsupported)
+    uint32_t nul_seen;      // 1: NUL byte in the input (unsupported); 2: a single field of 1 GiB or more
     uint32_t pad;
 };
 
@@ -34,7 +34,7 @@ struct Pass1Args {
     const uint32_t *col_recoff;
     const int32_t *col_numidx;
     uint32_t nnum;
-    uint32_t use_lds_ranges;              // 1: per-wave LDS min/max + seen, flushed once per wave
+    uint32_t use_lds_ranges;              // 1: column facts, min/max and seen in workgroup LDS, flushed once per workgroup
     uint32_t rec_stride; uint8_t *rec;    // rec[row][...]: u64 per numeric column, u32 id per text column
     uint32_t row_limit, partial_fields;
     uint32_t trim;
@@ -42,7 +42,8 @@ struct Pass1Args {
     uint64_t *col_min; uint64_t *col_max; uint8_t *col_seen;
     P1Status *st;
     LongRow *long_rows; uint32_t long_cap;
-    uint32_t debug_skip;                  // profiling only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary, 4 no integer parse, 8 no rec stores
+    uint32_t rebase_at;                   // relative position at which a visit moves its base (2^30; tests lower it)
+    uint32_t debug_skip;                  // profiling only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary
 };
 
 struct Pass2Args {
