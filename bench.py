@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--pass1-only", action="store_true", help="profiling: time pass 1 alone (not a valid bench line)")
     args = ap.parse_args()
 
     import torch
@@ -121,6 +122,8 @@ def main():
         rc, p1 = enc.pass1()
         if rc:
             raise capi.ZdwError(rc, "pass1")
+        if args.pass1_only:
+            return p1.num_rows, 0, 0
         _, dlen, _ = enc.dict_section_device()
         enc.stats()
         _, rlen = enc.pass2_device()

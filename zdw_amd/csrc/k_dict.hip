@@ -1,7 +1,7 @@
-// k_dict.hip — the block dictionary after pass 1: compaction of the hash table into a list of
-// unique strings, an exact string sort into strcmp order (unsigned bytes, shorter prefix first:
-// cplusplus/dictionary.h:30-35), offset assignment and the dictionary blob
-// (Dictionary::write, cplusplus/dictionary.cpp:76-111).
+// k_dict.hip — the block dictionary after pass 1: an exact string sort of the unique strings
+// (uniq_pos / uniq_len by unique id, as pass 1 left them; ids with length 0 are holes) into strcmp
+// order (unsigned bytes, shorter prefix first: cplusplus/dictionary.h:30-35), offset assignment and the
+// dictionary blob (Dictionary::write, cplusplus/dictionary.cpp:76-111).
 //
 // The sort is an MSD-by-8-bytes refinement: round d sorts the still-tied strings by
 // (tie group, big-endian bytes [8d, 8d+8)) with a stable LSD radix sort (8-bit digits; histogram,
@@ -15,76 +15,6 @@
 namespace zdw {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
-
-// ------------------------------------------------------------------------------------------
-// table -> list of uniques (order is arbitrary; the sort makes it canonical)
-// ------------------------------------------------------------------------------------------
-// Each workgroup owns a contiguous run of slots: it counts its occupied slots (ballots, no atomics),
-// reserves that many output entries with ONE atomic, then walks the run again (L2-warm) to fill them.
-__global__ __launch_bounds__(256) void k_dict_compact(const uint64_t *__restrict__ slots, const uint32_t *__restrict__ slot_len,
-                                                       uint64_t nslots, uint64_t per_block, uint64_t *__restrict__ uniq_pos,
-                                                       uint32_t *__restrict__ uniq_len, uint32_t *__restrict__ uniq_slot,
-                                                       uint32_t *count)
-{
-    __shared__ uint32_t wave_cnt[4];
-    __shared__ uint32_t wave_max[4];
-    __shared__ uint32_t block_base;
-    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint64_t beg = (uint64_t)blockIdx.x * per_block;
-    const uint64_t end = beg + per_block < nslots ? beg + per_block : nslots;
-    uint32_t mine = 0, ml = 0;
-    for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
-        if (slots[4 * i] != 0) { ++mine; const uint32_t l = slot_len[i]; ml = l > ml ? l : ml; }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        mine += (uint32_t)__shfl_xor((int)mine, d, 64);
-        const uint32_t o = (uint32_t)__shfl_xor((int)ml, d, 64);
-        ml = o > ml ? o : ml;
-    }
-    if (lane == 0) { wave_cnt[wv] = mine; wave_max[wv] = ml; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        uint32_t m = wave_max[0];
-        for (int k = 1; k < 4; ++k) m = wave_max[k] > m ? wave_max[k] : m;
-        block_base = tot ? atomicAdd(count, tot) : 0u;
-        if (m) atomicMax(count + 1, m);          // count[1] = longest string (bounds the sort rounds)
-    }
-    __syncthreads();
-    // second walk, wave by wave in slot order: wave w handles rounds w, w+4, ... of 64 slots
-    uint32_t running = block_base;
-    for (uint64_t r0 = beg; r0 < end; r0 += 256) {
-        // occupied counts of the four 64-slot groups of this 256-slot step
-        uint32_t before = 0, step_total = 0;
-        uint64_t my_mask = 0; uint64_t my_w = 0; uint64_t my_i = 0;
-        for (uint32_t g = 0; g < 4; ++g) {
-            const uint64_t i = r0 + 64ull * g + lane;
-            const uint64_t w = i < end ? slots[4 * i] : 0ull;
-            const uint64_t m = __ballot(w != 0);
-            if (g < wv) before += popc64(m);
-            if (g == wv) { my_mask = m; my_w = w; my_i = i; }
-            step_total += popc64(m);
-        }
-        if (my_w != 0) {
-            const uint32_t k = running + before + mbcnt64(my_mask);
-            uniq_pos[k] = (my_w & POS_MASK) - 1;
-            uniq_len[k] = slot_len[my_i];
-            uniq_slot[k] = (uint32_t)my_i;
-        }
-        running += step_total;
-    }
-}
-
-void launch_dict_compact(const uint64_t *slots, const uint32_t *slot_len, uint64_t nslots, uint64_t *uniq_pos, uint32_t *uniq_len,
-                         uint32_t *uniq_slot, uint32_t *count, hipStream_t s)
-{
-    uint64_t per_block = 256ull * 16;                      // 4096 slots (128 KiB of table) per workgroup
-    while ((nslots + per_block - 1) / per_block > 65536) per_block *= 2;
-    const uint32_t grid = (uint32_t)((nslots + per_block - 1) / per_block);
-    hipLaunchKernelGGL(k_dict_compact, dim3(grid ? grid : 1), dim3(256), 0, s, slots, slot_len, nslots, per_block, uniq_pos, uniq_len,
-                       uniq_slot, count);
-}
 
 // ------------------------------------------------------------------------------------------
 // LSD radix sort of (u64 key, u32 value) pairs, 8-bit digits.  One wave per 2048-element chunk.
@@ -175,7 +105,9 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ i
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t u = order[active[j]];
-    keys[j] = sort_key8(string_at(in, extra, uniq_pos[u]), uniq_len[u], depth);
+    const uint32_t len = uniq_len[u];
+    // a hole (length 0) sorts before every string (first byte >= 1) and apart from every other hole
+    keys[j] = len ? sort_key8(string_at(in, extra, uniq_pos[u]), len, depth) : (uint64_t)u;
     vals[j] = j;
 }
 
@@ -303,7 +235,7 @@ __global__ __launch_bounds__(256) void k_dict_lengths(const uint32_t *__restrict
                                                        uint32_t n, uint32_t *__restrict__ len_plus1)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) len_plus1[r] = uniq_len[order[r]] + 1;
+    if (r < n) { const uint32_t len = uniq_len[order[r]]; len_plus1[r] = len ? len + 1 : 0u; }    // holes take no room
 }
 
 void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s)
@@ -313,32 +245,31 @@ void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64
 }
 
 // one string per thread: copy into the blob (offset 1 + exclusive sum of len+1), NUL terminate,
-// publish the offset for its table slot
+// publish the offset for its unique id
 __global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
                                                     const uint32_t *__restrict__ order, const uint64_t *__restrict__ uniq_pos,
-                                                    const uint32_t *__restrict__ uniq_len, const uint32_t *__restrict__ uniq_slot,
-                                                    const uint64_t *__restrict__ off_excl, uint32_t n, uint8_t *__restrict__ blob,
-                                                    uint32_t *__restrict__ slot_off)
+                                                    const uint32_t *__restrict__ uniq_len, const uint64_t *__restrict__ off_excl, uint32_t n,
+                                                    uint8_t *__restrict__ blob, uint32_t *__restrict__ id_off)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r == 0) blob[0] = 0;                                     // origin byte (dictionary.cpp:96)
     if (r >= n) return;
     const uint32_t u = order[r];
-    const uint64_t off = 1 + off_excl[r];
     const uint32_t len = uniq_len[u];
+    if (!len) return;                                            // hole
+    const uint64_t off = 1 + off_excl[r];
     const uint8_t *p = string_at(in, extra, uniq_pos[u]);
     uint8_t *q = blob + off;
     for (uint32_t i = 0; i < len; ++i) q[i] = p[i];
     q[len] = 0;
-    slot_off[uniq_slot[u]] = (uint32_t)off;
+    id_off[u] = (uint32_t)off;
 }
 
 void launch_dict_emit(const uint8_t *in, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos, const uint32_t *uniq_len,
-                      const uint32_t *uniq_slot, const uint64_t *off_excl, uint64_t n, uint8_t *blob, uint32_t *slot_off, hipStream_t s)
+                      const uint64_t *off_excl, uint64_t n, uint8_t *blob, uint32_t *id_off, hipStream_t s)
 {
     const uint32_t grid = n ? (uint32_t)((n + 255) / 256) : 1u;
-    hipLaunchKernelGGL(k_dict_emit, dim3(grid), dim3(256), 0, s, in, extra, order, uniq_pos, uniq_len, uniq_slot, off_excl, (uint32_t)n,
-                       blob, slot_off);
+    hipLaunchKernelGGL(k_dict_emit, dim3(grid), dim3(256), 0, s, in, extra, order, uniq_pos, uniq_len, off_excl, (uint32_t)n, blob, id_off);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -350,9 +281,10 @@ __global__ __launch_bounds__(256) void k_export_strings(const uint8_t *__restric
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint32_t len = uniq_len[i];
+    if (!len) return;                                            // hole: no bytes were reserved for it
     const uint8_t *p = string_at(in, extra, uniq_pos[i]);
     uint8_t *q = bytes + off_excl[i];
-    const uint32_t len = uniq_len[i];
     for (uint32_t k = 0; k < len; ++k) q[k] = p[k];
     q[len] = 0;
 }
@@ -366,30 +298,39 @@ void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64
 }
 
 __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *__restrict__ lens,
-                                                         const uint64_t *__restrict__ offs, uint64_t count, uint64_t *slots,
-                                                         uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim,
-                                                         uint64_t hi, P1Status *st)
+                                                         const uint64_t *__restrict__ offs, uint64_t count, DictTable d, uint32_t max_entries,
+                                                         uint32_t trim, uint64_t hi)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool is_new = false;
-    if (i < count) {
-        const uint8_t *p = extra + offs[i];
-        dict_insert(p, p + lens[i] + 16, in, n, extra, hi, slots, slot_len, slot_mask, st, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
+    IdAlloc al;
+    al.cur = al.end = 0;
+    const bool mine = i < count && lens[i] != 0;                 // a length of 0 is the exporter's hole
+    const uint64_t mm = __ballot(mine);
+    if (mm) {
+        if (mine) {
+            const uint8_t *p = extra + offs[i];
+            dict_insert(p, p + lens[i] + 16, in, n, extra, hi, d, al, 0u, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
+        }
+        adopt_ids(al, mm);
+        retire_ids(al, d.uniq_len, d.id_cap);
     }
     const uint64_t m = __ballot(is_new);
     if (m && lane_id() == 0) {
-        const uint32_t total = atomicAdd(&st->entries, popc64(m)) + popc64(m);
-        if (total > max_entries) st->overflow = 1;
+        const uint32_t total = atomicAdd(&d.st->entries, popc64(m)) + popc64(m);
+        if (total > max_entries) d.st->overflow = 1;
     }
 }
 
 void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
-                           uint64_t *slots, uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim, uint64_t hi,
-                           P1Status *st, hipStream_t s)
+                           uint64_t *slots, uint64_t slot_mask, uint32_t max_entries, uint64_t *uniq_pos, uint32_t *uniq_len, uint32_t id_cap,
+                           uint32_t trim, uint64_t hi, P1Status *st, hipStream_t s)
 {
     if (!count) return;
-    hipLaunchKernelGGL(k_import_strings, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, in, n, extra, lens, offs, count, slots,
-                       slot_len, slot_mask, max_entries, trim, hi, st);
+    DictTable d;
+    d.slots = slots; d.slot_mask = slot_mask; d.uniq_pos = uniq_pos; d.uniq_len = uniq_len; d.id_cap = id_cap; d.st = st;
+    hipLaunchKernelGGL(k_import_strings, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, in, n, extra, lens, offs, count, d, max_entries,
+                       trim, hi);
 }
 
 }  // namespace zdw

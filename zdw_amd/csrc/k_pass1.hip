@@ -262,11 +262,13 @@ struct WaveState {
     uint32_t ring_lo;            // smallest relative position the byte ring still holds
     bool first_pending;          // the head descriptor is the visit's sentinel: the line end before the first owned row
     uint64_t vbase;              // visit base: absolute position = vbase + relative position (multiple of BYTE_RING)
+    IdAlloc ids;                 // this wave's chunk of unique ids
 };
 
 // Handles `cnt` (1..64) descriptors from the ring head, one per lane.  Returns how many new dictionary
 // entries were created.
-__device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const P1Lds &L, WaveState &ws, uint32_t cnt, uint32_t lane)
+__device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const DictTable &d, const P1Lds &L, WaveState &ws, uint32_t cnt,
+                                            uint32_t lane)
 {
     const bool live = lane < cnt;
     const uint32_t di = ws.q_head + lane;
@@ -313,37 +315,51 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // ---- text-like columns, <= 24 bytes: decided by one table slot ----
     bool ft = fast && kind == K_TEXT;
     if (ft && len > 24u) { slow = true; ft = false; }
-    if (__ballot(ft)) {
+    const uint64_t ftm = __ballot(ft);
+    if (ftm) {
         if (ft) {
             uint32_t id = 0;
+            bool pending = false;
+            uint64_t c0 = 0, c1 = 0, c2 = 0, acc = 0, i = 0;
             if (len) {                                                            // empty fields are skipped (:340-341)
                 if (!zdw_lds[t.seen + col]) zdw_lds[t.seen + col] = 1;
                 const uint32_t lo = L.lut + 32u * len;
-                const uint64_t c0 = lds_u64(ra) & lds_u64(lo), c1 = lds_u64(ra + 8) & lds_u64(lo + 8), c2 = lds_u64(ra + 16) & lds_u64(lo + 16);
-                if (!(a.debug_skip & 2u)) {
-                    const uint64_t acc = nh24(c0, c1, c2);
-                    uint64_t i = hash_place(acc) & a.slot_mask;
-                    bool pending = true;
-                    for (uint32_t probe = 0; probe < 4 && pending; ++probe) {
-                        uint64_t *slot = a.slots + 4 * i;
-                        const SlotWords w = load_slot(slot);
-                        if (w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len) {
-                            id = (uint32_t)i + 1; pending = false;
-                        } else if (w.key == 0) {
-                            const uint64_t old = claim_slot(slot, a.slot_len, i, make_slot_key(hash_tag(acc), len, ws.vbase + fs), len, c0, c1, c2);
-                            if (old == 0) { is_new = true; id = (uint32_t)i + 1; } else slow = true;      // lost the race: general form
-                            pending = false;
-                        } else if (w.s0 == 0) {
-                            slow = true; pending = false;                         // claimed, inline copy not complete yet
-                        } else {
-                            i = (i + 1) & a.slot_mask;
-                        }
+                c0 = lds_u64(ra) & lds_u64(lo); c1 = lds_u64(ra + 8) & lds_u64(lo + 8); c2 = lds_u64(ra + 16) & lds_u64(lo + 16);
+                acc = nh24(c0, c1, c2);
+                i = hash_place(acc) & a.slot_mask;
+                pending = !(a.debug_skip & 2u);
+            }
+            // uniform over the text lanes (runs while any of them is undecided): ids are handed out at loop level
+            for (uint32_t probe = 0; probe < 4; ++probe) {
+                if (!__ballot(pending)) break;
+                uint64_t *slot = a.slots + 4 * i;
+                SlotWords w;
+                w.key = 1; w.s0 = w.s1 = w.s2 = 0;
+                if (pending) w = load_slot(slot);
+                const bool same = pending && w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len;
+                const uint32_t nid = (a.debug_skip & 16u) ? ((uint32_t)i & 0xfffffu) : alloc_ids(ws.ids, pending && !same && w.key == 0, a.st, ID_CHUNK);
+                if (!pending) continue;
+                if (same) {
+                    id = (uint32_t)w.key; pending = false;
+                } else if (w.key == 0) {
+                    if (nid >= a.id_cap) { a.st->overflow = 1; }
+                    else {
+                        const uint64_t old = (a.debug_skip & 8u)
+                            ? claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), 0u, ws.vbase + fs, len, a.uniq_pos, a.uniq_len, c0, c1, c2)
+                            : claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, ws.vbase + fs, len, a.uniq_pos, a.uniq_len, c0, c1, c2);
+                        if (old == 0) { is_new = true; id = nid + 1; } else slow = true;          // lost the race: general form
                     }
-                    if (pending) slow = true;
+                    pending = false;
+                } else if (w.s0 == 0) {
+                    slow = true; pending = false;                                 // claimed, inline copy not complete yet
+                } else {
+                    i = (i + 1) & a.slot_mask;
                 }
             }
+            if (pending) slow = true;
             if (!slow && in_block) *reinterpret_cast<uint32_t *>(recp) = id;
         }
+        adopt_ids(ws.ids, ftm);
     }
 
     // ---- integers of <= 16 plain digits, char(1) ----
@@ -383,8 +399,11 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     }
 
     // ---- everything else: the general form, from global memory ----
-    if (__ballot(slow)) {
-        if (slow) process_field_general(a, t, ws.vbase + fs, len, col, row, in_block, is_new);
+    const uint64_t sm = __ballot(slow);
+    if (sm) {
+        if ((a.debug_skip & 4u) && lane == 0) atomicAdd(&a.st->pad, popc64(sm));      // profiling only: general-form fields
+        if (slow) process_field_general(a, t, d, ws.ids, ws.vbase + fs, len, col, row, in_block, is_new);
+        adopt_ids(ws.ids, sm);
     }
     return popc64(__ballot(is_new));
 }
@@ -420,13 +439,16 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a)
     ws.desc = L.desc + wv * QCAP * 4u;
     ws.bytes = L.bytes + wv * (BYTE_RING + RING_TAIL);
     ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.first_pending = false; ws.vbase = 0;
+    ws.ids.cur = ws.ids.end = 0;
+    DictTable d;
+    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st;
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
     for (uint32_t si = wave_id; si < a.nspans; si += wave_count) {
         const uint32_t rowbase = a.span_rowbase[si];
         if (a.span_rowbase[si + 1] == rowbase) continue;          // no row starts in this span
         if (rowbase > a.row_limit) break;                         // later spans hold rows of later blocks only
-        if (__hip_atomic_load(&a.st->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (*reinterpret_cast<volatile const uint32_t *>(&a.st->overflow)) break;      // an ordinary (cached) read: a stale 0 only delays the exit
         if (new_entries >= 128) {        // publish this wave's inserts in bulk; stop everybody once the table is half full
             uint32_t seen_total = 0;
             if (lane == 0) seen_total = atomicAdd(&a.st->entries, new_entries) + new_entries;
@@ -556,7 +578,7 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a)
                 __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
                 while (drain ? ws.q_count > 0 : ws.q_count >= 64) {
                     const uint32_t cnt = ws.q_count < 64 ? ws.q_count : 64u;
-                    new_entries += consume(a, t, L, ws, cnt, lane);
+                    new_entries += consume(a, t, d, L, ws, cnt, lane);
                     ws.q_head += cnt;
                     ws.q_count -= cnt;
                 }
@@ -593,6 +615,7 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a)
             ws.ring_lo = relb;              // the next round keeps this one next to it in the byte ring
         }
     }
+    retire_ids(ws.ids, a.uniq_len, a.id_cap);
     __syncthreads();
     if (new_entries && lane == 0) {
         const uint32_t total = atomicAdd(&a.st->entries, new_entries) + new_entries;

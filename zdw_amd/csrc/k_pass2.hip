@@ -7,11 +7,20 @@
 // differs from the previous row's, row bytes = ceil(used/8) flag bytes followed by the low
 // `size` bytes of every flagged value in column order.
 //
-// A row is handled by G = min(64, pow2 >= used columns) adjacent lanes (64/G rows per wave):
-// flag bits come from one wave ballot, the byte position of each value from a G-lane prefix sum.
 // Two launches: row lengths (then an exclusive scan gives each row's output offset), then emit.
+//
+// Wide schemas (more than 32 used columns, G = 64): one wave per row, lane = column.  All of a row's
+// loads (this row and the one above, up to 256 columns) are issued before anything is looked at; the
+// dictionary gathers of the row likewise.  The emit kernel assembles a chunk of rows in LDS and writes
+// it out with aligned 16-byte stores (the byte-granular scatter of the values stays inside the LDS).
+//
+// Narrow schemas: a row is handled by G = pow2 >= used columns adjacent lanes (64/G rows per wave):
+// flag bits come from one wave ballot, the byte position of each value from a G-lane prefix sum.
 #include "zdw_dev.h"
 #include "zdw_kernels.h"
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace zdw {
 
@@ -19,7 +28,7 @@ struct __attribute__((packed)) PackedW64 { uint64_t v; };
 struct __attribute__((packed)) PackedW32 { uint32_t v; };
 struct __attribute__((packed)) PackedW16 { uint16_t v; };
 
-// what pass 1 left for (row, used column u): table slot id + 1 (text) or the parsed value (numeric)
+// what pass 1 left for (row, used column u): unique id + 1 (text) or the parsed value (numeric)
 __device__ __forceinline__ uint64_t raw_value(const Pass2Args &a, uint32_t row, uint32_t off, bool text)
 {
     const uint8_t *p = a.rec + (uint64_t)row * a.rec_stride + off;
@@ -32,7 +41,7 @@ __device__ __forceinline__ uint64_t raw_value(const Pass2Args &a, uint32_t row, 
 __device__ __forceinline__ uint64_t stored_from_raw(const Pass2Args &a, uint64_t raw, uint32_t u, bool text)
 {
     if (!raw) return 0ull;
-    return text ? (uint64_t)a.slot_off[(uint32_t)raw - 1] : raw - a.used_base[u];
+    return text ? (uint64_t)a.id_off[(uint32_t)raw - 1] : raw - a.used_base[u];
 }
 __device__ __forceinline__ uint64_t stored_value(const Pass2Args &a, uint32_t row, uint32_t u)
 {
@@ -102,12 +111,194 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
     if (!EMIT && row_ok && sub == 0) a.row_len[row] = nflag + running;
 }
 
+// ------------------------------------------------------------------------------------------
+// wide schemas: a wave owns 64 columns of a chunk of rows
+// ------------------------------------------------------------------------------------------
+// Lane = column, so "the row above" is the value the lane loaded one step earlier: the record matrix is
+// read once, and all loads of a chunk (P2_R + 1 per lane) are in flight together.
+constexpr uint32_t P2_R = 16;                    // rows per chunk
+constexpr uint32_t P2_LDS_BUDGET = 40 * 1024;    // output image of one row chunk (emit)
+
+struct ColFacts { uint32_t off; uint32_t sz; bool text; bool ok; };
+
+__device__ __forceinline__ ColFacts col_facts(const Pass2Args &a, uint32_t u)
+{
+    ColFacts f;
+    f.ok = u < a.nused;
+    f.off = f.ok ? a.used_recoff[u] : 0u;
+    f.sz = f.ok ? a.used_size[u] : 0u;
+    f.text = f.ok && a.used_kind[u] == K_TEXT;
+    return f;
+}
+// one 8-byte load whatever the column kind (a text id is the low half; the matrix has slack behind its last row)
+__device__ __forceinline__ uint64_t raw_at(const uint8_t *rowp, const ColFacts &f)
+{
+    const uint64_t x = reinterpret_cast<const PackedW64 *>(rowp + f.off)->v;
+    return f.text ? (x & 0xffffffffull) : x;
+}
+// raw values of column f for rows row0 - 1 .. row0 + rows - 1 in v[0 .. rows]; v[0] = 0 for the block's first row
+__device__ __forceinline__ void load_column(const Pass2Args &a, const ColFacts &f, uint32_t row0, uint32_t rows, uint64_t (&v)[P2_R + 1])
+{
+    const uint8_t *rp = a.rec + (uint64_t)row0 * a.rec_stride;
+    v[0] = (f.ok && row0) ? raw_at(rp - a.rec_stride, f) : 0ull;
+#pragma unroll
+    for (uint32_t r = 0; r < P2_R; ++r) v[r + 1] = (f.ok && r < rows) ? raw_at(rp + (uint64_t)r * a.rec_stride, f) : 0ull;
+}
+
+// row lengths + for every (row, 64-column batch) the value bytes the batches before it take in that row
+__global__ __launch_bounds__(256) void k_pass2_size_cols(const Pass2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t p2s_lds[];
+    uint16_t *tot = reinterpret_cast<uint16_t *>(p2s_lds);          // [P2_R][nbatch]
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t nflag = (a.nused + 7) >> 3;
+    const uint32_t nbatch = (a.nused + 63) >> 6;
+    const uint32_t nchunks = (a.nrows + P2_R - 1) / P2_R;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t row0 = chunk * P2_R;
+        const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
+        for (uint32_t b = wv; b < nbatch; b += 4) {
+            const uint32_t u = 64 * b + lane;
+            const ColFacts f = col_facts(a, u);
+            uint64_t v[P2_R + 1];
+            load_column(a, f, row0, rows, v);
+#pragma unroll
+            for (uint32_t r = 0; r < P2_R; ++r) {
+                bool flag = v[r + 1] != v[r];
+                if (row0 + r == 0 && f.ok) flag = stored_from_raw(a, v[1], u, f.text) != a.prev0[u];     // the halo row arrives as stored values
+                const uint32_t t = lane_value(wave_incl_sum(flag ? f.sz : 0u), 63);
+                if (lane == 0) tot[r * nbatch + b] = (uint16_t)t;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < rows) {
+            const uint32_t r = threadIdx.x;
+            uint32_t run = 0;
+            for (uint32_t b = 0; b < nbatch; ++b) {
+                const uint32_t t = tot[r * nbatch + b];
+                a.batch_pre[(uint64_t)(row0 + r) * nbatch + b] = (uint16_t)run;
+                run += t;
+            }
+            a.row_len[row0 + r] = nflag + run;
+        }
+        __syncthreads();
+    }
+}
+
+struct __attribute__((packed)) PackedL64 { uint64_t v; };
+struct __attribute__((packed)) PackedL32 { uint32_t v; };
+struct __attribute__((packed)) PackedL16 { uint16_t v; };
+
+// emit: the workgroup assembles P2_R consecutive rows in LDS (at the byte offset that makes LDS and global
+// 16-byte phases agree) and copies the image out with aligned vector stores
+__global__ __launch_bounds__(256) void k_pass2_emit_cols(const Pass2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t p2_lds[];
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t nflag = (a.nused + 7) >> 3;
+    const uint32_t nbatch = (a.nused + 63) >> 6;
+    const uint32_t nchunks = (a.nrows + P2_R - 1) / P2_R;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t row0 = chunk * P2_R;
+        const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
+        const uint64_t base = a.row_off[row0];
+        const uint32_t nbytes = (uint32_t)(a.row_off[row0 + rows] - base);
+        const uint32_t shift = (uint32_t)base & 15u;
+        for (uint32_t b = wv; b < nbatch; b += 4) {
+            const uint32_t u = 64 * b + lane;
+            const ColFacts f = col_facts(a, u);
+            uint64_t v[P2_R + 1];
+            load_column(a, f, row0, rows, v);
+            // where each row's bytes of this batch begin in the image
+            uint32_t my_at = 0;
+            if (lane < rows) my_at = (uint32_t)(a.row_off[row0 + lane] - base) + shift;
+            uint32_t my_pre = 0;
+            if (lane < rows) my_pre = a.batch_pre[(uint64_t)(row0 + lane) * nbatch + b];
+            // flags first, then every dictionary gather of the chunk in flight together
+            uint32_t flags = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < P2_R; ++r) flags |= (v[r + 1] != v[r] ? 1u : 0u) << r;
+            if (row0 == 0 && f.ok) {     // the halo row arrives as stored values
+                const uint64_t s0 = stored_from_raw(a, v[1], u, f.text);
+                flags = (flags & ~1u) | (s0 != a.prev0[u] ? 1u : 0u);
+            }
+            if (!f.ok) flags = 0;
+            const uint64_t basev = f.ok && !f.text ? a.used_base[u] : 0ull;
+#pragma unroll
+            for (uint32_t r = 0; r < P2_R; ++r) {
+                uint64_t x = v[r + 1];
+                if ((flags >> r) & 1u) x = f.text ? (x ? (uint64_t)a.id_off[(uint32_t)x - 1] : 0ull) : (x ? x - basev : 0ull);
+                v[r + 1] = x;
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < P2_R; ++r) {
+                if (r >= rows) continue;
+                const bool flag = (flags >> r) & 1u;
+                const uint32_t mine = flag ? f.sz : 0u;
+                const uint32_t inc = wave_incl_sum(mine);
+                const uint64_t bal = __ballot(flag);
+                const uint32_t at = lane_value(my_at, r), pre = lane_value(my_pre, r);
+                if (lane < 8 && 64 * b + 8 * lane < a.nused) p2_lds[at + 8 * b + lane] = (uint8_t)(bal >> (8 * lane));
+                if (flag) {
+                    // little-endian truncating store in at most three pieces (4 + 2 + 1 bytes; LDS stores are unaligned-capable)
+                    uint8_t *q = p2_lds + at + nflag + pre + (inc - mine);
+                    const uint32_t sz = f.sz;
+                    uint64_t x = v[r + 1];
+                    if (sz == 8) { reinterpret_cast<PackedL64 *>(q)->v = x; }
+                    else {
+                        if (sz & 4u) { reinterpret_cast<PackedL32 *>(q)->v = (uint32_t)x; q += 4; x >>= 32; }
+                        if (sz & 2u) { reinterpret_cast<PackedL16 *>(q)->v = (uint16_t)x; q += 2; x >>= 16; }
+                        if (sz & 1u) *q = (uint8_t)x;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // image [shift, shift + nbytes) -> out[base, base + nbytes): whole 16-byte vectors where they are covered
+        uint8_t *gdst = a.out + (base - shift);              // 16-byte aligned
+        const uint32_t endb = shift + nbytes;
+        for (uint32_t o = threadIdx.x * 16u; o < endb; o += 256u * 16u) {
+            if (o >= shift && o + 16u <= endb) {
+                *reinterpret_cast<uint4 *>(gdst + o) = *reinterpret_cast<const uint4 *>(p2_lds + o);
+            } else {
+                const uint32_t lo = o > shift ? o : shift, hi = o + 16u < endb ? o + 16u : endb;
+                for (uint32_t k = lo; k < hi; ++k) gdst[k] = p2_lds[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <bool EMIT>
 static void launch_pass2(const Pass2Args &a, hipStream_t s)
 {
     if (!a.nrows) return;
     uint32_t g = 1;
     while (g < 64 && g < a.nused) g <<= 1;
+    if (g == 64 && P2_R * a.out_row_max + 32u <= P2_LDS_BUDGET && a.batch_pre) {
+        // wide schema: persistent grids sized to what is resident
+        int dev = 0, cus = 256, occ = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const uint64_t want = ((uint64_t)a.nrows + P2_R - 1) / P2_R;
+        const uint32_t nbatch = (a.nused + 63) / 64;
+        if (!EMIT) {
+            const uint32_t lds = P2_R * nbatch * 2u + 16u;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pass2_size_cols, 256, lds) != hipSuccess || occ < 1) occ = 1;
+            uint32_t per_cu = std::min(6u, (uint32_t)occ);      // six workgroups per CU measured best (8: 1.36x the time)
+            if (const char *e = getenv("ZDW_P2_SIZE_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));   // tuning experiments
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
+            hipLaunchKernelGGL(k_pass2_size_cols, dim3(grid), dim3(256), lds, s, a);
+        } else {
+            const uint32_t lds = P2_R * a.out_row_max + 32u;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pass2_emit_cols, 256, lds) != hipSuccess || occ < 1) occ = 1;
+            uint32_t per_cu = std::min(6u, (uint32_t)occ);
+            if (const char *e = getenv("ZDW_P2_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));   // tuning experiments
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
+            hipLaunchKernelGGL(k_pass2_emit_cols, dim3(grid), dim3(256), lds, s, a);
+        }
+        return;
+    }
     const uint64_t rows_per_block = (256 / 64) * (64 / g);
     const uint32_t grid = (uint32_t)((a.nrows + rows_per_block - 1) / rows_per_block);
     switch (g) {

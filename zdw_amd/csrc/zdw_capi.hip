@@ -87,13 +87,14 @@ struct zdw_ctx {
     bool p1_done = false, dict_done = false, stats_done = false, p2_done = false, is_last = true;
     uint32_t nrows = 0;
     uint64_t nslots = 0;
-    DevBuf span_starts, span_rowbase, scan_tmp, rec, slots, slot_len, col_min, col_max, col_seen, status, long_rows, d_scalar;
+    DevBuf span_starts, span_rowbase, scan_tmp, rec, slots, col_min, col_max, col_seen, status, long_rows, d_scalar;
     std::vector<uint64_t> h_min, h_max;
     std::vector<uint8_t> h_seen;
     // dictionary
-    DevBuf uniq_pos, uniq_len, uniq_slot, key_a, key_b, val_a, val_b, order, group, active_a, active_b, flags, hist, lenp1, off_excl,
+    DevBuf uniq_pos, uniq_len, key_a, key_b, val_a, val_b, order, group, active_a, active_b, flags, hist, lenp1, off_excl,
         slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
     uint64_t nuniq = 0, dict_size = 0, extra_bytes = 0;
+    uint32_t id_cap = 0;                   // capacity of uniq_pos / uniq_len (unique ids, holes included)
     uint8_t index_size = 0;
     uint64_t dict_sec_off = 0, dict_sec_len = 0;
     uint32_t sort_rounds = 0;
@@ -102,7 +103,7 @@ struct zdw_ctx {
     std::vector<uint64_t> col_base;
     std::vector<uint32_t> used;
     // pass 2
-    DevBuf d_used_recoff, d_used_kind, d_used_size, d_used_base, d_prev0, d_last, row_len, row_off, rows_out;
+    DevBuf d_used_recoff, d_used_kind, d_used_size, d_used_base, d_prev0, d_last, row_len, row_off, rows_out, batch_pre;
     std::vector<uint64_t> prev_row;        // per column, for a shard that does not start the block
     bool have_prev = false;
     uint64_t rows_len = 0;
@@ -232,29 +233,17 @@ int ensure_dict(zdw_ctx *c)
     if (c->dict_done) return ZDW_OK;
     if (!c->p1_done) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_block_pass1 has not run for this block");
     hipStream_t s = c->stream;
-    uint32_t count = 0, max_len = 0;
+    // pass 1 (and the shard import) left the uniques by id: uniq_pos / uniq_len, length 0 = hole
+    uint32_t count = 0, max_len = 24;
     {
-        StageScope ts(c, ZDW_STAGE_DICT_COMPACT);
-        const uint64_t cap = c->nslots;   // upper bound on uniques; the table holds at most max_entries
-        const P1Status *st = c->status.as<P1Status>();
-        uint32_t entries = 0;
-        HIP_TRY(c, hipMemcpyAsync(&entries, &st->entries, 4, hipMemcpyDeviceToHost, s));
+        P1Status st{};
+        HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        (void)cap;
-        const uint64_t u = entries;
-        HIP_TRY(c, c->uniq_pos.ensure((u + 1) * 8));
-        HIP_TRY(c, c->uniq_len.ensure((u + 1) * 4));
-        HIP_TRY(c, c->uniq_slot.ensure((u + 1) * 4));
-        HIP_TRY(c, hipMemsetAsync(c->d_scalar.p, 0, 64, s));
-        launch_dict_compact(c->slots.as<uint64_t>(), c->slot_len.as<uint32_t>(), c->nslots, c->uniq_pos.as<uint64_t>(),
-                            c->uniq_len.as<uint32_t>(), c->uniq_slot.as<uint32_t>(), c->d_scalar.as<uint32_t>(), s);
-        uint32_t cm[2] = {0, 0};
-        HIP_TRY(c, hipMemcpyAsync(cm, c->d_scalar.p, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        count = cm[0]; max_len = cm[1];
-        if (count != entries) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary table count mismatch (%u vs %u)", count, entries);
+        count = st.id_next;
+        if (st.max_len > max_len) max_len = st.max_len;
+        if (count > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", count, c->id_cap);
+        c->nuniq = st.entries;
     }
-    c->nuniq = count;
     const uint64_t u = count;
     {
         StageScope ts(c, ZDW_STAGE_DICT_SORT);
@@ -295,11 +284,11 @@ int ensure_dict(zdw_ctx *c)
         }
         c->index_size = (uint8_t)bytes_for(c->dict_size);
         HIP_TRY(c, c->dict_sec.ensure(16 + c->dict_size));
-        HIP_TRY(c, c->slot_off.ensure(c->nslots * 4));
+        HIP_TRY(c, c->slot_off.ensure((u + 1) * 4));
         uint8_t *blob = c->dict_sec.as<uint8_t>() + 8;
         launch_dict_emit(c->d_in, c->extra.as<uint8_t>(), c->order.as<uint32_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(),
-                         c->uniq_slot.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, blob, c->slot_off.as<uint32_t>(), s);
-        if (u == 0) {                                   // empty set: a single 00 (dictionary.cpp:80-84)
+                         c->off_excl.as<uint64_t>(), u, blob, c->slot_off.as<uint32_t>(), s);
+        if (c->nuniq == 0) {                                   // empty set: a single 00 (dictionary.cpp:80-84)
             c->dict_sec_off = 8; c->dict_sec_len = 1;
         } else {
             uint8_t hdr[8];
@@ -355,7 +344,9 @@ int prepare_pass2(zdw_ctx *c, Pass2Args &a)
         const uint32_t k = c->used[u];
         uo[u] = c->recoff[k]; uk[u] = c->kind[k]; us[u] = c->col_size[k]; ub[u] = c->col_base[k];
         if (c->have_prev) up[u] = c->prev_row[k];
+        a.out_row_max += us[u];
     }
+    a.out_row_max += (nu + 7) / 8;
     HIP_TRY(c, c->d_used_recoff.ensure(nu * 4)); HIP_TRY(c, c->d_used_kind.ensure(nu)); HIP_TRY(c, c->d_used_size.ensure(nu));
     HIP_TRY(c, c->d_used_base.ensure(nu * 8)); HIP_TRY(c, c->d_prev0.ensure(nu * 8)); HIP_TRY(c, c->d_last.ensure(nu * 8));
     HIP_TRY(c, hipMemcpyAsync(c->d_used_recoff.p, uo.data(), nu * 4, hipMemcpyHostToDevice, s));
@@ -367,7 +358,7 @@ int prepare_pass2(zdw_ctx *c, Pass2Args &a)
     a.rec = c->rec.as<uint8_t>();
     a.used_recoff = c->d_used_recoff.as<uint32_t>(); a.used_kind = c->d_used_kind.as<uint8_t>();
     a.used_size = c->d_used_size.as<uint8_t>(); a.used_base = c->d_used_base.as<uint64_t>();
-    a.slot_off = c->slot_off.as<uint32_t>(); a.prev0 = c->d_prev0.as<uint64_t>();
+    a.id_off = c->slot_off.as<uint32_t>(); a.prev0 = c->d_prev0.as<uint64_t>();
     a.last_stored = c->d_last.as<uint64_t>();
     return ZDW_OK;
 }
@@ -384,7 +375,9 @@ int run_pass2(zdw_ctx *c)
     HIP_TRY(c, c->row_len.ensure((c->nrows + 1ull) * 4));
     HIP_TRY(c, c->row_off.ensure((c->nrows + 2ull) * 8));
     HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(c->nrows + 1ull)));
+    HIP_TRY(c, c->batch_pre.ensure(((uint64_t)c->nrows + 1) * ((a.nused + 63) / 64) * 2));
     a.row_len = c->row_len.as<uint32_t>(); a.row_off = c->row_off.as<uint64_t>(); a.out = nullptr;
+    a.batch_pre = c->batch_pre.as<uint16_t>();
     {
         StageScope ts(c, ZDW_STAGE_PASS2_SIZE);
         launch_pass2_size(a, s);
@@ -470,11 +463,11 @@ void zdw_ctx_destroy(zdw_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_times(c);
     DevBuf *bufs[] = {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->scan_tmp, &c->rec,
-                      &c->slots, &c->slot_len, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
-                      &c->uniq_pos, &c->uniq_len, &c->uniq_slot, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
+                      &c->slots, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
+                      &c->uniq_pos, &c->uniq_len, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
                       &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
                       &c->extra_lens, &c->extra_offs, &c->exp_bytes, &c->d_used_recoff, &c->d_used_kind, &c->d_used_size,
-                      &c->d_used_base, &c->d_prev0, &c->d_last, &c->row_len, &c->row_off, &c->rows_out};
+                      &c->d_used_base, &c->d_prev0, &c->d_last, &c->row_len, &c->row_off, &c->rows_out, &c->batch_pre};
     for (DevBuf *b : bufs) b->release();
     c->h_dict.release(); c->h_rows.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -601,7 +594,11 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     for (int attempt = 0;; ++attempt) {
         if (nslots > (1ull << 31)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary needs more than 2^31 table slots; split the block");
         HIP_TRY(c, c->slots.ensure(nslots * 32));
-        HIP_TRY(c, c->slot_len.ensure(nslots * 4));
+        {   // unique ids: the table's load limit plus what waves can leave unused in their chunks (holes)
+            const uint64_t cap = std::min<uint64_t>(nslots / 8 * 5 + 64ull * 65536, 0xFFFFFFF0ull);
+            HIP_TRY(c, c->uniq_pos.ensure(cap * 8)); HIP_TRY(c, c->uniq_len.ensure(cap * 4));
+            c->id_cap = (uint32_t)cap;
+        }
         HIP_TRY(c, hipMemsetAsync(c->slots.p, 0, nslots * 32, s));
         HIP_TRY(c, hipMemsetAsync(c->col_min.p, 0xFF, c->ncols * 8 + 8, s));
         HIP_TRY(c, hipMemsetAsync(c->col_max.p, 0, c->ncols * 8 + 8, s));
@@ -620,7 +617,8 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             a.col_numidx = c->d_numidx.as<int32_t>(); a.nnum = c->nnum; a.use_lds_ranges = lds_ranges ? 1u : 0u;
             a.rec_stride = c->rec_stride; a.rec = c->rec.as<uint8_t>();
             a.row_limit = row_limit; a.partial_fields = partial; a.trim = c->trim ? 1u : 0u;
-            a.slots = c->slots.as<uint64_t>(); a.slot_len = c->slot_len.as<uint32_t>(); a.slot_mask = nslots - 1;
+            a.slots = c->slots.as<uint64_t>(); a.slot_mask = nslots - 1;
+            a.uniq_pos = c->uniq_pos.as<uint64_t>(); a.uniq_len = c->uniq_len.as<uint32_t>(); a.id_cap = c->id_cap;
             a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 8 * 5, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
             a.rebase_at = 1u << 30;
@@ -633,6 +631,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         HIP_TRY(c, hipStreamSynchronize(s));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));
+        if (getenv("ZDW_DEBUG_SKIP")) fprintf(stderr, "[zdw] pass 1: entries=%u ids=%u general-form fields=%u\n", st.entries, st.id_next, st.pad);
         if (st.nul_seen == 2) return fail(c, ZDW_UNKNOWN_ERROR, "a single field of 1 GiB or more is not supported");
         if (!st.overflow) break;
         nslots <<= 4;                       // table too small for this block's uniques: grow and redo the pass
@@ -797,15 +796,13 @@ int zdw_shard_export_uniques(zdw_ctx *c, const void **d_lens, const void **d_byt
     if (!c || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
     (void)hipSetDevice(c->device);
     hipStream_t s = c->stream;
-    uint32_t entries = 0;
-    HIP_TRY(c, hipMemcpy(&entries, &c->status.as<P1Status>()->entries, 4, hipMemcpyDeviceToHost));
-    const uint64_t u = entries;
-    HIP_TRY(c, c->uniq_pos.ensure((u + 1) * 8)); HIP_TRY(c, c->uniq_len.ensure((u + 1) * 4)); HIP_TRY(c, c->uniq_slot.ensure((u + 1) * 4));
+    // the uniques as pass 1 left them, by id; ids with length 0 are holes and travel as such (no bytes)
+    uint32_t ids = 0;
+    HIP_TRY(c, hipMemcpy(&ids, &c->status.as<P1Status>()->id_next, 4, hipMemcpyDeviceToHost));
+    if (ids > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", ids, c->id_cap);
+    const uint64_t u = ids;
     HIP_TRY(c, c->lenp1.ensure((u + 1) * 4)); HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
     HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(u + 1)));
-    HIP_TRY(c, hipMemsetAsync(c->d_scalar.p, 0, 64, s));
-    launch_dict_compact(c->slots.as<uint64_t>(), c->slot_len.as<uint32_t>(), c->nslots, c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(),
-                        c->uniq_slot.as<uint32_t>(), c->d_scalar.as<uint32_t>(), s);
     // identity order: lenp1[i] = len[i] + 1
     HIP_TRY(c, c->order.ensure((u + 1) * 4));
     {
@@ -863,9 +860,9 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
                         (unsigned long long)total, (unsigned long long)nbytes);
     }
     launch_import_strings(c->d_in, c->n, c->extra.as<uint8_t>(), c->extra_lens.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count,
-                          c->slots.as<uint64_t>(), c->slot_len.as<uint32_t>(), c->nslots - 1,
-                          (uint32_t)std::min<uint64_t>(c->nslots - c->nslots / 8, 0xFFFFFFF0ull), c->trim ? 1u : 0u, c->hi,
-                          c->status.as<P1Status>(), s);
+                          c->slots.as<uint64_t>(), c->nslots - 1,
+                          (uint32_t)std::min<uint64_t>(c->nslots - c->nslots / 8, 0xFFFFFFF0ull), c->uniq_pos.as<uint64_t>(),
+                          c->uniq_len.as<uint32_t>(), c->id_cap, c->trim ? 1u : 0u, c->hi, c->status.as<P1Status>(), s);
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));

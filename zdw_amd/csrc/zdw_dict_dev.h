@@ -4,11 +4,17 @@
 // of heap copies; strings stay where they are in the TSV image.
 //
 // A slot is 32 bytes, 32-byte aligned:
-//     word 0   key = tag(16) | min(len, 255)(8) | first-occurrence position + 1 (40); 0 = empty.
+//     word 0   key = tag(16) << 40 | min(len, 255)(8) << 32 | unique id + 1 (32); 0 = empty.
 //              Claimed with a 64-bit CAS.
 //     word 1-3 the string's first 24 bytes, zero padded, written by the claimer AFTER the CAS:
 //              words 3, 2 first, then (every earlier store drained) word 1.  Strings hold no NUL and
 //              are never empty, so word 1 != 0 means "words 1-3 are complete".
+// Unique ids are dense and handed out in order of first insertion (per-wave chunks of a global
+// counter): uniq_pos[id] / uniq_len[id] hold where the string first occurs and how long it is; the
+// claimer writes them before word 1, so a set word 1 also means "the unique's facts are there".  An id
+// whose claim lost its race, or that was left over in a wave's chunk, stays a hole (length 0).  Early ids are
+// the frequent strings, so pass 2's id -> dictionary offset gather hits a small, cache-resident
+// prefix of its table.
 // Strings of <= 24 bytes are decided from the slot alone (length byte + three words): one random
 // memory access per lookup.  Longer strings, or a slot whose inline copy is not complete yet, are
 // compared against the first occurrence in the image (or the imported-string buffer): always exact.
@@ -19,7 +25,7 @@
 
 namespace zdw {
 
-constexpr uint32_t KEY_LEN_SHIFT = 40, KEY_TAG_SHIFT = 48;
+constexpr uint32_t KEY_LEN_SHIFT = 32, KEY_TAG_SHIFT = 40;
 
 __device__ __forceinline__ const uint8_t *string_at(const uint8_t *in, const uint8_t *extra, uint64_t pos)
 {
@@ -60,9 +66,9 @@ __device__ __forceinline__ uint64_t nh24(uint64_t c0, uint64_t c1, uint64_t c2)
 }
 __device__ __forceinline__ uint32_t hash_place(uint64_t acc) { return (uint32_t)(acc >> 32) ^ __umulhi((uint32_t)acc, NH_FOLD); }
 __device__ __forceinline__ uint32_t hash_tag(uint64_t acc) { return ((uint32_t)acc >> 16) & 0xffffu; }
-__device__ __forceinline__ uint64_t make_slot_key(uint32_t tag16, uint32_t len, uint64_t pos)
+__device__ __forceinline__ uint64_t make_slot_key(uint32_t tag16, uint32_t len, uint32_t id)
 {
-    return ((uint64_t)tag16 << KEY_TAG_SHIFT) | ((uint64_t)(len < 255u ? len : 255u) << KEY_LEN_SHIFT) | (pos + 1);
+    return ((uint64_t)tag16 << KEY_TAG_SHIFT) | ((uint64_t)(len < 255u ? len : 255u) << KEY_LEN_SHIFT) | ((uint64_t)id + 1u);
 }
 // whole-string hash for any length (the first step equals what pass 1 computes from registers)
 __device__ inline uint64_t nh_string(const uint8_t *p, uint32_t len, const uint8_t *end, uint64_t c0, uint64_t c1, uint64_t c2)
@@ -93,18 +99,74 @@ __device__ __forceinline__ SlotWords load_slot(const uint64_t *slot)
     return w;
 }
 
-// claim an empty slot for (key, first 24 bytes); returns the previous key word (0 = claimed)
-__device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint32_t *slot_len, uint64_t index, uint64_t key, uint32_t len,
-                                               uint64_t c0, uint64_t c1, uint64_t c2)
+// ---- unique ids -------------------------------------------------------------------------------
+struct IdAlloc { uint32_t cur, end; };     // wave-uniform: ids [cur, end) belong to this wave
+constexpr uint32_t ID_CHUNK = 64;          // ids a pass-1 wave takes beyond what it needs right now
+
+// One id for every active lane with `need` (call it with all lanes of the surrounding control flow).  Ids
+// come from the wave's chunk; when that runs out the wave takes what is missing plus `extra` more from
+// the global counter with one atomic.
+__device__ __forceinline__ uint32_t alloc_ids(IdAlloc &al, bool need, P1Status *st, uint32_t extra)
 {
+    const uint64_t m = __ballot(need);
+    if (!m) return 0;
+    const uint32_t k = popc64(m), rank = mbcnt64(m), have = al.end - al.cur;
+    uint32_t id = al.cur + rank;
+    if (k <= have) {
+        al.cur += k;
+    } else {
+        const int first = lowest_bit(m);
+        const uint32_t grab = k - have + extra;
+        uint32_t fresh = 0;
+        if (lane_id() == (uint32_t)first) fresh = atomicAdd(&st->id_next, grab);
+        fresh = lane_value(fresh, first);
+        if (rank >= have) id = fresh + (rank - have);
+        al.cur = fresh + (k - have);
+        al.end = fresh + grab;
+    }
+    return id;
+}
+// After a divergent region in which some lanes (mask m, non-empty) took ids: every lane adopts the chunk
+// state of one that was inside.
+__device__ __forceinline__ void adopt_ids(IdAlloc &al, uint64_t m)
+{
+    const int src = lowest_bit(m);
+    al.cur = lane_value(al.cur, src);
+    al.end = lane_value(al.end, src);
+}
+// ids left in the wave's chunk stay holes
+__device__ __forceinline__ void retire_ids(const IdAlloc &al, uint32_t *uniq_len, uint32_t id_cap)
+{
+    for (uint32_t id = al.cur + lane_id(); id < al.end; id += 64)
+        if (id < id_cap) uniq_len[id] = 0;
+}
+
+// claim an empty slot for unique `id`: the unique's facts (in flight while the CAS travels: their lines
+// are cold), the CAS, the inline copy, then (all of those drained) word 1; returns the previous key word
+// (0 = claimed).  A lost race leaves the id a hole.
+template <bool FACTS_AT_AGENT_SCOPE>
+__device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uint32_t id, uint64_t pos, uint32_t len, uint64_t *uniq_pos,
+                                               uint32_t *uniq_len, uint64_t c0, uint64_t c1, uint64_t c2)
+{
+    // Only strings of more than 24 bytes are ever compared against their first occurrence while the pass
+    // runs; for the others the facts are read after the kernel, so ordinary (write-back) stores do.
+    if (FACTS_AT_AGENT_SCOPE) {
+        __hip_atomic_store(uniq_pos + id, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(uniq_len + id, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        uniq_pos[id] = pos;
+        uniq_len[id] = len;
+    }
     const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), 0ull, (unsigned long long)key);
     if (old == 0) {
-        slot_len[index] = len;
-        // publish the inline copy: words 3 and 2, drain, then word 1
         if (c2) __hip_atomic_store(slot + 3, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c1) __hip_atomic_store(slot + 2, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(slot + 1, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (FACTS_AT_AGENT_SCOPE) {
+        __hip_atomic_store(uniq_len + id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        uniq_len[id] = 0u;
     }
     return old;
 }
@@ -126,40 +188,54 @@ __device__ inline bool stored_ends_here(const uint8_t *in, uint64_t pos, uint32_
 }
 
 // Insert-or-find, general form: string of `len` >= 1 bytes at p (image or imported buffer; `end` = end of
-// that allocation, reads never reach it), position code `pos`.  Returns slot index + 1, or 0 when the
-// table is too full (caller retries with more slots).  The caller counts new entries (is_new) and adds
+// that allocation, reads never reach it), position code `pos`.  Returns unique id + 1, or 0 when the
+// table is too full (caller retries with more slots).  Wave-level: every lane of the surrounding control
+// flow calls it together (ids are handed out by ballot).  The caller counts new entries (is_new) and adds
 // them to st->entries in bulk: one returning atomic per insert on a single counter serialises the chip.
+struct DictTable {
+    uint64_t *slots; uint64_t slot_mask;
+    uint64_t *uniq_pos; uint32_t *uniq_len; uint32_t id_cap;
+    P1Status *st;
+};
+
 __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi,
-                                       uint64_t *slots, uint32_t *slot_len, uint64_t slot_mask, P1Status *st, uint64_t pos, uint32_t len,
-                                       bool trim, bool &is_new)
+                                       const DictTable &d, IdAlloc &al, uint32_t id_extra, uint64_t pos, uint32_t len, bool trim, bool &is_new)
 {
     const uint64_t c0 = str_word(p, len, 0, end), c1 = str_word(p, len, 8, end), c2 = str_word(p, len, 16, end);
     const uint64_t acc = nh_string(p, len, end, c0, c1, c2);
     const uint32_t tag = hash_tag(acc), len8 = len < 255u ? len : 255u;
-    const uint64_t mine = make_slot_key(tag, len, pos);
-    uint64_t i = hash_place(acc) & slot_mask;
-    const uint32_t max_probe = slot_mask + 1 < 8192 ? (uint32_t)(slot_mask + 1) : 8192u;
+    if (len > 24u && len > d.st->max_len) atomicMax(&d.st->max_len, len);
+    uint64_t i = hash_place(acc) & d.slot_mask;
+    const uint32_t max_probe = d.slot_mask + 1 < 8192 ? (uint32_t)(d.slot_mask + 1) : 8192u;
+    uint32_t result = 0;
+    bool searching = true;
+    // The loop is uniform over the calling lanes (it runs while any of them still searches) and ids are
+    // handed out at loop level, so the wave's id chunk stays consistent across those lanes.
     for (uint32_t probe = 0; probe < max_probe; ++probe) {
-        uint64_t *slot = slots + 4 * i;
-        SlotWords w = load_slot(slot);
+        if (!__ballot(searching)) break;
+        uint64_t *slot = d.slots + 4 * i;
+        SlotWords w;
+        w.key = 1; w.s0 = w.s1 = w.s2 = 0;
+        if (searching) w = load_slot(slot);
+        const uint32_t nid = alloc_ids(al, searching && w.key == 0, d.st, id_extra);
+        if (!searching) continue;
         if (w.key == 0) {
-            const uint64_t old = claim_slot(slot, slot_len, i, mine, len, c0, c1, c2);
-            if (old == 0) { is_new = true; return (uint32_t)i + 1; }
-            w.key = old; w.s0 = 0;                        // somebody else just claimed it: its inline copy is not trusted yet
+            if (nid >= d.id_cap) { d.st->overflow = 1; searching = false; continue; }
+            const uint64_t old = claim_slot<true>(slot, make_slot_key(tag, len, nid), nid, pos, len, d.uniq_pos, d.uniq_len, c0, c1, c2);
+            if (old == 0) { is_new = true; result = nid + 1; searching = false; continue; }
+            w.key = old; w.s0 = 0;                        // somebody else just claimed it
         }
-        if ((w.key >> KEY_TAG_SHIFT) == tag && ((w.key >> KEY_LEN_SHIFT) & 0xffu) == len8) {
-            const uint64_t sp = (w.key & POS_MASK) - 1;
-            if (sp == pos) return (uint32_t)i + 1;
-            uint32_t from = 0;                            // bytes [0, from) are already known to be equal
-            bool differ = false;
-            if (w.s0 != 0) {
-                differ = !(w.s0 == c0 && w.s1 == c1 && w.s2 == c2);
-                from = 24;
-            }
-            if (!differ) {
-                if (from >= len) return (uint32_t)i + 1;  // len <= 24 with equal length bytes: the slot decides
+        if (((uint32_t)(w.key >> KEY_TAG_SHIFT) & 0xffffu) == tag && ((uint32_t)(w.key >> KEY_LEN_SHIFT) & 0xffu) == len8) {
+            // a candidate whose claimer has not finished publishing: wait for word 1 (the claimer waits for
+            // nobody, and a claimer in this very wave has finished before its rivals get here)
+            for (uint32_t spin = 0; w.s0 == 0 && spin < (1u << 22); ++spin) w = load_slot(slot);
+            if (w.s0 == 0) { d.st->overflow = 1; searching = false; continue; }      // cannot happen; never hang on it
+            const uint32_t from = 24;                     // bytes [0, 24) are decided by the inline copy
+            if (w.s0 == c0 && w.s1 == c1 && w.s2 == c2) {
+                if (from >= len) { result = (uint32_t)w.key; searching = false; continue; }   // len <= 24, equal length bytes: the slot decides
                 // compare the rest against the stored occurrence; with a length byte < 255 both lengths are
                 // known to be equal, so only bytes are compared
+                const uint64_t sp = __hip_atomic_load(d.uniq_pos + ((uint32_t)w.key - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool is_extra = sp >= EXTRA_BASE;
                 if (is_extra || sp + len < hi) {
                     const uint8_t *q = string_at(in, extra, sp);
@@ -177,14 +253,14 @@ __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, con
                             eq = stored_ends_here(in, sp, len, hi, trim, (nbs & 1u) != 0);
                         }
                     }
-                    if (eq) return (uint32_t)i + 1;
+                    if (eq) { result = (uint32_t)w.key; searching = false; continue; }
                 }
             }
         }
-        i = (i + 1) & slot_mask;
+        i = (i + 1) & d.slot_mask;
     }
-    st->overflow = 1;
-    return 0;
+    if (searching) d.st->overflow = 1;
+    return result;
 }
 
 // big-endian 8-byte sort key of bytes [8*depth, 8*depth+8) of a string, zero padded.  Strings hold

@@ -91,8 +91,8 @@ __device__ __forceinline__ void mark_seen(const Pass1Args &a, const ColTables &t
 // ------------------------------------------------------------------------------------------
 // one field, general form (field bytes in global memory at a.in + fs)
 // ------------------------------------------------------------------------------------------
-__device__ inline void process_field_general(const Pass1Args &a, const ColTables &t, uint64_t fs, uint32_t len, uint32_t col, uint32_t row,
-                                                   bool in_block, bool &is_new)
+__device__ inline void process_field_general(const Pass1Args &a, const ColTables &t, const DictTable &d, IdAlloc &al, uint64_t fs, uint32_t len,
+                                             uint32_t col, uint32_t row, bool in_block, bool &is_new)
 {
     const uint8_t *p = a.in + fs;
     if (a.trim) while (len > 0 && p[len - 1] == ' ') --len;          // ConvertToZDW.cpp:295-313
@@ -101,13 +101,19 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
     const uint32_t kind = meta & 3u;
     uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + (meta >> 16);
     if (kind == K_TEXT) {
+        if (len) mark_seen(a, t, col);                                // empty fields are skipped (:340-341)
+    }
+    // the table insert is wave-level (ids are handed out by ballot): all calling lanes pass through it
+    const bool want = kind == K_TEXT && len && !(a.debug_skip & 2u);
+    if (__ballot(want)) {
         uint32_t id = 0;
-        if (len) {                                                    // empty fields are skipped (:340-341)
-            mark_seen(a, t, col);
-            if (!(a.debug_skip & 2u))
-                id = dict_insert(p, a.in + a.n, a.in, a.n, a.extra, a.hi, a.slots, a.slot_len, a.slot_mask, a.st, fs, len, a.trim != 0, is_new);
-        }
-        if (in_block) *reinterpret_cast<uint32_t *>(recp) = id;
+        const uint64_t wm = __ballot(want);
+        if (want) id = dict_insert(p, a.in + a.n, a.in, a.n, a.extra, a.hi, d, al, ID_CHUNK, fs, len, a.trim != 0, is_new);
+        adopt_ids(al, wm);
+        if (want && in_block) *reinterpret_cast<uint32_t *>(recp) = id;
+    }
+    if (kind == K_TEXT) {
+        if (!want && in_block) *reinterpret_cast<uint32_t *>(recp) = 0u;
         return;
     }
     uint64_t v_range = 0, v_rec = 0;

@@ -11,14 +11,22 @@ constexpr uint64_t POS_MASK = (1ull << POS_BITS) - 1ull;
 constexpr uint64_t EXTRA_BASE = 1ull << 39;
 constexpr uint32_t COL_SKIP = 0xFFFFFFu;
 
+// Written by the kernels, read by the host after each launch.  The two busy counters sit on memory lines of
+// their own: every wave polls `overflow`, and an atomic that shares a line with a polled word queues behind
+// the polls (measured: ~40 us per add instead of ~2).
 struct P1Status {
     uint32_t bad_row;       // smallest 0-based row with a wrong field count, 0xFFFFFFFF = none
-    uint32_t overflow;      // dictionary table too small: retry with more slots
-    uint32_t entries;       // unique strings inserted
+    uint32_t overflow;      // dictionary table (or the list of uniques) too small: retry with more slots
     uint32_t long_count;    // rows >= 16383 bytes recorded in long_rows
-    uint64_t split_pos;     // start of row `row_limit` (the first row of the next block)
     uint32_t nul_seen;      // 1: NUL byte in the input (unsupported); 2: a single field of 1 GiB or more
-    uint32_t pad;
+    uint64_t split_pos;     // start of row `row_limit` (the first row of the next block)
+    uint32_t max_len;       // longest string beyond 24 bytes (bounds the sort rounds)
+    uint32_t pad;           // profiling only
+    uint8_t gap0[256 - 32];
+    uint32_t entries;       // unique strings inserted
+    uint8_t gap1[256 - 4];
+    uint32_t id_next;       // unique ids handed out so far (ids of lost races and unused chunk tails stay holes: length 0)
+    uint8_t gap2[256 - 4];
 };
 
 struct LongRow { uint64_t start; uint64_t len; };   // len includes the terminating newline
@@ -38,7 +46,8 @@ struct Pass1Args {
     uint32_t rec_stride; uint8_t *rec;    // rec[row][...]: u64 per numeric column, u32 id per text column
     uint32_t row_limit, partial_fields;
     uint32_t trim;
-    uint64_t *slots; uint32_t *slot_len; uint64_t slot_mask; uint32_t max_entries;
+    uint64_t *slots; uint64_t slot_mask; uint32_t max_entries;
+    uint64_t *uniq_pos; uint32_t *uniq_len; uint32_t id_cap;   // per unique id: first occurrence and length (0 = hole)
     uint64_t *col_min; uint64_t *col_max; uint8_t *col_seen;
     P1Status *st;
     LongRow *long_rows; uint32_t long_cap;
@@ -49,13 +58,15 @@ struct Pass1Args {
 struct Pass2Args {
     const uint8_t *rec; uint32_t rec_stride; uint32_t nrows;
     uint32_t nused;
+    uint32_t out_row_max;          // most bytes one row can take: flag bytes + every used column's size
     const uint32_t *used_recoff;   // per used column: offset inside a rec row
     const uint8_t *used_kind;      // K_TEXT / K_INT / K_CHAR
     const uint8_t *used_size;      // bytes stored per value
     const uint64_t *used_base;     // column base (min - 1; 0 for text)
-    const uint32_t *slot_off;      // dictionary offset per table slot
+    const uint32_t *id_off;        // dictionary offset per unique id
     const uint64_t *prev0;         // stored values of the row before row 0 (per used column)
     uint32_t *row_len;             // out (size kernel)
+    uint16_t *batch_pre;           // wide schemas, size kernel -> emit kernel: per (row, 64-column batch) the value bytes of the batches before it
     const uint64_t *row_off;       // in (emit kernel): exclusive scan of row_len
     uint8_t *out;
     uint64_t *last_stored;         // k_last_row only: stored values of the last row (per used column)
@@ -74,8 +85,6 @@ void launch_scan_u32_to_u32(const uint32_t *in, uint32_t *out, uint64_t n, void 
 void launch_scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, uint64_t *total, hipStream_t s);
 
 // dictionary
-void launch_dict_compact(const uint64_t *slots, const uint32_t *slot_len, uint64_t nslots,
-                         uint64_t *uniq_pos, uint32_t *uniq_len, uint32_t *uniq_slot, uint32_t *count, hipStream_t s);
 struct SortBuffers {   // all sized for n elements unless noted
     uint64_t *key_a, *key_b;
     uint32_t *val_a, *val_b;
@@ -93,11 +102,11 @@ int dict_sort(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos,
               SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len);
 void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s);
 void launch_dict_emit(const uint8_t *in, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
-                      const uint32_t *uniq_len, const uint32_t *uniq_slot, const uint64_t *off_excl, uint64_t n,
-                      uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *slot_off, hipStream_t s);
+                      const uint32_t *uniq_len, const uint64_t *off_excl, uint64_t n,
+                      uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *id_off, hipStream_t s);
 void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
-                           uint64_t *slots, uint32_t *slot_len, uint64_t slot_mask, uint32_t max_entries, uint32_t trim,
-                           uint64_t hi, P1Status *st, hipStream_t s);
+                           uint64_t *slots, uint64_t slot_mask, uint32_t max_entries, uint64_t *uniq_pos, uint32_t *uniq_len,
+                           uint32_t id_cap, uint32_t trim, uint64_t hi, P1Status *st, hipStream_t s);
 void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                            const uint64_t *off_excl, uint64_t n, uint8_t *bytes, hipStream_t s);
 

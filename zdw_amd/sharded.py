@@ -92,6 +92,7 @@ def export_uniques_tensors(enc, device):
     """(lens int32[count], bytes uint8[nbytes]) as torch tensors owned by the caller (copies)."""
     d_lens, d_bytes, count, nbytes = enc.export_uniques()
     lens = _wrap(d_lens, count * 4, "<i4", device).clone()
+    lens = lens[lens != 0]                 # the library lists uniques by id; ids it never used have length 0 and no bytes
     byts = _wrap(d_bytes, nbytes, "|u1", device).clone()
     _torch_done()          # the library may reuse its buffers as soon as we return
     return lens, byts
