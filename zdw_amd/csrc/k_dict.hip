@@ -23,7 +23,15 @@ constexpr uint32_t SORT_CHUNK = 2048;
 
 uint32_t sort_blocks(uint64_t n) { return (uint32_t)((n + SORT_CHUNK - 1) / SORT_CHUNK); }
 
-__global__ __launch_bounds__(64) void k_radix_hist(const uint64_t *__restrict__ keys, uint32_t n, uint32_t shift,
+// The digit of element i comes from its key, or -- when `dsrc` is given -- from dsrc[vals[i]] (a second,
+// more significant sort key looked up through the value; the pairs themselves keep travelling).
+__device__ __forceinline__ uint32_t radix_digit(const uint64_t *keys, const uint32_t *vals, const uint32_t *dsrc, uint32_t i, uint32_t shift)
+{
+    return dsrc ? (dsrc[vals[i]] >> shift) & 255u : (uint32_t)(keys[i] >> shift) & 255u;
+}
+
+__global__ __launch_bounds__(64) void k_radix_hist(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                    const uint32_t *__restrict__ dsrc, uint32_t n, uint32_t shift,
                                                     uint32_t *__restrict__ hist, uint32_t nblocks)
 {
     __shared__ uint32_t h[256];
@@ -32,15 +40,15 @@ __global__ __launch_bounds__(64) void k_radix_hist(const uint64_t *__restrict__ 
     __syncthreads();
     const uint32_t beg = blockIdx.x * SORT_CHUNK;
     const uint32_t end = beg + SORT_CHUNK < n ? beg + SORT_CHUNK : n;
-    for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&h[radix_digit(keys, vals, dsrc, i, shift)], 1u);
     __syncthreads();
     for (uint32_t d = lane; d < 256; d += 64) hist[d * nblocks + blockIdx.x] = h[d];
 }
 
 __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                       uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                       uint32_t n, uint32_t shift, const uint32_t *__restrict__ offsets,
-                                                       uint32_t nblocks)
+                                                       const uint32_t *__restrict__ dsrc, uint64_t *__restrict__ keys_out,
+                                                       uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
+                                                       const uint32_t *__restrict__ offsets, uint32_t nblocks)
 {
     __shared__ uint32_t offs[256];
     const uint32_t lane = threadIdx.x;
@@ -53,7 +61,7 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict
         const bool valid = i < end;
         const uint64_t key = valid ? keys_in[i] : 0ull;
         const uint32_t val = valid ? vals_in[i] : 0u;
-        const uint32_t digit = (uint32_t)(key >> shift) & 255u;
+        const uint32_t digit = valid ? (dsrc ? (dsrc[val] >> shift) & 255u : (uint32_t)(key >> shift) & 255u) : 0u;
         uint64_t mm = __ballot(valid);                 // lanes holding the same digit as this lane
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
@@ -70,17 +78,17 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict
     }
 }
 
-// sorts by bits [bit_lo, bit_hi) of the key; result lands in (*keys, *vals) (pointers are swapped as needed)
-static void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **keys_alt, uint32_t **vals_alt, uint32_t n,
+// sorts by bits [bit_lo, bit_hi) of the key (or of dsrc[value]); result lands in (*keys, *vals) (pointers are swapped as needed)
+static void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **keys_alt, uint32_t **vals_alt, const uint32_t *dsrc, uint32_t n,
                              uint32_t bit_lo, uint32_t bit_hi, uint32_t *hist, void *scan_tmp, hipStream_t s)
 {
     const uint32_t nb = sort_blocks(n);
     for (uint32_t shift = bit_lo; shift < bit_hi; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(64), 0, s, *keys, n, shift, hist, nb);
+        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, n, shift, hist, nb);
         // exclusive scan in place is not used: scan into the second half of the histogram buffer
         uint32_t *offsets = hist + (size_t)256 * nb + 1;
         launch_scan_u32_to_u32(hist, offsets, (uint64_t)256 * nb, scan_tmp, nullptr, s);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(64), 0, s, *keys, *vals, *keys_alt, *vals_alt, n, shift, offsets, nb);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, *keys_alt, *vals_alt, n, shift, offsets, nb);
         uint64_t *tk = *keys; *keys = *keys_alt; *keys_alt = tk;
         uint32_t *tv = *vals; *vals = *vals_alt; *vals_alt = tv;
     }
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void k_sort_init(uint32_t *order, uint32_t *ac
 }
 
 // keys[j] = 8 bytes at depth d of the string now at position active[j]; vals[j] = j
-__global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
+__global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
                                                     const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
                                                     const uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     uint32_t m, uint32_t depth, uint64_t *__restrict__ keys,
@@ -107,15 +115,10 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ i
     const uint32_t u = order[active[j]];
     const uint32_t len = uniq_len[u];
     // a hole (length 0) sorts before every string (first byte >= 1) and apart from every other hole
-    keys[j] = len ? sort_key8(string_at(in, extra, uniq_pos[u]), len, depth) : (uint64_t)u;
+    const uint64_t pos = uniq_pos[u];
+    const uint8_t *p = string_at(in, extra, pos);
+    keys[j] = len ? sort_key8(p, len, depth, pos >= EXTRA_BASE ? p + len + 16 : in + in_bytes) : (uint64_t)u;      // imported strings carry slack
     vals[j] = j;
-}
-
-__global__ __launch_bounds__(256) void k_sort_group_keys(const uint32_t *__restrict__ group, const uint32_t *__restrict__ vals,
-                                                          uint32_t m, uint64_t *__restrict__ keys)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < m) keys[j] = group[vals[j]];
 }
 
 // tmp[j] = the unique that belongs at the j-th tied position after this round
@@ -129,34 +132,20 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint32_t *__restrict_
 // writes the round's result back and flags what is still tied:
 //   head[j]   = 1 when position j starts a run of two or more equal (group, key)
 //   still[j]  = 1 when position j is tied with a neighbour (needs another round)
-__global__ __launch_bounds__(256) void k_sort_ties(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
-                                                    const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
-                                                    uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
+// The radix sort's key array is aligned with the result (the tie-group passes move the pairs along), so no
+// string is read here.
+__global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     const uint32_t *__restrict__ group, const uint32_t *__restrict__ tmp,
-                                                    const uint64_t *__restrict__ sorted_keys, uint32_t m, uint32_t depth,
+                                                    const uint64_t *__restrict__ sorted_keys, uint32_t m,
                                                     uint32_t *__restrict__ head, uint32_t *__restrict__ still)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    const uint32_t u = tmp[j];
-    order[active[j]] = u;
-    bool tie_prev = false, tie_next = false;
-    if (sorted_keys) {
-        // the radix sort's key array is still aligned with the result (no tie-group pass ran): no string reads
-        const uint64_t k = sorted_keys[j];
-        tie_prev = j > 0 && group[j - 1] == group[j] && sorted_keys[j - 1] == k;
-        tie_next = j + 1 < m && group[j + 1] == group[j] && sorted_keys[j + 1] == k;
-    } else {
-        const uint64_t k = sort_key8(string_at(in, extra, uniq_pos[u]), uniq_len[u], depth);
-        if (j > 0 && group[j - 1] == group[j]) {
-            const uint32_t v = tmp[j - 1];
-            tie_prev = sort_key8(string_at(in, extra, uniq_pos[v]), uniq_len[v], depth) == k;
-        }
-        if (j + 1 < m && group[j + 1] == group[j]) {
-            const uint32_t v = tmp[j + 1];
-            tie_next = sort_key8(string_at(in, extra, uniq_pos[v]), uniq_len[v], depth) == k;
-        }
-    }
+    order[active[j]] = tmp[j];
+    const uint64_t k = sorted_keys[j];
+    const uint32_t g = group[j];
+    const bool tie_prev = j > 0 && group[j - 1] == g && sorted_keys[j - 1] == k;
+    const bool tie_next = j + 1 < m && group[j + 1] == g && sorted_keys[j + 1] == k;
     // run labels must stay dense (1..#runs) because the next round radix-sorts them on as few bits
     // as the number of still-tied strings needs: count a head only for runs that stay in the working set
     head[j] = (!tie_prev && tie_next) ? 1u : 0u;
@@ -176,7 +165,7 @@ __global__ __launch_bounds__(256) void k_sort_compact(const uint32_t *__restrict
 }
 
 // Sort n unique strings.  Buffers: see SortBuffers.  Returns 0 or a hipError_t.
-int dict_sort(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n64,
+int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n64,
               SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len)
 {
     const uint32_t n = (uint32_t)n64;
@@ -200,18 +189,16 @@ int dict_sort(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos,
         const uint32_t gb = (m + 255) / 256;
         uint64_t *keys = b.key_a, *keys_alt = b.key_b;
         uint32_t *vals = b.val_a, *vals_alt = b.val_b;
-        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, b.order, active, m, depth, keys, vals);
-        radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, m, 0, 64, b.hist, b.scan_tmp, s);
+        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, b.order, active, m, depth, keys, vals);
+        radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, 64, b.hist, b.scan_tmp, s);
         if (depth > 0) {
-            // stable second key: the tie group (labels are < m + 1)
-            hipLaunchKernelGGL(k_sort_group_keys, dim3(gb), dim3(256), 0, s, group, vals, m, keys);
+            // stable, more significant key: the tie group of the element's old position (labels are < m + 1)
             uint32_t bits = 1;
             while (bits < 32 && (1ull << bits) <= (uint64_t)m + 1) ++bits;
-            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
+            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
         }
         hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, b.order, active, vals, m, tmp);
-        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, b.order, active, group, tmp,
-                           depth == 0 ? (const uint64_t *)keys : (const uint64_t *)nullptr, m, depth, head, still);
+        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active, group, tmp, (const uint64_t *)keys, m, head, still);
         launch_scan_u32_to_u32(head, head_scan, m, b.scan_tmp, nullptr, s);
         launch_scan_u32_to_u32(still, still_scan, m, b.scan_tmp, nullptr, s);
         hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active, head, still, head_scan, still_scan, m, active_alt,
@@ -246,7 +233,7 @@ void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64
 
 // one string per thread: copy into the blob (offset 1 + exclusive sum of len+1), NUL terminate,
 // publish the offset for its unique id
-__global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
+__global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
                                                     const uint32_t *__restrict__ order, const uint64_t *__restrict__ uniq_pos,
                                                     const uint32_t *__restrict__ uniq_len, const uint64_t *__restrict__ off_excl, uint32_t n,
                                                     uint8_t *__restrict__ blob, uint32_t *__restrict__ id_off)
@@ -258,18 +245,25 @@ __global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ i
     const uint32_t len = uniq_len[u];
     if (!len) return;                                            // hole
     const uint64_t off = 1 + off_excl[r];
-    const uint8_t *p = string_at(in, extra, uniq_pos[u]);
+    const uint64_t pos = uniq_pos[u];
+    const uint8_t *p = string_at(in, extra, pos);
+    const uint8_t *end = pos >= EXTRA_BASE ? p + len + 16 : in + in_bytes;       // imported strings carry slack
     uint8_t *q = blob + off;
-    for (uint32_t i = 0; i < len; ++i) q[i] = p[i];
+    uint32_t i = 0;
+    for (; i + 8 <= len; i += 8) reinterpret_cast<PackedU64 *>(q + i)->v = load_upto8(p + i, 8, end);     // unaligned 8-byte moves
+    if (i < len) {
+        uint64_t w = load_upto8(p + i, len - i, end);
+        for (; i < len; ++i) { q[i] = (uint8_t)w; w >>= 8; }
+    }
     q[len] = 0;
     id_off[u] = (uint32_t)off;
 }
 
-void launch_dict_emit(const uint8_t *in, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos, const uint32_t *uniq_len,
-                      const uint64_t *off_excl, uint64_t n, uint8_t *blob, uint32_t *id_off, hipStream_t s)
+void launch_dict_emit(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
+                      const uint32_t *uniq_len, const uint64_t *off_excl, uint64_t n, uint8_t *blob, uint32_t *id_off, hipStream_t s)
 {
     const uint32_t grid = n ? (uint32_t)((n + 255) / 256) : 1u;
-    hipLaunchKernelGGL(k_dict_emit, dim3(grid), dim3(256), 0, s, in, extra, order, uniq_pos, uniq_len, off_excl, (uint32_t)n, blob, id_off);
+    hipLaunchKernelGGL(k_dict_emit, dim3(grid), dim3(256), 0, s, in, in_bytes, extra, order, uniq_pos, uniq_len, off_excl, (uint32_t)n, blob, id_off);
 }
 
 // ------------------------------------------------------------------------------------------

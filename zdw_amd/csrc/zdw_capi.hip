@@ -262,7 +262,7 @@ int ensure_dict(zdw_ctx *c)
         b.active_a = c->active_a.as<uint32_t>(); b.active_b = c->active_b.as<uint32_t>();
         b.flags = c->flags.as<uint32_t>(); b.hist = c->hist.as<uint32_t>();
         b.scan_tmp = c->scan_tmp.p; b.counter = c->d_scalar.as<uint32_t>();
-        const int e = dict_sort(c->d_in, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, b, s,
+        const int e = dict_sort(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, b, s,
                                 &c->sort_rounds, max_len);
         if (e) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary sort: %s", hipGetErrorString((hipError_t)e));
     }
@@ -286,7 +286,7 @@ int ensure_dict(zdw_ctx *c)
         HIP_TRY(c, c->dict_sec.ensure(16 + c->dict_size));
         HIP_TRY(c, c->slot_off.ensure((u + 1) * 4));
         uint8_t *blob = c->dict_sec.as<uint8_t>() + 8;
-        launch_dict_emit(c->d_in, c->extra.as<uint8_t>(), c->order.as<uint32_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(),
+        launch_dict_emit(c->d_in, c->n, c->extra.as<uint8_t>(), c->order.as<uint32_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(),
                          c->off_excl.as<uint64_t>(), u, blob, c->slot_off.as<uint32_t>(), s);
         if (c->nuniq == 0) {                                   // empty set: a single 00 (dictionary.cpp:80-84)
             c->dict_sec_off = 8; c->dict_sec_len = 1;

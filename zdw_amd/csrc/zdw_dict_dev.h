@@ -265,16 +265,14 @@ __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, con
 
 // big-endian 8-byte sort key of bytes [8*depth, 8*depth+8) of a string, zero padded.  Strings hold
 // no NUL byte, so zero padding orders a shorter prefix first, like strcmp (dictionary.h:30-35).
-__device__ inline uint64_t sort_key8(const uint8_t *p, uint32_t len, uint32_t depth)
+// `end` = end of the allocation the string lives in: one unaligned 8-byte load when that stays inside.
+__device__ inline uint64_t sort_key8(const uint8_t *p, uint32_t len, uint32_t depth, const uint8_t *end)
 {
-    uint64_t k = 0;
-    const uint64_t base = 8ull * depth;
-#pragma unroll
-    for (uint32_t b = 0; b < 8; ++b) {
-        const uint64_t i = base + b;
-        k = (k << 8) | (i < len ? p[i] : 0u);
-    }
-    return k;
+    const uint32_t base = 8u * depth;
+    if (base >= len) return 0ull;
+    const uint32_t want = len - base < 8u ? len - base : 8u;
+    const uint64_t w = load_upto8(p + base, want, end);          // first byte in the low bits
+    return __builtin_bswap64(w);
 }
 
 }  // namespace zdw

@@ -98,10 +98,10 @@ struct SortBuffers {   // all sized for n elements unless noted
 };
 uint32_t sort_blocks(uint64_t n);
 // sorts unique strings into strcmp order; returns through `order`.  Host-driven loop (synchronises on s).
-int dict_sort(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n,
+int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n,
               SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len);
 void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s);
-void launch_dict_emit(const uint8_t *in, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
+void launch_dict_emit(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
                       const uint32_t *uniq_len, const uint64_t *off_excl, uint64_t n,
                       uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *id_off, hipStream_t s);
 void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
