@@ -168,7 +168,7 @@ def main():
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         b_alg = 2 * nbytes + out_local
         traffic, traffic_note = pmc_traffic({"pass1": "zdw::k_pass1", "scan_rows": "zdw::k_count_row_starts",
-                                             "pass2_emit": "void zdw::k_pass2<64u, true>", "pass2_size": "void zdw::k_pass2<64u, false>"}.get(dom), nbytes)
+                                             "pass2_emit": "zdw::k_pass2_emit_cols", "pass2_size": "zdw::k_pass2_size_cols"}.get(dom), nbytes)
         res = {
             "metric": "TSV->ZDW encode throughput (input bytes / wall time, input resident in HBM, raw .zdw left in HBM)",
             "value": round(total_in / 1e6 / (dt / args.steps), 1), "unit": "MB/s",
