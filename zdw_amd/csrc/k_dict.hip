@@ -12,6 +12,8 @@
 #include "zdw_kernels.h"
 #include "zdw_dict_dev.h"
 
+#include <algorithm>
+
 namespace zdw {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void k_dict_lengths(const uint32_t *__restrict
                                                        uint32_t n, uint32_t *__restrict__ len_plus1)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) { const uint32_t len = uniq_len[order[r]]; len_plus1[r] = len ? len + 1 : 0u; }    // holes take no room
+    if (r < n) { const uint32_t len = uniq_len[order ? order[r] : r]; len_plus1[r] = len ? len + 1 : 0u; }    // holes take no room; no order = identity
 }
 
 void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s)
@@ -291,40 +293,53 @@ void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64
                        (uint32_t)n, bytes);
 }
 
+// Persistent waves: a wave keeps its chunk of unique ids across the groups of 64 strings it handles (one
+// returning atomic on the id counter per wave and group would bound the kernel: ~30 M/s on one word).
 __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *__restrict__ lens,
                                                          const uint64_t *__restrict__ offs, uint64_t count, DictTable d, uint32_t max_entries,
-                                                         uint32_t trim, uint64_t hi)
+                                                         uint32_t trim, uint64_t hi, uint32_t *__restrict__ ids_out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool is_new = false;
+    const uint32_t lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     IdAlloc al;
     al.cur = al.end = 0;
-    const bool mine = i < count && lens[i] != 0;                 // a length of 0 is the exporter's hole
-    const uint64_t mm = __ballot(mine);
-    if (mm) {
-        if (mine) {
-            const uint8_t *p = extra + offs[i];
-            dict_insert(p, p + lens[i] + 16, in, n, extra, hi, d, al, 0u, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
+    uint32_t created = 0;
+    for (uint64_t g = wave * 64; g < count; g += nwaves * 64) {
+        const uint64_t i = g + lane;
+        bool is_new = false;
+        uint32_t id1 = 0;
+        const bool mine = i < count && lens[i] != 0;                 // a length of 0 is the exporter's hole
+        const uint64_t mm = __ballot(mine);
+        if (mm) {
+            if (mine) {
+                const uint8_t *p = extra + offs[i];
+                id1 = dict_insert(p, p + lens[i] + 16, in, n, extra, hi, d, al, ID_CHUNK, EXTRA_BASE + offs[i], lens[i], trim != 0, is_new);
+            }
+            adopt_ids(al, mm);
         }
-        adopt_ids(al, mm);
-        retire_ids(al, d.uniq_len, d.id_cap);
+        if (ids_out && i < count) ids_out[i] = id1;                  // unique id + 1 of every imported string (0: hole)
+        created += popc64(__ballot(is_new));
     }
-    const uint64_t m = __ballot(is_new);
-    if (m && lane_id() == 0) {
-        const uint32_t total = atomicAdd(&d.st->entries, popc64(m)) + popc64(m);
+    retire_ids(al, d.uniq_len, d.id_cap);
+    if (created && lane == 0) {
+        const uint32_t total = atomicAdd(&d.st->entries, created) + created;
         if (total > max_entries) d.st->overflow = 1;
     }
 }
 
 void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
                            uint64_t *slots, uint64_t slot_mask, uint32_t max_entries, uint64_t *uniq_pos, uint32_t *uniq_len, uint32_t id_cap,
-                           uint32_t trim, uint64_t hi, P1Status *st, hipStream_t s)
+                           uint32_t trim, uint64_t hi, P1Status *st, uint32_t *ids_out, hipStream_t s)
 {
     if (!count) return;
     DictTable d;
     d.slots = slots; d.slot_mask = slot_mask; d.uniq_pos = uniq_pos; d.uniq_len = uniq_len; d.id_cap = id_cap; d.st = st;
-    hipLaunchKernelGGL(k_import_strings, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, in, n, extra, lens, offs, count, d, max_entries,
-                       trim, hi);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t want = (count + 255) / 256;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * 8);
+    hipLaunchKernelGGL(k_import_strings, dim3(grid), dim3(256), 0, s, in, n, extra, lens, offs, count, d, max_entries, trim, hi, ids_out);
 }
 
 }  // namespace zdw

@@ -803,15 +803,7 @@ int zdw_shard_export_uniques(zdw_ctx *c, const void **d_lens, const void **d_byt
     const uint64_t u = ids;
     HIP_TRY(c, c->lenp1.ensure((u + 1) * 4)); HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
     HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(u + 1)));
-    // identity order: lenp1[i] = len[i] + 1
-    HIP_TRY(c, c->order.ensure((u + 1) * 4));
-    {
-        std::vector<uint32_t> ident(u);
-        for (uint64_t i = 0; i < u; ++i) ident[i] = (uint32_t)i;
-        if (u) HIP_TRY(c, hipMemcpyAsync(c->order.p, ident.data(), u * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
-    launch_dict_lengths(c->order.as<uint32_t>(), c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
+    launch_dict_lengths(nullptr, c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);      // identity order
     launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
     uint64_t total = 0;
     HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
@@ -839,17 +831,10 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
     HIP_TRY(c, c->extra_lens.ensure((count + 1) * 4));
     HIP_TRY(c, c->extra_offs.ensure((count + 2) * 8));
     HIP_TRY(c, c->lenp1.ensure((count + 1) * 4));
-    HIP_TRY(c, c->order.ensure((count + 1) * 4));
     HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(count + 1)));
     HIP_TRY(c, hipMemcpyAsync(c->extra.p, d_bytes, nbytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(c->extra_lens.p, d_lens, count * 4, hipMemcpyDeviceToDevice, s));
-    {
-        std::vector<uint32_t> ident(count);
-        for (uint64_t i = 0; i < count; ++i) ident[i] = (uint32_t)i;
-        HIP_TRY(c, hipMemcpyAsync(c->order.p, ident.data(), count * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
-    launch_dict_lengths(c->order.as<uint32_t>(), c->extra_lens.as<uint32_t>(), count, c->lenp1.as<uint32_t>(), s);
+    launch_dict_lengths(nullptr, c->extra_lens.as<uint32_t>(), count, c->lenp1.as<uint32_t>(), s);      // identity order
     launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count, c->scan_tmp.p, nullptr, s);
     {   // the lengths must describe exactly the bytes that came with them, or the insert kernel would walk off the buffer
         uint64_t total = 0;
@@ -862,7 +847,7 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
     launch_import_strings(c->d_in, c->n, c->extra.as<uint8_t>(), c->extra_lens.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count,
                           c->slots.as<uint64_t>(), c->nslots - 1,
                           (uint32_t)std::min<uint64_t>(c->nslots - c->nslots / 8, 0xFFFFFFF0ull), c->uniq_pos.as<uint64_t>(),
-                          c->uniq_len.as<uint32_t>(), c->id_cap, c->trim ? 1u : 0u, c->hi, c->status.as<P1Status>(), s);
+                          c->uniq_len.as<uint32_t>(), c->id_cap, c->trim ? 1u : 0u, c->hi, c->status.as<P1Status>(), nullptr, s);
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));

@@ -106,7 +106,7 @@ void launch_dict_emit(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra
                       uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *id_off, hipStream_t s);
 void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
                            uint64_t *slots, uint64_t slot_mask, uint32_t max_entries, uint64_t *uniq_pos, uint32_t *uniq_len,
-                           uint32_t id_cap, uint32_t trim, uint64_t hi, P1Status *st, hipStream_t s);
+                           uint32_t id_cap, uint32_t trim, uint64_t hi, P1Status *st, uint32_t *ids_out /* optional */, hipStream_t s);
 void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                            const uint64_t *off_excl, uint64_t n, uint8_t *bytes, hipStream_t s);
 
