@@ -58,6 +58,9 @@ __device__ __forceinline__ uint32_t eq16(const uint4 &v, uint32_t pat)
     return eq4(v.x, pat) | (eq4(v.y, pat) << 4) | (eq4(v.z, pat) << 8) | (eq4(v.w, pat) << 12);
 }
 
+// bit 7 of each byte: set iff the byte of x is non-zero (exact, no carries between bytes)
+__device__ __forceinline__ uint32_t nz7b(uint32_t x) { return ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x; }
+
 // this lane's 16 bytes of the round at `pos`, branch-free: lanes whose chunk would start at or past
 // the end of the allocation re-read the last 16-byte chunk that starts inside it (an aligned chunk
 // whose first byte is inside an allocation never leaves its page); callers mask by position.
@@ -177,6 +180,27 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
                 const uint4 v = nxt;
                 nxt = load_round16(in, pos + WROUND, lane, n);            // next round in flight while this one is counted
                 const uint64_t lp = pos + 16ull * lane;
+                {
+                    // common case -- the round lies inside the span and holds no backslash: count in place on the
+                    // bit-7 flags of the SWAR compares (no compaction to 16-bit sets)
+                    const uint32_t H = 0x80808080u, L1 = 0x01010101u;
+                    const uint32_t b0 = v.x ^ 0x5c5c5c5cu, b1 = v.y ^ 0x5c5c5c5cu, b2 = v.z ^ 0x5c5c5c5cu, b3 = v.w ^ 0x5c5c5c5cu;
+                    const uint32_t anybs = (((b0 - L1) & ~b0) | ((b1 - L1) & ~b1) | ((b2 - L1) & ~b2) | ((b3 - L1) & ~b3)) & H;     // exact for "some byte is a backslash"
+                    if (!(__ballot(anybs != 0) | bs_carry) && pos >= ss && pos + WROUND <= se) {
+                        const uint32_t n0 = ~nz7b(v.x ^ 0x0a0a0a0au) & H, n1 = ~nz7b(v.y ^ 0x0a0a0a0au) & H, n2 = ~nz7b(v.z ^ 0x0a0a0a0au) & H,
+                                       n3 = ~nz7b(v.w ^ 0x0a0a0a0au) & H;                       // bit 7 of a byte: it is a newline
+                        uint32_t before = wave_shr1(n3);                                          // the byte before my first one
+                        if (lane == 0) before = prev_term ? 0x80000000u : 0u;
+                        // "the previous byte is a newline" for each of my bytes, then: a row starts where that holds and the byte is none
+                        mine += (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n0, before, 24) & ~n0)
+                              + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n1, n0, 24) & ~n1)
+                              + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n2, n1, 24) & ~n2)
+                              + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n3, n2, 24) & ~n3);
+                        nul |= (((v.x - L1) & ~v.x) | ((v.y - L1) & ~v.y) | ((v.z - L1) & ~v.z) | ((v.w - L1) & ~v.w)) & H;        // exact for "some byte is NUL"
+                        prev_term = lane_value(n3 >> 31, 63);
+                        continue;
+                    }
+                }
                 Lane16 m;
                 classify16(in, lo, n, lp, v, lane, bs_carry, m, false);
                 uint32_t vm = 0xffffu;
