@@ -290,7 +290,9 @@ struct WaveState {
 };
 
 // Handles `cnt` (1..64) descriptors from the ring head, one per lane.  Returns how many new dictionary
-// entries were created.
+// entries were created.  DEFER: fields that need the general form are queued for k_pass1_deferred instead of
+// being handled here (the general form costs this kernel a fifth of its registers and a wave per SIMD).
+template <bool DEFER>
 __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const DictTable &d, const P1Lds &L, WaveState &ws, uint32_t cnt,
                                             uint32_t lane)
 {
@@ -425,13 +427,27 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // ---- everything else: the general form, from global memory ----
     const uint64_t sm = __ballot(slow);
     if (sm) {
-        if ((a.debug_skip & 4u) && lane == 0) atomicAdd(&a.st->pad, popc64(sm));      // profiling only: general-form fields
-        if (slow) process_field_general(a, t, d, ws.ids, ws.vbase + fs, len, col, row, in_block, is_new);
-        adopt_ids(ws.ids, sm);
+        if (DEFER) {
+            uint32_t qb = 0;
+            if (lane == (uint32_t)lowest_bit(sm)) qb = atomicAdd(&a.st->deferred, popc64(sm));
+            qb = lane_value(qb, lowest_bit(sm)) + mbcnt64(sm);
+            if (slow) {
+                if (qb < a.dq_cap) {
+                    a.dq[2ull * qb] = (ws.vbase + fs) | ((uint64_t)col << 40);
+                    a.dq[2ull * qb + 1] = (uint64_t)len | ((uint64_t)row << 32);
+                } else {
+                    a.st->deferred_lost = 1;
+                }
+            }
+        } else {
+            if (slow) process_field_general(a, t, d, ws.ids, ws.vbase + fs, len, col, row, in_block, is_new);
+            adopt_ids(ws.ids, sm);
+        }
     }
     return popc64(__ballot(is_new));
 }
 
+template <bool DEFER>
 __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a)
 {
     const uint32_t wv = threadIdx.x >> 6;
@@ -602,7 +618,7 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a)
                 __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
                 while (drain ? ws.q_count > 0 : ws.q_count >= 64) {
                     const uint32_t cnt = ws.q_count < 64 ? ws.q_count : 64u;
-                    new_entries += consume(a, t, d, L, ws, cnt, lane);
+                    new_entries += consume<DEFER>(a, t, d, L, ws, cnt, lane);
                     ws.q_head += cnt;
                     ws.q_count -= cnt;
                 }
@@ -662,16 +678,58 @@ __global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a)
     }
 }
 
+// The fields the fast kernel queued: one per lane through the general form, with the column tables and
+// ranges in global memory (the fast kernel has flushed its own by then).
+__global__ __launch_bounds__(256) void k_pass1_deferred(const Pass1Args a, uint32_t count)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    ColTables t;
+    t.meta = t.mn = t.mx = t.seen = 0; t.cols_in_lds = false;
+    DictTable d;
+    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st;
+    IdAlloc al;
+    al.cur = al.end = 0;
+    uint32_t created = 0;
+    for (uint32_t g = wave * 64; g < count; g += nwaves * 64) {
+        const uint32_t i = g + lane;
+        bool is_new = false;
+        const bool mine = i < count;
+        const uint64_t mm = __ballot(mine);
+        if (mine) {
+            const uint64_t w0 = a.dq[2ull * i], w1 = a.dq[2ull * i + 1];
+            const uint32_t row = (uint32_t)(w1 >> 32);
+            process_field_general(a, t, d, al, w0 & POS_MASK, (uint32_t)w1, (uint32_t)(w0 >> 40), row, row < a.row_limit, is_new);
+        }
+        adopt_ids(al, mm);
+        created += popc64(__ballot(is_new));
+    }
+    retire_ids(al, a.uniq_len, a.id_cap);
+    if (created && lane == 0) {
+        const uint32_t total = atomicAdd(&a.st->entries, created) + created;
+        if (total > a.max_entries) a.st->overflow = 1;
+    }
+}
+
+void launch_pass1_deferred(const Pass1Args &a, uint32_t count, hipStream_t s)
+{
+    if (!count) return;
+    const uint32_t want = (count + 255) / 256;
+    hipLaunchKernelGGL(k_pass1_deferred, dim3(want < 2048u ? want : 2048u), dim3(256), 0, s, a, count);
+}
+
 void launch_pass1(const Pass1Args &a, hipStream_t s)
 {
     if (!a.nspans) return;
     const size_t lds = pass1_lds_bytes(a.ncols, a.nnum, a.use_lds_ranges != 0);
+    const bool defer = a.dq != nullptr;
     // Waves walk the spans with a grid stride, so every wave carries the same share of the block: the grid
     // must not exceed what is resident at once, or the surplus waves run alone after the others finish.
     int per_cu = 0, dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pass1, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+    const void *fn = defer ? (const void *)k_pass1<true> : (const void *)k_pass1<false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
     const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules
     if ((size_t)per_cu > by_lds && by_lds >= 1) per_cu = (int)by_lds;
     if (per_cu > 16) per_cu = 16;                                               // workgroup slots per CU
@@ -679,7 +737,8 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / P1_WPB;   // tuning experiments
     const uint32_t want_blocks = (a.nspans + P1_WPB - 1) / P1_WPB;
     const uint32_t grid = want_blocks < max_blocks ? want_blocks : (max_blocks ? max_blocks : 1u);
-    hipLaunchKernelGGL(k_pass1, dim3(grid), dim3(64 * P1_WPB), lds, s, a);
+    if (defer) hipLaunchKernelGGL(k_pass1<true>, dim3(grid), dim3(64 * P1_WPB), lds, s, a);
+    else hipLaunchKernelGGL(k_pass1<false>, dim3(grid), dim3(64 * P1_WPB), lds, s, a);
 }
 
 }  // namespace zdw

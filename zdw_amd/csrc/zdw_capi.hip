@@ -87,7 +87,7 @@ struct zdw_ctx {
     bool p1_done = false, dict_done = false, stats_done = false, p2_done = false, is_last = true;
     uint32_t nrows = 0;
     uint64_t nslots = 0;
-    DevBuf span_starts, span_rowbase, scan_tmp, rec, slots, col_min, col_max, col_seen, status, long_rows, d_scalar;
+    DevBuf span_starts, span_rowbase, scan_tmp, rec, slots, deferred_q, col_min, col_max, col_seen, status, long_rows, d_scalar;
     std::vector<uint64_t> h_min, h_max;
     std::vector<uint8_t> h_seen;
     // dictionary
@@ -95,6 +95,7 @@ struct zdw_ctx {
         slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
     uint64_t nuniq = 0, dict_size = 0, extra_bytes = 0;
     uint32_t id_cap = 0;                   // capacity of uniq_pos / uniq_len (unique ids, holes included)
+    bool p1_all_in_one = false;            // an earlier block overflowed the deferred-field queue: use the all-in-one kernel
     uint8_t index_size = 0;
     uint64_t dict_sec_off = 0, dict_sec_len = 0;
     uint32_t sort_rounds = 0;
@@ -463,7 +464,7 @@ void zdw_ctx_destroy(zdw_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_times(c);
     DevBuf *bufs[] = {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->scan_tmp, &c->rec,
-                      &c->slots, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
+                      &c->slots, &c->deferred_q, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
                       &c->uniq_pos, &c->uniq_len, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
                       &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
                       &c->extra_lens, &c->extra_offs, &c->exp_bytes, &c->d_used_recoff, &c->d_used_kind, &c->d_used_size,
@@ -625,7 +626,26 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::max(16384u, (uint32_t)strtoul(e, nullptr, 10));   // tests
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
+            // Fields that need the general form (-t, long strings, signed / padded numbers, contended slots) are
+            // queued by the main kernel and handled by a second one; a block with more than about 1 % of them
+            // (or a schema whose tables do not fit LDS) runs the all-in-one kernel instead.
+            const bool defer = lds_ranges && !c->trim && !c->p1_all_in_one && !getenv("ZDW_P1_ALL_IN_ONE");
+            if (defer) {
+                const uint64_t cap = std::min<uint64_t>((hi - lo) / 1024 + 65536, 1ull << 26);
+                HIP_TRY(c, c->deferred_q.ensure(cap * 16));
+                a.dq = c->deferred_q.as<uint64_t>(); a.dq_cap = (uint32_t)cap;
+            }
             launch_pass1(a, s);
+            if (defer) {
+                HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipStreamSynchronize(s));
+                if (st.deferred_lost) {             // too many for the queue: this block (and the context's later ones) all in one
+                    c->p1_all_in_one = true;
+                    --attempt;
+                    continue;
+                }
+                if (st.deferred && !st.overflow) launch_pass1_deferred(a, st.deferred, s);
+            }
         }
         HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));

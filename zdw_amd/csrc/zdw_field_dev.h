@@ -96,10 +96,15 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
 {
     const uint8_t *p = a.in + fs;
     if (a.trim) while (len > 0 && p[len - 1] == ' ') --len;          // ConvertToZDW.cpp:295-313
-    const uint32_t meta = t.cols_in_lds ? *reinterpret_cast<const uint32_t *>(zdw_lds + t.meta + 4 * col)
-                                        : pack_col_meta(a.col_kind[col], (uint32_t)a.col_numidx[col] & 0x3fffu, a.col_recoff[col]);
-    const uint32_t kind = meta & 3u;
-    uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + (meta >> 16);
+    // column facts: packed in LDS (14-bit numeric index, 16-bit record offset) or, for schemas too wide for that, from global memory
+    uint32_t kind, numidx, recoff;
+    if (t.cols_in_lds) {
+        const uint32_t meta = *reinterpret_cast<const uint32_t *>(zdw_lds + t.meta + 4 * col);
+        kind = meta & 3u; numidx = (meta >> 2) & 0x3fffu; recoff = meta >> 16;
+    } else {
+        kind = a.col_kind[col]; numidx = (uint32_t)a.col_numidx[col]; recoff = a.col_recoff[col];
+    }
+    uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + recoff;
     if (kind == K_TEXT) {
         if (len) mark_seen(a, t, col);                                // empty fields are skipped (:340-341)
     }
@@ -127,7 +132,7 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
             v_range = (uint64_t)(b0 == '\\' ? c0 + hi8 : c0);
             v_rec = (uint64_t)(c0 + hi8);
         }
-        if (v_range > 0) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
+        if (v_range > 0) range_update(a, t, col, numidx, v_range);
     }
     if (in_block) *reinterpret_cast<uint64_t *>(recp) = v_rec;
 }

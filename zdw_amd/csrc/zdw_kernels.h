@@ -22,11 +22,15 @@ struct P1Status {
     uint64_t split_pos;     // start of row `row_limit` (the first row of the next block)
     uint32_t max_len;       // longest string beyond 24 bytes (bounds the sort rounds)
     uint32_t pad;           // profiling only
-    uint8_t gap0[256 - 32];
+    uint32_t deferred_lost; // the deferred-field queue was too small: redo the pass with the all-in-one kernel
+    uint32_t pad2;
+    uint8_t gap0[256 - 40];
     uint32_t entries;       // unique strings inserted
     uint8_t gap1[256 - 4];
     uint32_t id_next;       // unique ids handed out so far (ids of lost races and unused chunk tails stay holes: length 0)
     uint8_t gap2[256 - 4];
+    uint32_t deferred;      // fields queued for the general-form kernel
+    uint8_t gap3[256 - 4];
 };
 
 struct LongRow { uint64_t start; uint64_t len; };   // len includes the terminating newline
@@ -52,6 +56,7 @@ struct Pass1Args {
     P1Status *st;
     LongRow *long_rows; uint32_t long_cap;
     uint32_t rebase_at;                   // relative position at which a visit moves its base (2^30; tests lower it)
+    uint64_t *dq; uint32_t dq_cap;        // deferred fields (two words each: position | column << 40, length | row << 32); dq == nullptr: none, one kernel does everything
     uint32_t debug_skip;                  // profiling only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary
 };
 
@@ -77,6 +82,7 @@ void launch_find_effective_end(const uint8_t *in, uint64_t n, uint64_t lo, uint6
 void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t hi, uint64_t span0, uint32_t nspans,
                              uint32_t *span_starts, P1Status *st, hipStream_t s);
 void launch_pass1(const Pass1Args &a, hipStream_t s);
+void launch_pass1_deferred(const Pass1Args &a, uint32_t count, hipStream_t s);
 size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds);
 
 // exclusive scans; tmp must hold scan_tmp_bytes(n) bytes; total (optional) receives the sum
