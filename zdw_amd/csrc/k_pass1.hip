@@ -448,7 +448,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
 }
 
 template <bool DEFER>
-__global__ __launch_bounds__(64 * P1_WPB) void k_pass1(const Pass1Args a)
+__global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass1Args a)
 {
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t wave_id = blockIdx.x * P1_WPB + wv, wave_count = gridDim.x * P1_WPB;
