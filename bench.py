@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gb", type=float, default=10.0, help="input GB (1e9 bytes) per GPU")
     ap.add_argument("--cols", type=int, default=200)
-    ap.add_argument("--cpu-mb", type=float, default=200.0, help="size of the CPU-baseline sample")
+    ap.add_argument("--cpu-mb", type=float, default=600.0, help="size of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")

@@ -95,7 +95,7 @@ typedef struct zdw_stage_times {
 enum {
     ZDW_STAGE_SCAN_ROWS = 0,   /* row-start count per span + exclusive scan            */
     ZDW_STAGE_PASS1 = 1,       /* tokenise + hash/dedupe + integer parse + column ranges */
-    ZDW_STAGE_DICT_COMPACT = 2,
+    ZDW_STAGE_DICT_COMPACT = 2, /* unused since unique ids are dense (kept so that stage numbers stay put) */
     ZDW_STAGE_DICT_SORT = 3,
     ZDW_STAGE_DICT_EMIT = 4,   /* offsets + dictionary blob */
     ZDW_STAGE_PASS2_SIZE = 5,  /* per-row encoded length + exclusive scan */
