@@ -82,6 +82,14 @@ __device__ __forceinline__ uint32_t valid16(uint64_t lp, uint64_t vlo, uint64_t 
     return hi_i > lo_i ? (((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u)) : 0u;
 }
 
+// the same on 32-bit positions relative to a visit base
+__device__ __forceinline__ uint32_t valid16r(uint32_t lp, uint32_t vlo, uint32_t vhi)
+{
+    const uint32_t lo_i = vlo > lp ? (vlo - lp < 16u ? vlo - lp : 16u) : 0u;
+    const uint32_t hi_i = vhi > lp ? (vhi - lp < 16u ? vhi - lp : 16u) : 0u;
+    return hi_i > lo_i ? (((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u)) : 0u;
+}
+
 struct Lane16 {
     uint32_t tab, nl;     // UNESCAPED tabs / newlines among this lane's 16 bytes
 };
@@ -272,7 +280,7 @@ __device__ __forceinline__ uint64_t lds_u64(uint32_t off) { return reinterpret_c
 // bit 7 of each byte: set iff the byte of x is non-zero (exact, no carries between bytes)
 __device__ __forceinline__ uint32_t nz7(uint32_t x) { return ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x; }
 // bits 7, 15, 23, 31 -> bits 0..3 (one 24-bit multiply)
-__device__ __forceinline__ uint32_t pack4(uint32_t m7) { return ((__umul24(m7 >> 7, 0x4081u) >> 14) & 7u) | ((m7 >> 28) & 8u); }
+__device__ __forceinline__ uint32_t pack4(uint32_t m7) { return ((__umul24((m7 & 0x00808080u) >> 7, 0x4081u) >> 14) & 7u) | ((m7 >> 28) & 8u); }      // (the mask lets the compiler prove 24 bits: v_mul_u32_u24, not the quarter-rate 32-bit multiply)
 __device__ __forceinline__ uint32_t pack16(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
     return pack4(a) | (pack4(b) << 4) | (pack4(c) << 8) | (pack4(d) << 12);
@@ -448,7 +456,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
 }
 
 template <bool DEFER>
-__global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass1Args a)
+__global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass1Args a)
 {
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t wave_id = blockIdx.x * P1_WPB + wv, wave_count = gridDim.x * P1_WPB;
@@ -517,14 +525,26 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         uint32_t bs_carry = (pos0 > a.lo && a.in[pos0 - 1] == '\\') ? 1u : 0u;
         bool done = false;
 
+        // Per-round bookkeeping is 32-bit: positions relative to the visit base, clamped to [0, 2^31) (a visit
+        // moves its base long before it gets there); 64-bit positions are rebuilt only on the rare paths.
+        uint32_t rel_ss, rel_se1, rel_hi, rel_n;
+        auto rel31 = [&](uint64_t x) {
+            const int64_t dlt = (int64_t)(x - ws.vbase);
+            return dlt < 0 ? 0u : (dlt > 0x7fffffffll ? 0x7fffffffu : (uint32_t)dlt);
+        };
+        auto set_rels = [&]() { rel_ss = rel31(ss); rel_se1 = rel31(se - 1); rel_hi = rel31(a.hi); rel_n = rel31(a.n); };
+        set_rels();
+
+        const uint8_t *lane_ptr = a.in + pos0 + 16u * lane;               // this lane's 16 bytes of the current round
         uint4 nxt = load_round16(a.in, pos0, lane, a.n);
-        for (uint64_t pos = pos0; !done && pos < a.hi; pos += WROUND) {
+        for (uint32_t relb = (uint32_t)(pos0 - ws.vbase); !done && relb < rel_hi; relb += WROUND, lane_ptr += WROUND) {
             const uint4 v = nxt;
-            nxt = load_round16(a.in, pos + WROUND, lane, a.n);            // next round in flight
-            const uint64_t lp = pos + 16ull * lane;
-            uint32_t relb = (uint32_t)(pos - ws.vbase);                   // relative position of the round
+            // next round in flight: a plain load while it stays inside the image, the clamped form at its end
+            if (relb + 2u * WROUND <= rel_n) nxt = *reinterpret_cast<const uint4 *>(lane_ptr + WROUND);
+            else nxt = load_round16(a.in, ws.vbase + relb + WROUND, lane, a.n);
+            uint32_t lrel = relb + 16u * lane;                            // relative position of my first byte
             {   // keep the round in the LDS byte ring (two rounds deep): field work reads its bytes from there
-                const uint32_t slot = (uint32_t)pos & (BYTE_RING - 1);            // 0 or 1024
+                const uint32_t slot = relb & (BYTE_RING - 1);                     // 0 or 1024 (the base is a multiple of the ring)
                 *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + slot + 16u * lane) = v;
                 if (slot == 0 && lane < RING_TAIL / 16u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + BYTE_RING + 16u * lane) = v;
             }
@@ -533,19 +553,21 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
             uint32_t bnd, nl = 0;
             {
                 const uint32_t tn0 = nz7(v.x ^ 0x0a0a0a0au), tn1 = nz7(v.y ^ 0x0a0a0a0au), tn2 = nz7(v.z ^ 0x0a0a0a0au), tn3 = nz7(v.w ^ 0x0a0a0a0au);
-                const uint32_t tb0 = nz7(v.x ^ 0x5c5c5c5cu), tb1 = nz7(v.y ^ 0x5c5c5c5cu), tb2 = nz7(v.z ^ 0x5c5c5c5cu), tb3 = nz7(v.w ^ 0x5c5c5c5cu);
-                const uint32_t H = 0x80808080u;
+                const uint32_t H = 0x80808080u, L1 = 0x01010101u;
                 bnd = pack16(~(nz7(v.x ^ 0x09090909u) & tn0) & H, ~(nz7(v.y ^ 0x09090909u) & tn1) & H,
                              ~(nz7(v.z ^ 0x09090909u) & tn2) & H, ~(nz7(v.w ^ 0x09090909u) & tn3) & H);
                 if (__ballot(((tn0 & tn1 & tn2 & tn3) & H) != H)) nl = pack16(~tn0 & H, ~tn1 & H, ~tn2 & H, ~tn3 & H);
-                if (__ballot(((tb0 & tb1 & tb2 & tb3) & H) != H) | bs_carry) {
+                const uint32_t b0 = v.x ^ 0x5c5c5c5cu, b1 = v.y ^ 0x5c5c5c5cu, b2 = v.z ^ 0x5c5c5c5cu, b3 = v.w ^ 0x5c5c5c5cu;
+                const uint32_t anybs = (((b0 - L1) & ~b0) | ((b1 - L1) & ~b1) | ((b2 - L1) & ~b2) | ((b3 - L1) & ~b3)) & H;      // exact for "some byte is a backslash"
+                if (__ballot(anybs != 0) | bs_carry) {
                     // a backslash in (or right before) this round: special iff an even number of backslashes precedes
-                    const uint32_t bs = pack16(~tb0 & H, ~tb1 & H, ~tb2 & H, ~tb3 & H);
+                    const uint32_t bs = pack16(~nz7(b0) & H, ~nz7(b1) & H, ~nz7(b2) & H, ~nz7(b3) & H);
                     uint32_t prev = wave_shr1(bs >> 15);
                     if (lane == 0) prev = bs_carry;
                     bs_carry = lane_value(bs >> 15, 63);
                     const uint32_t cand = bnd & ((bs << 1) | prev) & 0xffffu;
                     if (__ballot(cand != 0)) {          // count the run exactly (bounded by the block start)
+                        const uint64_t lp = ws.vbase + lrel;
                         uint32_t c = cand, esc = 0;
                         while (c) {
                             const uint32_t i = (uint32_t)__builtin_ctz(c);
@@ -560,9 +582,9 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
             }
 
             // positions that exist for this visit: [ss, hi), cut after the first line end at or past se - 1
-            if (pos < ss || pos + WROUND > se - 1) {
-                uint32_t vm = valid16(lp, ss, a.hi);
-                const uint32_t late = nl & vm & valid16(lp, se - 1, ~0ull);
+            if (relb < rel_ss || relb + WROUND > rel_se1) {
+                uint32_t vm = valid16r(lrel, rel_ss, rel_hi);
+                const uint32_t late = nl & vm & valid16r(lrel, rel_se1, 0xffffffffu);
                 const uint64_t lb = __ballot(late != 0);
                 if (lb) {
                     const int fl = lowest_bit(lb);
@@ -582,7 +604,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                 const uint32_t ft_bit = lane_value((uint32_t)__builtin_ctz(nl | 0x10000u), ft_lane);
                 if (!ignoring) {
                     // only the row that was open when the round began can be long enough to grow m_LongestLine
-                    const uint64_t rl = pos + 16ull * (uint32_t)ft_lane + ft_bit - st_row_start + 1;
+                    const uint64_t rl = ws.vbase + (relb + 16u * (uint32_t)ft_lane + ft_bit) - st_row_start + 1;
                     if (rl >= FIRST_ROW_CAP - 1 && lane == 0) {
                         const uint32_t li = atomicAdd(&a.st->long_count, 1u);
                         if (li < a.long_cap) { a.long_rows[li].start = st_row_start; a.long_rows[li].len = rl; }
@@ -594,63 +616,78 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                 }
                 const int lt_lane = highest_bit(tb);
                 const uint32_t lt_bit = lane_value(31u - (uint32_t)__builtin_clz(nl | 1u), lt_lane);
-                st_row_start = pos + 16ull * (uint32_t)lt_lane + lt_bit + 1;
+                st_row_start = ws.vbase + (relb + 16u * (uint32_t)lt_lane + lt_bit) + 1;
             } else if (ignoring) {
                 bnd = 0;
             }
 
             // ---- emit this lane's boundaries; handle descriptors 64 at a time ----
-            // The ring always keeps the head's predecessor, so it can take QCAP - 1 - pending new descriptors;
-            // a denser round is emitted as four 16-lane pieces (<= 256 boundaries each, which always fit an
-            // empty ring) with the ring drained in between.  One loop does both, so that the (large) field
-            // code exists once.
+            // The ring always keeps the head's predecessor, so it can take QCAP - 1 - pending new descriptors.
             static_assert(QCAP >= 256 + 2, "a drained ring must take one 16-lane piece");
             uint32_t nb_total;
             const uint32_t nb_before = wave_excl_sum((uint32_t)__builtin_popcount(bnd), lane, nb_total);
-            bool rebase = relb >= a.rebase_at;                           // relative positions must stay below 2^31
-            const bool whole = !rebase && ws.q_count + nb_total <= QCAP - 1;
-            const bool end_of_visit = done || pos + WROUND >= a.hi;
-            const uint32_t b16 = lane_value(nb_before, 16), b32 = lane_value(nb_before, 32), b48 = lane_value(nb_before, 48);
-            const uint32_t npieces = whole ? 1u : 4u;
-            for (uint32_t piece = 0;; ++piece) {
-                const bool emitting = piece < npieces;
-                const bool drain = emitting ? !whole : end_of_visit;
-                __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
-                while (drain ? ws.q_count > 0 : ws.q_count >= 64) {
-                    const uint32_t cnt = ws.q_count < 64 ? ws.q_count : 64u;
-                    new_entries += consume<DEFER>(a, t, d, L, ws, cnt, lane);
-                    ws.q_head += cnt;
-                    ws.q_count -= cnt;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (!emitting) break;
-                if (rebase) {
-                    // nothing is pending: move the visit base up; the head's predecessor moves with it
-                    const uint32_t delta = (relb - 2u * BYTE_RING) & ~(BYTE_RING - 1u);
-                    if (!ws.first_pending) {
-                        const uint32_t pa = ws.desc | (((ws.q_head - 1u) << 2) & (QCAP * 4u - 1u));
-                        const uint32_t pd = lds_u32(pa);
-                        uint32_t pp = pd & ~DESC_NL;
-                        if (pp < delta) { pp = delta; if (lane == 0) a.st->nul_seen = 2; }      // a single field of 1 GiB or more
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + pa) = (pd & DESC_NL) | (pp - delta);
-                    }
-                    ws.vbase += delta; ws.ring_lo -= delta; relb -= delta;
-                    rebase = false;
-                }
-                const bool active = whole || (lane >> 4) == piece;
-                const uint32_t piece_base = whole ? 0u : (piece == 0 ? 0u : (piece == 1 ? b16 : (piece == 2 ? b32 : b48)));
-                const uint32_t piece_end = whole ? nb_total : (piece == 0 ? b16 : (piece == 1 ? b32 : (piece == 2 ? b48 : nb_total)));
-                uint32_t qoff = (ws.q_head + ws.q_count + nb_before - piece_base) << 2;
-                const uint32_t lrel = relb + 16u * lane;
-                uint32_t bits = active ? bnd : 0u;
+            const bool end_of_visit = done || relb + WROUND >= rel_hi;
+            auto emit = [&](uint32_t bits, uint32_t first_slot) {
+                uint32_t qoff = first_slot << 2;
                 while (bits) {
                     const uint32_t i = (uint32_t)__builtin_ctz(bits);
                     bits &= bits - 1;
                     *reinterpret_cast<uint32_t *>(zdw_lds + (ws.desc | (qoff & (QCAP * 4u - 1u)))) = (lrel + i) | (((nl >> i) & 1u) << 31);
                     qoff += 4;
                 }
-                ws.q_count += piece_end - piece_base;
+            };
+            if (relb < a.rebase_at && ws.q_count + nb_total <= QCAP - 1 && !end_of_visit) {
+                // the common round: everything fits; take descriptors 64 at a time
+                emit(bnd, ws.q_head + ws.q_count + nb_before);
+                ws.q_count += nb_total;
+                __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
+                while (ws.q_count >= 64) {
+                    if (!(a.debug_skip & 32u)) new_entries += consume<DEFER>(a, t, d, L, ws, 64u, lane);      // 32: profiling only, the producer alone
+                    ws.q_head += 64;
+                    ws.q_count -= 64;
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // the last round of a visit (drain everything), a round denser than the ring (emitted as four
+                // 16-lane pieces of <= 256 boundaries each, the ring drained in between), or a visit that has
+                // outgrown its relative positions (drain, then move the base)
+                bool rebase = relb >= a.rebase_at;                           // relative positions must stay below 2^31
+                const bool whole = !rebase && ws.q_count + nb_total <= QCAP - 1;
+                const uint32_t b16 = lane_value(nb_before, 16), b32 = lane_value(nb_before, 32), b48 = lane_value(nb_before, 48);
+                const uint32_t npieces = whole ? 1u : 4u;
+                for (uint32_t piece = 0;; ++piece) {
+                    const bool emitting = piece < npieces;
+                    const bool drain = emitting ? !whole : end_of_visit;
+                    __builtin_amdgcn_wave_barrier();
+                    while (drain ? ws.q_count > 0 : ws.q_count >= 64) {
+                        const uint32_t cnt = ws.q_count < 64 ? ws.q_count : 64u;
+                        new_entries += consume<DEFER>(a, t, d, L, ws, cnt, lane);
+                        ws.q_head += cnt;
+                        ws.q_count -= cnt;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (!emitting) break;
+                    if (rebase) {
+                        // nothing is pending: move the visit base up; the head's predecessor moves with it
+                        const uint32_t delta = (relb - 2u * BYTE_RING) & ~(BYTE_RING - 1u);
+                        if (!ws.first_pending) {
+                            const uint32_t pa = ws.desc | (((ws.q_head - 1u) << 2) & (QCAP * 4u - 1u));
+                            const uint32_t pd = lds_u32(pa);
+                            uint32_t pp = pd & ~DESC_NL;
+                            if (pp < delta) { pp = delta; if (lane == 0) a.st->nul_seen = 2; }      // a single field of 1 GiB or more
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + pa) = (pd & DESC_NL) | (pp - delta);
+                        }
+                        ws.vbase += delta; ws.ring_lo -= delta; relb -= delta; lrel -= delta;
+                        set_rels();
+                        rebase = false;
+                    }
+                    const bool active = whole || (lane >> 4) == piece;
+                    const uint32_t piece_base = whole ? 0u : (piece == 0 ? 0u : (piece == 1 ? b16 : (piece == 2 ? b32 : b48)));
+                    const uint32_t piece_end = whole ? nb_total : (piece == 0 ? b16 : (piece == 1 ? b32 : (piece == 2 ? b48 : nb_total)));
+                    emit(active ? bnd : 0u, ws.q_head + ws.q_count + nb_before - piece_base);
+                    ws.q_count += piece_end - piece_base;
+                }
             }
             ws.ring_lo = relb;              // the next round keeps this one next to it in the byte ring
         }
