@@ -527,21 +527,27 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
 
         // Per-round bookkeeping is 32-bit: positions relative to the visit base, clamped to [0, 2^31) (a visit
         // moves its base long before it gets there); 64-bit positions are rebuilt only on the rare paths.
-        uint32_t rel_ss, rel_se1, rel_hi, rel_n;
+        uint32_t rel_ss, rel_se1, rel_hi;
         auto rel31 = [&](uint64_t x) {
             const int64_t dlt = (int64_t)(x - ws.vbase);
             return dlt < 0 ? 0u : (dlt > 0x7fffffffll ? 0x7fffffffu : (uint32_t)dlt);
         };
-        auto set_rels = [&]() { rel_ss = rel31(ss); rel_se1 = rel31(se - 1); rel_hi = rel31(a.hi); rel_n = rel31(a.n); };
+        auto set_rels = [&]() { rel_ss = rel31(ss); rel_se1 = rel31(se - 1); rel_hi = rel31(a.hi); };
         set_rels();
 
         const uint8_t *lane_ptr = a.in + pos0 + 16u * lane;               // this lane's 16 bytes of the current round
+        const uint8_t *last_chunk = a.in + ((a.n - 1) & ~15ull);
         uint4 nxt = load_round16(a.in, pos0, lane, a.n);
         for (uint32_t relb = (uint32_t)(pos0 - ws.vbase); !done && relb < rel_hi; relb += WROUND, lane_ptr += WROUND) {
             const uint4 v = nxt;
-            // next round in flight: a plain load while it stays inside the image, the clamped form at its end
-            if (relb + 2u * WROUND <= rel_n) nxt = *reinterpret_cast<const uint4 *>(lane_ptr + WROUND);
-            else nxt = load_round16(a.in, ws.vbase + relb + WROUND, lane, a.n);
+            // next round in flight; lanes whose chunk would start at or past the end of the image re-read the last
+            // 16-byte chunk that starts inside it (an aligned chunk whose first byte is inside an allocation never
+            // leaves its page; their bytes lie past `hi` and are masked)
+            {
+                const uint8_t *q = lane_ptr + WROUND;
+                q = q < last_chunk ? q : last_chunk;
+                nxt = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(q, 16));
+            }
             uint32_t lrel = relb + 16u * lane;                            // relative position of my first byte
             {   // keep the round in the LDS byte ring (two rounds deep): field work reads its bytes from there
                 const uint32_t slot = relb & (BYTE_RING - 1);                     // 0 or 1024 (the base is a multiple of the ring)
