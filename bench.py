@@ -110,9 +110,12 @@ def main():
     buf, nbytes = table.generate(rank * rows_per_rank, rows_per_rank)
     torch.cuda.synchronize()
 
-    # N > 1: every rank's table must hold the union of all ranks' strings (record ids are slot indices, so it
-    # cannot be regrown after pass 1): 2^26 slots of 32 B = 2 GiB, room for 42 M distinct strings
-    enc = capi.Encoder(table.types, device=local, dict_slots=(1 << 26) if world > 1 and args.gb >= 2 else ((1 << 22) if world > 1 else 0))
+    # N > 1: every rank's table must hold the union of all ranks' strings (it is not regrown after pass 1):
+    # 2^25 slots of 32 B = 1 GiB take 21 M distinct strings (up to 4 ranks of this table), 2^26 take 42 M
+    slots = 0
+    if world > 1:
+        slots = (1 << 22) if args.gb < 2 else ((1 << 25) if world <= 4 else (1 << 26))
+    enc = capi.Encoder(table.types, device=local, dict_slots=slots)
     enc.set_input_device(buf.data_ptr(), nbytes, keepalive=buf)
     enc.enable_timing(True)
 
