@@ -6,7 +6,8 @@ of a synthetic TSV that is already resident in HBM; outputs stay in HBM.  Worklo
 BASELINE.json configs[3], "Synthetic 10 GB TSV, 200 cols mixed VARCHAR/LONG, Zipf strings"
 (zdw_amd/synth.py).  N > 1 (launched by torch.distributed.run, one rank per GPU):
 weak scaling, every rank holds its own 10 GB row range of ONE ZDW block; RCCL carries the column
-range all-reduce, the dictionary merge (all-gather of unique strings) and the previous-row halo.
+range all-reduce, the dictionary merge (range-partitioned: two all-to-all-v of unique strings / offsets,
+small all-gathers of samples and range sizes) and the previous-row halo.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--gb G] [--cols C] [--no-cpu]
 """
@@ -112,8 +113,9 @@ def main():
 
     # N > 1: every rank's table must hold the union of all ranks' strings (it is not regrown after pass 1):
     # 2^25 slots of 32 B = 1 GiB take 21 M distinct strings (up to 4 ranks of this table), 2^26 take 42 M
-    slots = 0
-    if world > 1:
+    merge = os.environ.get("ZDW_SHARD_MERGE", "partition")
+    slots = 0                     # the range-partitioned dictionary keeps a rank's table to its own strings
+    if world > 1 and merge == "allgather":
         slots = (1 << 22) if args.gb < 2 else ((1 << 25) if world <= 4 else (1 << 26))
     enc = capi.Encoder(table.types, device=local, dict_slots=slots)
     enc.set_input_device(buf.data_ptr(), nbytes, keepalive=buf)
@@ -121,7 +123,7 @@ def main():
 
     def step():
         if world > 1:
-            return sharded.encode_shard_dist(enc, rank, world)
+            return sharded.encode_shard_dist(enc, rank, world, merge=merge)
         rc, p1 = enc.pass1()
         if rc:
             raise capi.ZdwError(rc, "pass1")

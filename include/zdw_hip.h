@@ -156,6 +156,26 @@ int zdw_shard_import_uniques(zdw_ctx *ctx, const void *d_lens, const void *d_byt
 int zdw_shard_last_row(zdw_ctx *ctx, uint64_t *stored /* ncols */);
 int zdw_shard_set_prev_row(zdw_ctx *ctx, const uint64_t *stored /* ncols, NULL = zeros */);
 
+/* Range-partitioned dictionary (instead of export / import of the union): the node-wide dictionary is sorted
+ * once, 1/N of it on every rank.  Per shard, after zdw_block_pass1 and the range exchange:
+ *   zdw_shard_sort_uniques    sort this shard's unique strings (count = how many)
+ *   zdw_shard_sample_keys     nsamples evenly spaced 16-byte prefix keys (2 big-endian u64 each) -> the caller
+ *                             gathers all shards' samples and picks N-1 splitters (the same on every shard)
+ *   zdw_shard_partition       strings in sorted order as lens + NUL-terminated bytes; part p = keys in
+ *                             [splitter[p-1], splitter[p]); counts / nbytes per part -> all-to-all
+ *   zdw_owner_build           (as owner of range r) dedupe + sort + lay out the strings received for it
+ *   zdw_owner_offsets         dictionary offset of every received string, in arrival order -> all-to-all back
+ *   zdw_shard_set_offsets     offsets of this shard's strings (in the order they were sent); from then on
+ *                             zdw_block_dict[_device] returns the piece of the section this rank owns
+ *                             (ranks 0..N-1 concatenated = the reference's section). */
+int zdw_shard_sort_uniques(zdw_ctx *ctx, uint64_t *count);
+int zdw_shard_sample_keys(zdw_ctx *ctx, uint32_t nsamples, uint64_t *keys /* 2 * nsamples */);
+int zdw_shard_partition(zdw_ctx *ctx, uint32_t nparts, const uint64_t *splitters /* 2 * (nparts - 1) */, uint64_t *counts /* nparts */,
+                        uint64_t *nbytes /* nparts */, const void **d_lens, const void **d_bytes);
+int zdw_owner_build(zdw_ctx *ctx, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes, uint64_t *slice_bytes);
+int zdw_owner_offsets(zdw_ctx *ctx, uint64_t base /* dictionary offset of the range's first string */, const void **d_offsets);
+int zdw_shard_set_offsets(zdw_ctx *ctx, const void *d_offsets, uint64_t count, uint64_t dict_size, int first_range);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,13 @@ def _worker(rank, world, port, q):
     r = sharded.allreduce_ranges(mn, mx, seen, device="cpu")
     ol, ob = sharded.allgather_uniques(lens, byts, rank, world)
     prev = sharded.exchange_prev_row(last, nrows, rank, world, device="cpu")
-    q.put((rank, r, ol.tolist(), ob.tolist(), prev))
+    # all-to-all-v plumbing of the range-partitioned dictionary: rank r sends r + 1 + q elements to rank q
+    send_counts = [rank + 1 + peer for peer in range(world)]
+    payload = torch.tensor([1000 * rank + 10 * peer + k for peer in range(world) for k in range(send_counts[peer])], dtype=torch.int32)
+    recv_counts = sharded.exchange_counts(send_counts, "cpu")
+    got = sharded.alltoallv(payload, send_counts, recv_counts)
+    gathered = sharded.allgather_i64([rank * 7, -rank], "cpu")
+    q.put((rank, r, ol.tolist(), ob.tolist(), prev, recv_counts, got.tolist(), gathered))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,8 +52,8 @@ def test_collectives_match_pure_merges():
         p.start()
     got = {}
     for _ in range(world):
-        rank, r, ol, ob, prev = q.get(timeout=120)
-        got[rank] = (r, ol, ob, prev)
+        rank, r, ol, ob, prev, rc_, a2a, gath = q.get(timeout=120)
+        got[rank] = (r, ol, ob, prev, rc_, a2a, gath)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -55,11 +61,26 @@ def test_collectives_match_pure_merges():
     want_ranges = sharded.merge_ranges([(d[0], d[1], d[2]) for d in data])
     want_prev = sharded.chain_prev_rows([d[5] for d in data], [d[6] for d in data])
     for rank in range(world):
-        r, ol, ob, prev = got[rank]
+        r, ol, ob, prev, rc_, a2a, gath = got[rank]
+        assert rc_ == [peer + 1 + rank for peer in range(world)]
+        assert a2a == [1000 * peer + 10 * rank + k for peer in range(world) for k in range(peer + 1 + rank)]
+        assert gath == [[p * 7, -p] for p in range(world)]
         assert (list(r[0]), list(r[1]), list(r[2])) == (want_ranges[0], want_ranges[1], want_ranges[2])
         wl, wb = sharded.concat_uniques([(d[3], d[4]) for d in data], skip=rank)
         assert ol == wl.tolist() and ob == wb.tolist()
         assert prev == want_prev[rank]
+
+
+def test_pure_partition_helpers():
+    assert sharded.pick_splitters([(5, 1), (3, 2), (9, 9), (1, 1), (7, 0), (2, 2)], 3) == [(3, 2), (7, 0)]
+    assert sharded.pick_splitters([(1, 1)], 1) == []
+    big = (1 << 64) - 1
+    sp = sharded.pick_splitters([(big, big)] * 4 + [(2, 0), (2, 5)], 3)
+    assert sp == sorted(sp) and len(sp) == 2
+    assert sharded.range_bases([10, 0, 5]) == ([1, 11, 11], 16)
+    assert sharded.range_bases([]) == ([], 1)
+    for v in (0, 1, (1 << 63) - 1, 1 << 63, big):
+        assert sharded._i64_to_u64(sharded._u64_to_i64(v)) == v
 
 
 def test_pure_merges():

@@ -67,6 +67,12 @@ def lib():
         L.zdw_shard_import_ranges.argtypes = [vp, u64p, u64p, u8p]
         L.zdw_shard_export_uniques.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), u64p, u64p]
         L.zdw_shard_import_uniques.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
+        L.zdw_shard_sort_uniques.argtypes = [vp, u64p]
+        L.zdw_shard_sample_keys.argtypes = [vp, C.c_uint32, u64p]
+        L.zdw_shard_partition.argtypes = [vp, C.c_uint32, u64p, u64p, u64p, C.POINTER(vp), C.POINTER(vp)]
+        L.zdw_owner_build.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, u64p]
+        L.zdw_owner_offsets.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+        L.zdw_shard_set_offsets.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int]
         L.zdw_shard_last_row.argtypes = [vp, u64p]
         L.zdw_shard_set_prev_row.argtypes = [vp, u64p]
         _lib = L
@@ -206,6 +212,40 @@ class Encoder:
 
     def import_uniques(self, d_lens, d_bytes, count, nbytes):
         self._chk(self.L.zdw_shard_import_uniques(self.h, C.c_void_p(d_lens), C.c_void_p(d_bytes), count, nbytes))
+
+    # ---- range-partitioned dictionary (see include/zdw_hip.h) ----
+    def sort_uniques(self):
+        n = C.c_uint64()
+        self._chk(self.L.zdw_shard_sort_uniques(self.h, C.byref(n)))
+        return n.value
+
+    def sample_keys(self, nsamples):
+        """[(k0, k1)] * nsamples: 16-byte prefix keys (two big-endian words) at evenly spaced sorted positions"""
+        buf = (C.c_uint64 * max(1, 2 * nsamples))()
+        self._chk(self.L.zdw_shard_sample_keys(self.h, nsamples, buf))
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(nsamples)]
+
+    def partition(self, splitters):
+        """splitters: sorted [(k0, k1)] * (nparts - 1).  Returns (counts[nparts], nbytes[nparts], d_lens, d_bytes)."""
+        nparts = len(splitters) + 1
+        flat = (C.c_uint64 * max(1, 2 * len(splitters)))(*[w for k in splitters for w in k])
+        counts, nb = (C.c_uint64 * nparts)(), (C.c_uint64 * nparts)()
+        lens, byts = C.c_void_p(), C.c_void_p()
+        self._chk(self.L.zdw_shard_partition(self.h, nparts, flat, counts, nb, C.byref(lens), C.byref(byts)))
+        return list(counts), list(nb), lens.value, byts.value
+
+    def owner_build(self, d_lens, d_bytes, count, nbytes):
+        out = C.c_uint64()
+        self._chk(self.L.zdw_owner_build(self.h, C.c_void_p(d_lens), C.c_void_p(d_bytes), count, nbytes, C.byref(out)))
+        return out.value
+
+    def owner_offsets(self, base):
+        p = C.c_void_p()
+        self._chk(self.L.zdw_owner_offsets(self.h, base, C.byref(p)))
+        return p.value
+
+    def set_offsets(self, d_offsets, count, dict_size, first_range):
+        self._chk(self.L.zdw_shard_set_offsets(self.h, C.c_void_p(d_offsets), count, dict_size, 1 if first_range else 0))
 
     def last_row(self):
         out = (C.c_uint64 * max(1, self.ncols))()

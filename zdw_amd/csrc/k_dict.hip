@@ -273,24 +273,104 @@ void launch_dict_emit(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_export_strings(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
                                                          const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
-                                                         const uint64_t *__restrict__ off_excl, uint32_t n, uint8_t *__restrict__ bytes)
+                                                         const uint32_t *__restrict__ order, const uint64_t *__restrict__ off_excl, uint32_t n,
+                                                         uint8_t *__restrict__ bytes, uint32_t *__restrict__ lens_out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t len = uniq_len[i];
+    const uint32_t u = order ? order[i] : i;
+    const uint32_t len = uniq_len[u];
+    if (lens_out) lens_out[i] = len;
     if (!len) return;                                            // hole: no bytes were reserved for it
-    const uint8_t *p = string_at(in, extra, uniq_pos[i]);
+    const uint8_t *p = string_at(in, extra, uniq_pos[u]);
     uint8_t *q = bytes + off_excl[i];
     for (uint32_t k = 0; k < len; ++k) q[k] = p[k];
     q[len] = 0;
 }
 
-void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
-                           const uint64_t *off_excl, uint64_t n, uint8_t *bytes, hipStream_t s)
+void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, const uint32_t *order,
+                           const uint64_t *off_excl, uint64_t n, uint8_t *bytes, uint32_t *lens_out, hipStream_t s)
 {
     if (!n) return;
-    hipLaunchKernelGGL(k_export_strings, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, off_excl,
-                       (uint32_t)n, bytes);
+    hipLaunchKernelGGL(k_export_strings, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, order, off_excl,
+                       (uint32_t)n, bytes, lens_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// range-partitioned dictionary (multi-GPU): 16-byte prefix keys, splitter search, offset plumbing
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void key16_of(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos,
+                                         const uint32_t *uniq_len, uint32_t u, uint64_t &k0, uint64_t &k1)
+{
+    const uint64_t pos = uniq_pos[u];
+    const uint32_t len = uniq_len[u];
+    const uint8_t *p = string_at(in, extra, pos);
+    const uint8_t *end = pos >= EXTRA_BASE ? p + len + 16 : in + in_bytes;
+    k0 = sort_key8(p, len, 0, end);
+    k1 = sort_key8(p, len, 1, end);
+}
+
+// keys[2i], keys[2i+1] = first 16 bytes (big-endian words) of the string at sorted position idx[i]
+__global__ __launch_bounds__(64) void k_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos,
+                                                  const uint32_t *uniq_len, const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key16_of(in, in_bytes, extra, uniq_pos, uniq_len, order[idx[i]], keys[2 * i], keys[2 * i + 1]);
+}
+
+// bounds[j] = first sorted position p in [lo, hi) whose 16-byte key is >= splitter j (hi when none)
+__global__ __launch_bounds__(64) void k_partition_search(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos,
+                                                          const uint32_t *uniq_len, const uint32_t *order, uint32_t lo, uint32_t hi,
+                                                          const uint64_t *splitters, uint32_t nsplit, uint32_t *bounds)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nsplit) return;
+    const uint64_t s0 = splitters[2 * j], s1 = splitters[2 * j + 1];
+    uint32_t a = lo, b = hi;
+    while (a < b) {
+        const uint32_t m = a + (b - a) / 2;
+        uint64_t k0, k1;
+        key16_of(in, in_bytes, extra, uniq_pos, uniq_len, order[m], k0, k1);
+        const bool less = k0 < s0 || (k0 == s0 && k1 < s1);
+        if (less) a = m + 1; else b = m;
+    }
+    bounds[j] = a;
+}
+
+__global__ __launch_bounds__(256) void k_owner_offsets(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ id_off, uint32_t base,
+                                                        uint32_t n, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ids[i] ? base + id_off[ids[i] - 1] : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_scatter_offsets(const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets, uint32_t n,
+                                                          uint32_t *__restrict__ id_off)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) id_off[order[i]] = offsets[i];
+}
+
+void launch_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                     const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_key16_at, dim3((n + 63) / 64), dim3(64), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order, idx, n, keys);
+}
+void launch_partition_search(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                             const uint32_t *order, uint32_t lo, uint32_t hi, const uint64_t *splitters, uint32_t nsplit, uint32_t *bounds,
+                             hipStream_t s)
+{
+    if (nsplit) hipLaunchKernelGGL(k_partition_search, dim3((nsplit + 63) / 64), dim3(64), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order,
+                                   lo, hi, splitters, nsplit, bounds);
+}
+void launch_owner_offsets(const uint32_t *ids, const uint32_t *id_off, uint32_t base, uint64_t n, uint32_t *out, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_owner_offsets, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, ids, id_off, base, (uint32_t)n, out);
+}
+void launch_scatter_offsets(const uint32_t *order, const uint32_t *offsets, uint64_t n, uint32_t *id_off, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_scatter_offsets, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, order, offsets, (uint32_t)n, id_off);
 }
 
 // Persistent waves: a wave keeps its chunk of unique ids across the groups of 64 strings it handles (one

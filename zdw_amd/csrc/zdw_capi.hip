@@ -95,6 +95,14 @@ struct zdw_ctx {
         slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
     uint64_t nuniq = 0, dict_size = 0, extra_bytes = 0;
     uint32_t id_cap = 0;                   // capacity of uniq_pos / uniq_len (unique ids, holes included)
+    // range-partitioned dictionary (multi-GPU): this shard as a requester ...
+    DevBuf my_order, part_idx, part_keys, part_bounds, part_split, part_lens;
+    uint64_t sorted_n = 0, sorted_holes = 0;
+    bool uniques_sorted = false;
+    // ... and as the owner of one key range of the node-wide dictionary
+    DevBuf own_slots, own_upos, own_ulen, own_status, own_extra, own_lens, own_offs, own_ids, own_idoff, own_blob, own_out;
+    uint64_t own_count = 0, own_slice = 0;
+    bool own_built = false;
     bool p1_all_in_one = false;            // an earlier block overflowed the deferred-field queue: use the all-in-one kernel
     uint8_t index_size = 0;
     uint64_t dict_sec_off = 0, dict_sec_len = 0;
@@ -170,6 +178,7 @@ void collect_times(zdw_ctx *c)
 void reset_block(zdw_ctx *c)
 {
     c->p1_done = c->dict_done = c->stats_done = c->p2_done = false;
+    c->uniques_sorted = c->own_built = false;
     c->nrows = 0; c->nuniq = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
     c->have_prev = false;
 }
@@ -228,6 +237,32 @@ int after_input(zdw_ctx *c)
     return ZDW_OK;
 }
 
+// exact string sort of u strings (by id: pos / len, length 0 = hole) into c->order (holes first)
+int sort_strings(zdw_ctx *c, const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *upos, const uint32_t *ulen, uint64_t u,
+                 uint32_t max_len)
+{
+    hipStream_t s = c->stream;
+    StageScope ts(c, ZDW_STAGE_DICT_SORT);
+    const size_t nb = sort_blocks(u ? u : 1);
+    HIP_TRY(c, c->key_a.ensure((u + 1) * 8)); HIP_TRY(c, c->key_b.ensure((u + 1) * 8));
+    HIP_TRY(c, c->val_a.ensure((u + 1) * 4)); HIP_TRY(c, c->val_b.ensure((u + 1) * 4));
+    HIP_TRY(c, c->order.ensure((u + 1) * 4)); HIP_TRY(c, c->group.ensure((u + 1) * 4));
+    HIP_TRY(c, c->active_a.ensure((u + 1) * 4)); HIP_TRY(c, c->active_b.ensure((u + 1) * 4));
+    HIP_TRY(c, c->flags.ensure((6 * u + 8) * 4));
+    HIP_TRY(c, c->hist.ensure((2 * (256 * nb + 1) + 8) * 4));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(std::max<uint64_t>(256 * nb + 1, std::max<uint64_t>(u + 1, c->nrows + 1ull)))));
+    SortBuffers b{};
+    b.key_a = c->key_a.as<uint64_t>(); b.key_b = c->key_b.as<uint64_t>();
+    b.val_a = c->val_a.as<uint32_t>(); b.val_b = c->val_b.as<uint32_t>();
+    b.order = c->order.as<uint32_t>(); b.group = c->group.as<uint32_t>();
+    b.active_a = c->active_a.as<uint32_t>(); b.active_b = c->active_b.as<uint32_t>();
+    b.flags = c->flags.as<uint32_t>(); b.hist = c->hist.as<uint32_t>();
+    b.scan_tmp = c->scan_tmp.p; b.counter = c->d_scalar.as<uint32_t>();
+    const int e = dict_sort(in, in_bytes, extra, upos, ulen, u, b, s, &c->sort_rounds, max_len);
+    if (e) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary sort: %s", hipGetErrorString((hipError_t)e));
+    return ZDW_OK;
+}
+
 // ---- dictionary: table -> sorted blob + slot offsets -----------------------------------------
 int ensure_dict(zdw_ctx *c)
 {
@@ -247,25 +282,8 @@ int ensure_dict(zdw_ctx *c)
     }
     const uint64_t u = count;
     {
-        StageScope ts(c, ZDW_STAGE_DICT_SORT);
-        const size_t nb = sort_blocks(u ? u : 1);
-        HIP_TRY(c, c->key_a.ensure((u + 1) * 8)); HIP_TRY(c, c->key_b.ensure((u + 1) * 8));
-        HIP_TRY(c, c->val_a.ensure((u + 1) * 4)); HIP_TRY(c, c->val_b.ensure((u + 1) * 4));
-        HIP_TRY(c, c->order.ensure((u + 1) * 4)); HIP_TRY(c, c->group.ensure((u + 1) * 4));
-        HIP_TRY(c, c->active_a.ensure((u + 1) * 4)); HIP_TRY(c, c->active_b.ensure((u + 1) * 4));
-        HIP_TRY(c, c->flags.ensure((6 * u + 8) * 4));
-        HIP_TRY(c, c->hist.ensure((2 * (256 * nb + 1) + 8) * 4));
-        HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(std::max<uint64_t>(256 * nb + 1, std::max<uint64_t>(u + 1, c->nrows + 1ull)))));
-        SortBuffers b{};
-        b.key_a = c->key_a.as<uint64_t>(); b.key_b = c->key_b.as<uint64_t>();
-        b.val_a = c->val_a.as<uint32_t>(); b.val_b = c->val_b.as<uint32_t>();
-        b.order = c->order.as<uint32_t>(); b.group = c->group.as<uint32_t>();
-        b.active_a = c->active_a.as<uint32_t>(); b.active_b = c->active_b.as<uint32_t>();
-        b.flags = c->flags.as<uint32_t>(); b.hist = c->hist.as<uint32_t>();
-        b.scan_tmp = c->scan_tmp.p; b.counter = c->d_scalar.as<uint32_t>();
-        const int e = dict_sort(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, b, s,
-                                &c->sort_rounds, max_len);
-        if (e) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary sort: %s", hipGetErrorString((hipError_t)e));
+        int rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, max_len);
+        if (rc) return rc;
     }
     {
         StageScope ts(c, ZDW_STAGE_DICT_EMIT);
@@ -464,7 +482,9 @@ void zdw_ctx_destroy(zdw_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_times(c);
     DevBuf *bufs[] = {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->scan_tmp, &c->rec,
-                      &c->slots, &c->deferred_q, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
+                      &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
+                      &c->own_upos, &c->own_ulen, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
+                      &c->own_out, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
                       &c->uniq_pos, &c->uniq_len, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
                       &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
                       &c->extra_lens, &c->extra_offs, &c->exp_bytes, &c->d_used_recoff, &c->d_used_kind, &c->d_used_size,
@@ -829,8 +849,8 @@ int zdw_shard_export_uniques(zdw_ctx *c, const void **d_lens, const void **d_byt
     HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, c->exp_bytes.ensure(total + 16));
-    launch_export_strings(c->d_in, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), c->off_excl.as<uint64_t>(), u,
-                          c->exp_bytes.as<uint8_t>(), s);
+    launch_export_strings(c->d_in, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), nullptr, c->off_excl.as<uint64_t>(), u,
+                          c->exp_bytes.as<uint8_t>(), nullptr, s);
     HIP_TRY(c, hipStreamSynchronize(s));
     if (d_lens) *d_lens = c->uniq_len.p;
     if (d_bytes) *d_bytes = c->exp_bytes.p;
@@ -904,6 +924,232 @@ int zdw_shard_last_row(zdw_ctx *c, uint64_t *stored)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (uint32_t u = 0; u < a.nused; ++u) stored[c->used[u]] = last[u];
     }
+    return ZDW_OK;
+}
+
+
+// ---- range-partitioned dictionary: the node-wide dictionary is sorted once, 1/N of it on every rank -------
+// Requester side of shard r:  sort own uniques -> sample 16-byte keys -> (splitters agreed by the caller) ->
+// partition: strings in sorted order, part p = keys in [splitter[p-1], splitter[p]) -> all-to-all ->
+// (owner side builds its range) -> offsets come back in the order the strings were sent -> set_offsets.
+int zdw_shard_sort_uniques(zdw_ctx *c, uint64_t *count)
+{
+    if (!c || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    P1Status st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (st.id_next > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", st.id_next, c->id_cap);
+    const uint64_t u = st.id_next;
+    int rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u,
+                          std::max<uint32_t>(24, st.max_len));
+    if (rc) return rc;
+    // keep the order: the owner-side sort reuses the sort buffers.  Holes (length 0) sort first.
+    HIP_TRY(c, c->my_order.ensure((u + 1) * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->my_order.p, c->order.p, u * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->sorted_n = u;
+    c->sorted_holes = u - st.entries;
+    {   // holes sort first and `entries` counts the strings: check the boundary rather than trust the arithmetic
+        const uint64_t H = c->sorted_holes;
+        uint32_t ids[2] = {0, 0}, lens[2] = {0, 1};
+        if (st.entries > u) return fail(c, ZDW_UNKNOWN_ERROR, "more dictionary entries (%u) than unique ids (%u)", st.entries, st.id_next);
+        if (H > 0) HIP_TRY(c, hipMemcpy(&ids[0], c->my_order.as<uint32_t>() + (H - 1), 4, hipMemcpyDeviceToHost));
+        if (H < u) HIP_TRY(c, hipMemcpy(&ids[1], c->my_order.as<uint32_t>() + H, 4, hipMemcpyDeviceToHost));
+        if (H > 0) HIP_TRY(c, hipMemcpy(&lens[0], c->uniq_len.as<uint32_t>() + ids[0], 4, hipMemcpyDeviceToHost));
+        if (H < u) HIP_TRY(c, hipMemcpy(&lens[1], c->uniq_len.as<uint32_t>() + ids[1], 4, hipMemcpyDeviceToHost));
+        if (lens[0] != 0 || lens[1] == 0) return fail(c, ZDW_UNKNOWN_ERROR, "unique-id holes (%llu) do not match the entry count", (unsigned long long)H);
+    }
+    c->uniques_sorted = true;
+    if (count) *count = st.entries;
+    return ZDW_OK;
+}
+
+int zdw_shard_sample_keys(zdw_ctx *c, uint32_t nsamples, uint64_t *keys)
+{
+    if (!c || !c->uniques_sorted) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_sort_uniques has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    const uint64_t real = c->sorted_n - c->sorted_holes;
+    for (uint32_t i = 0; i < 2 * nsamples; ++i) keys[i] = ~0ull;           // a shard without strings samples "infinity"
+    if (!real || !nsamples) return ZDW_OK;
+    std::vector<uint32_t> idx(nsamples);
+    for (uint32_t i = 0; i < nsamples; ++i) idx[i] = (uint32_t)(c->sorted_holes + (uint64_t)(i + 1) * real / (nsamples + 1));
+    for (auto &x : idx) if (x >= c->sorted_n) x = (uint32_t)c->sorted_n - 1;
+    HIP_TRY(c, c->part_idx.ensure(nsamples * 4)); HIP_TRY(c, c->part_keys.ensure(nsamples * 16));
+    HIP_TRY(c, hipMemcpyAsync(c->part_idx.p, idx.data(), nsamples * 4, hipMemcpyHostToDevice, s));
+    launch_key16_at(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), c->my_order.as<uint32_t>(),
+                    c->part_idx.as<uint32_t>(), nsamples, c->part_keys.as<uint64_t>(), s);
+    HIP_TRY(c, hipMemcpyAsync(keys, c->part_keys.p, nsamples * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return ZDW_OK;
+}
+
+int zdw_shard_partition(zdw_ctx *c, uint32_t nparts, const uint64_t *splitters, uint64_t *counts, uint64_t *nbytes, const void **d_lens,
+                        const void **d_bytes)
+{
+    if (!c || !c->uniques_sorted) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_sort_uniques has not run") : ZDW_UNKNOWN_ERROR;
+    if (!nparts || !counts || !nbytes) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_partition: bad arguments");
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    const uint64_t real = c->sorted_n - c->sorted_holes;
+    const uint32_t *order = c->my_order.as<uint32_t>() + c->sorted_holes;      // the real strings, sorted
+    HIP_TRY(c, c->lenp1.ensure((real + 1) * 4)); HIP_TRY(c, c->off_excl.ensure((real + 2) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(real + 1)));
+    HIP_TRY(c, c->part_lens.ensure((real + 1) * 4));
+    launch_dict_lengths(order, c->uniq_len.as<uint32_t>(), real, c->lenp1.as<uint32_t>(), s);
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), real, c->scan_tmp.p, nullptr, s);
+    // part boundaries: first sorted position whose 16-byte key reaches each splitter
+    std::vector<uint32_t> bounds(nparts + 1, 0);
+    bounds[nparts] = (uint32_t)real;
+    if (nparts > 1) {
+        HIP_TRY(c, c->part_split.ensure((nparts - 1) * 16)); HIP_TRY(c, c->part_bounds.ensure((nparts - 1) * 4));
+        HIP_TRY(c, hipMemcpyAsync(c->part_split.p, splitters, (nparts - 1) * 16, hipMemcpyHostToDevice, s));
+        launch_partition_search(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), order, 0,
+                                (uint32_t)real, c->part_split.as<uint64_t>(), nparts - 1, c->part_bounds.as<uint32_t>(), s);
+        HIP_TRY(c, hipMemcpyAsync(bounds.data() + 1, c->part_bounds.p, (nparts - 1) * 4, hipMemcpyDeviceToHost, s));
+    }
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + real, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (uint32_t p = 1; p <= nparts; ++p) if (bounds[p] < bounds[p - 1]) bounds[p] = bounds[p - 1];      // splitters arrive sorted; be safe
+    std::vector<uint64_t> offs(nparts + 1, 0);
+    for (uint32_t p = 1; p < nparts; ++p)
+        HIP_TRY(c, hipMemcpyAsync(&offs[p], c->off_excl.as<uint64_t>() + bounds[p], 8, hipMemcpyDeviceToHost, s));
+    offs[nparts] = total;
+    HIP_TRY(c, c->exp_bytes.ensure(total + 16));
+    launch_export_strings(c->d_in, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), order, c->off_excl.as<uint64_t>(),
+                          real, c->exp_bytes.as<uint8_t>(), c->part_lens.as<uint32_t>(), s);
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (uint32_t p = 0; p < nparts; ++p) { counts[p] = bounds[p + 1] - bounds[p]; nbytes[p] = offs[p + 1] - offs[p]; }
+    if (d_lens) *d_lens = c->part_lens.p;
+    if (d_bytes) *d_bytes = c->exp_bytes.p;
+    return ZDW_OK;
+}
+
+// Owner side: the strings of one key range from every shard (lens + NUL-terminated bytes, any order, duplicates
+// across shards): dedupe, sort, lay out.  slice_bytes = the bytes this range takes in the dictionary.
+int zdw_owner_build(zdw_ctx *c, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes, uint64_t *slice_bytes)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    c->own_built = false; c->own_count = count; c->own_slice = 0;
+    if (nbytes >= EXTRA_BASE || count >= 0xFFFFFFF0ull) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary range too large");
+    uint64_t nslots = 1ull << 14;
+    while (nslots < 2 * count) nslots <<= 1;
+    const uint64_t cap = count + 64ull * 16384 + 64;
+    HIP_TRY(c, c->own_slots.ensure(nslots * 32)); HIP_TRY(c, c->own_upos.ensure(cap * 8)); HIP_TRY(c, c->own_ulen.ensure(cap * 4));
+    HIP_TRY(c, c->own_status.ensure(sizeof(P1Status)));
+    HIP_TRY(c, c->own_extra.ensure(nbytes + 16)); HIP_TRY(c, c->own_lens.ensure((count + 1) * 4)); HIP_TRY(c, c->own_offs.ensure((count + 2) * 8));
+    HIP_TRY(c, c->own_ids.ensure((count + 1) * 4));
+    HIP_TRY(c, c->lenp1.ensure((cap + 1) * 4)); HIP_TRY(c, c->off_excl.ensure((cap + 2) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(cap + 1)));
+    HIP_TRY(c, hipMemsetAsync(c->own_slots.p, 0, nslots * 32, s));
+    P1Status init{};
+    init.bad_row = 0xFFFFFFFFu;
+    HIP_TRY(c, hipMemcpyAsync(c->own_status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
+    if (count) {
+        HIP_TRY(c, hipMemcpyAsync(c->own_extra.p, d_bytes, nbytes, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->own_lens.p, d_lens, count * 4, hipMemcpyDeviceToDevice, s));
+    }
+    launch_dict_lengths(nullptr, c->own_lens.as<uint32_t>(), count, c->lenp1.as<uint32_t>(), s);
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->own_offs.as<uint64_t>(), count, c->scan_tmp.p, nullptr, s);
+    uint64_t total_in = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total_in, c->own_offs.as<uint64_t>() + count, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (total_in != nbytes)
+        return fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_build: lengths add up to %llu bytes, %llu were passed", (unsigned long long)total_in,
+                    (unsigned long long)nbytes);
+    launch_import_strings(nullptr, 0, c->own_extra.as<uint8_t>(), c->own_lens.as<uint32_t>(), c->own_offs.as<uint64_t>(), count,
+                          c->own_slots.as<uint64_t>(), nslots - 1, (uint32_t)std::min<uint64_t>(nslots - nslots / 8, 0xFFFFFFF0ull),
+                          c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), (uint32_t)cap, 0u, 0, c->own_status.as<P1Status>(),
+                          c->own_ids.as<uint32_t>(), s);
+    P1Status st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->own_status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (st.overflow || st.id_next > cap) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_build: range table overflow");
+    const uint64_t u = st.id_next;
+    int rc = sort_strings(c, nullptr, 0, c->own_extra.as<uint8_t>(), c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), u,
+                          std::max<uint32_t>(24, st.max_len));
+    if (rc) return rc;
+    {
+        StageScope ts(c, ZDW_STAGE_DICT_EMIT);
+        launch_dict_lengths(c->order.as<uint32_t>(), c->own_ulen.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
+        launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+        uint64_t total = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (total >= (1ull << 32)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary range exceeds 2^32 bytes: split the block");
+        HIP_TRY(c, c->own_blob.ensure(16 + total + 16));
+        HIP_TRY(c, c->own_idoff.ensure((u + 1) * 4));
+        // blob[0] is the byte before the range (the origin byte when this is the first range); local offsets start at 1
+        launch_dict_emit(nullptr, 0, c->own_extra.as<uint8_t>(), c->order.as<uint32_t>(), c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(),
+                         c->off_excl.as<uint64_t>(), u, c->own_blob.as<uint8_t>() + 8, c->own_idoff.as<uint32_t>(), s);
+        HIP_TRY(c, hipStreamSynchronize(s));
+        c->own_slice = total;
+    }
+    c->own_built = true;
+    if (slice_bytes) *slice_bytes = c->own_slice;
+    return ZDW_OK;
+}
+
+// dictionary offsets of the strings zdw_owner_build received, in arrival order; base = offset of the range's first string
+int zdw_owner_offsets(zdw_ctx *c, uint64_t base, const void **d_offsets)
+{
+    if (!c || !c->own_built) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_build has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    if (base == 0 || base + c->own_slice > (1ull << 32)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary exceeds 2^32 bytes: split the block");
+    HIP_TRY(c, c->own_out.ensure((c->own_count + 1) * 4));
+    launch_owner_offsets(c->own_ids.as<uint32_t>(), c->own_idoff.as<uint32_t>(), (uint32_t)(base - 1), c->own_count, c->own_out.as<uint32_t>(),
+                         c->stream);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (d_offsets) *d_offsets = c->own_out.p;
+    return ZDW_OK;
+}
+
+// Requester side, last step: offsets of this shard's strings (in the order zdw_shard_partition sent them);
+// dict_size = size of the whole dictionary.  The shard's dictionary section becomes the range it owns
+// (with the section header when it owns the first range): sections of ranks 0..N-1 concatenate to the file's.
+int zdw_shard_set_offsets(zdw_ctx *c, const void *d_offsets, uint64_t count, uint64_t dict_size, int first_range)
+{
+    if (!c || !c->uniques_sorted || !c->own_built) return c ? fail(c, ZDW_UNKNOWN_ERROR, "partitioned dictionary steps out of order") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    const uint64_t real = c->sorted_n - c->sorted_holes;
+    if (count != real) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_set_offsets: %llu offsets for %llu strings", (unsigned long long)count,
+                                   (unsigned long long)real);
+    const uint64_t limit = c->max_dict_bytes && c->max_dict_bytes < (1ull << 32) ? c->max_dict_bytes : (1ull << 32) - 1;
+    if (dict_size > limit)
+        return fail(c, ZDW_OUT_OF_MEMORY, "dictionary of %llu bytes exceeds the limit of %llu: split the block (smaller zdw_split_hint.max_rows)",
+                    (unsigned long long)dict_size, (unsigned long long)limit);
+    HIP_TRY(c, c->slot_off.ensure((c->sorted_n + 1) * 4));
+    launch_scatter_offsets(c->my_order.as<uint32_t>() + c->sorted_holes, static_cast<const uint32_t *>(d_offsets), real, c->slot_off.as<uint32_t>(), s);
+    c->dict_size = dict_size;
+    c->index_size = (uint8_t)bytes_for(dict_size);
+    // this rank's piece of the dictionary section
+    HIP_TRY(c, c->dict_sec.ensure(16 + c->own_slice + 16));
+    uint8_t *sec = c->dict_sec.as<uint8_t>();
+    HIP_TRY(c, hipMemcpyAsync(sec + 8, c->own_blob.as<uint8_t>() + 8, 1 + c->own_slice, hipMemcpyDeviceToDevice, s));
+    if (first_range) {
+        if (dict_size <= 1) {                       // empty set: a single 00 (dictionary.cpp:80-84)
+            c->dict_sec_off = 8; c->dict_sec_len = 1;
+        } else {
+            uint8_t hdr[8];
+            hdr[0] = c->index_size;
+            for (unsigned i = 0; i < c->index_size; ++i) hdr[1 + i] = (uint8_t)(dict_size >> (8 * i));
+            c->dict_sec_off = 8 - 1 - c->index_size;
+            c->dict_sec_len = 1 + c->index_size + 1 + c->own_slice;
+            HIP_TRY(c, hipMemcpyAsync(sec + c->dict_sec_off, hdr, 1 + c->index_size, hipMemcpyHostToDevice, s));
+        }
+    } else {
+        c->dict_sec_off = 9; c->dict_sec_len = c->own_slice;
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->nuniq = dict_size > 1 ? std::max<uint64_t>(real, 1) : 0;
+    c->dict_done = true;
+    c->stats_done = false; c->p2_done = false;
     return ZDW_OK;
 }
 

@@ -114,7 +114,16 @@ void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, 
                            uint64_t *slots, uint64_t slot_mask, uint32_t max_entries, uint64_t *uniq_pos, uint32_t *uniq_len,
                            uint32_t id_cap, uint32_t trim, uint64_t hi, P1Status *st, uint32_t *ids_out /* optional */, hipStream_t s);
 void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
-                           const uint64_t *off_excl, uint64_t n, uint8_t *bytes, hipStream_t s);
+                           const uint32_t *order /* optional */, const uint64_t *off_excl, uint64_t n, uint8_t *bytes,
+                           uint32_t *lens_out /* optional */, hipStream_t s);
+// range-partitioned dictionary (multi-GPU)
+void launch_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                     const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys, hipStream_t s);
+void launch_partition_search(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                             const uint32_t *order, uint32_t lo, uint32_t hi, const uint64_t *splitters, uint32_t nsplit, uint32_t *bounds,
+                             hipStream_t s);
+void launch_owner_offsets(const uint32_t *ids, const uint32_t *id_off, uint32_t base, uint64_t n, uint32_t *out, hipStream_t s);
+void launch_scatter_offsets(const uint32_t *order, const uint32_t *offsets, uint64_t n, uint32_t *id_off, hipStream_t s);
 
 // pass 2
 void launch_pass2_size(const Pass2Args &a, hipStream_t s);

@@ -5,7 +5,11 @@ block's bytes must not depend on the number of shards, so three things are excha
 shard's pass 1:
 
   1. column ranges   min / max / seen per column     -> element-wise min / max / or   (all-reduce)
-  2. dictionary      every shard's unique strings    -> union on every shard          (all-gather-v)
+  2. dictionary      range-partitioned (default): every shard sorts its own unique strings, 16-byte prefix
+                     samples are all-gathered and give N-1 splitters, strings travel to the owner of their key
+                     range (all-to-all-v), the owner dedupes + sorts its range, range sizes are all-gathered and
+                     every string's offset travels back (all-to-all-v): the node-wide dictionary is sorted once.
+                     merge="allgather": every shard's unique strings -> union on every shard (all-gather-v);
                      each shard then sorts the same set, so offsets agree without a reverse map
   3. row halo        stored values of a shard's last row -> first row's "previous row" of the next shard
 
@@ -53,6 +57,27 @@ def concat_uniques(parts, skip=None):
         dev = parts[0][0].device
         return torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.uint8, device=dev)
     return torch.cat(lens), torch.cat(byts)
+
+
+def pick_splitters(samples, nparts):
+    """samples: every shard's [(k0, k1)] 16-byte prefix keys (any order, all shards concatenated; a shard
+    without strings contributes (2^64-1, 2^64-1)).  Returns nparts - 1 sorted splitters, the same on every
+    shard because they are a pure function of the multiset of samples."""
+    if nparts <= 1:
+        return []
+    srt = sorted(samples)
+    n = len(srt)
+    return [srt[min(n - 1, (j * n) // nparts)] for j in range(1, nparts)]
+
+
+def range_bases(slice_bytes):
+    """slice_bytes[r] = bytes of key range r.  Returns (dictionary offset of each range's first string, total
+    dictionary size): offset 0 is the origin byte (dictionary.cpp:96)."""
+    bases, at = [], 1
+    for b in slice_bytes:
+        bases.append(at)
+        at += b
+    return bases, at
 
 
 def chain_prev_rows(last_rows, nrows):
@@ -129,6 +154,144 @@ def encode_shards_local(encoders, device="cuda"):
     return blocks
 
 
+SAMPLES_PER_SHARD = 64
+
+
+def _split(t, counts):
+    out, at = [], 0
+    for c in counts:
+        out.append(t[at:at + c])
+        at += c
+    return out
+
+
+def encode_shards_partitioned_local(encoders, device="cuda"):
+    """encode_shards_local with the range-partitioned dictionary: the all-to-all steps are plain tensor
+    slicing here (all shards live in this process).  Returns per-shard capi.Block list; the blocks'
+    dict_section fields are the PIECES of the section (concatenate them in shard order)."""
+    from . import capi
+    n = len(encoders)
+    p1s = []
+    for e in encoders:
+        rc, p1 = e.pass1()
+        if rc:
+            raise capi.ZdwError(rc, "pass 1 failed on a shard")
+        p1s.append(p1)
+    mn, mx, seen = merge_ranges([e.export_ranges() for e in encoders])
+    for e in encoders:
+        e.import_ranges(mn, mx, seen)
+    samples = []
+    for e in encoders:
+        e.sort_uniques()
+        samples += e.sample_keys(SAMPLES_PER_SHARD)
+    splitters = pick_splitters(samples, n)
+    sent = []          # per shard: (counts, nbytes, lens tensor, bytes tensor)
+    for e in encoders:
+        counts, nb, d_lens, d_bytes = e.partition(splitters)
+        lens = _wrap(d_lens, sum(counts) * 4, "<i4", device).clone()
+        byts = _wrap(d_bytes, sum(nb), "|u1", device).clone()
+        _torch_done()
+        sent.append((counts, nb, _split(lens, counts), _split(byts, nb)))
+    slices = []
+    for r, e in enumerate(encoders):        # owner r receives part r of every shard
+        lens = torch.cat([sent[q][2][r] for q in range(n)]) if n else None
+        byts = torch.cat([sent[q][3][r] for q in range(n)])
+        _torch_done()
+        slices.append(e.owner_build(lens.data_ptr() if lens.numel() else 0, byts.data_ptr() if byts.numel() else 0, lens.numel(), byts.numel()))
+    bases, total = range_bases(slices)
+    replies = []
+    for r, e in enumerate(encoders):
+        cnt = sum(sent[q][0][r] for q in range(n))
+        offs = _wrap(e.owner_offsets(bases[r]), cnt * 4, "<i4", device).clone()
+        _torch_done()
+        replies.append(_split(offs, [sent[q][0][r] for q in range(n)]))
+    for q, e in enumerate(encoders):        # shard q gets back, range by range, the offsets of what it sent
+        mine = torch.cat([replies[r][q] for r in range(n)])
+        _torch_done()
+        e.set_offsets(mine.data_ptr() if mine.numel() else 0, mine.numel(), total, q == 0)
+    prev = chain_prev_rows([e.last_row() for e in encoders], [p.num_rows for p in p1s])
+    blocks = []
+    for i, e in enumerate(encoders):
+        e.set_prev_row(prev[i])
+        sec, _ = e.dict_section()
+        cs, cb = e.stats()
+        rows = e.pass2()
+        blocks.append(capi.Block(p1s[i].num_rows, p1s[i].longest_line, True, sec, cs, cb, rows, p1s[i]))
+    return blocks
+
+
+def _staged(t, group):
+    """gloo moves CPU tensors only for all-to-all; RCCL takes device tensors as they are"""
+    import torch.distributed as dist
+    return t.cpu() if dist.get_backend(group) == "gloo" and t.is_cuda else t
+
+
+def alltoallv(t, send_counts, recv_counts, group=None):
+    """1-D all-to-all-v: t = concatenation of the pieces for ranks 0..N-1 (send_counts elements each)."""
+    import torch.distributed as dist
+    dev = t.device
+    src = _staged(t.contiguous(), group)
+    out = torch.empty(int(sum(recv_counts)), dtype=t.dtype, device=src.device)
+    dist.all_to_all_single(out, src, output_split_sizes=[int(x) for x in recv_counts], input_split_sizes=[int(x) for x in send_counts], group=group)
+    return out.to(dev)
+
+
+def exchange_counts(vals, device, group=None):
+    """vals[r] = a number for rank r.  Returns what every rank has for me: got[q] = rank q's vals[me]."""
+    import torch.distributed as dist
+    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    src = _staged(t, group)
+    out = torch.empty_like(src)
+    dist.all_to_all_single(out, src, group=group)
+    return [int(x) for x in out.cpu().tolist()]
+
+
+def allgather_i64(vals, device, group=None):
+    """every rank's list of int64 (same length on all ranks), as a list of lists"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t, group=group)
+    return [[int(x) for x in o.cpu().tolist()] for o in outs]
+
+
+def _u64_to_i64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _i64_to_u64(v):
+    return v + (1 << 64) if v < 0 else v
+
+
+def partitioned_dictionary(enc, rank, world, device, group=None):
+    """The dictionary steps of one rank with the range-partitioned dictionary (after the range exchange)."""
+    enc.sort_uniques()
+    mine = enc.sample_keys(SAMPLES_PER_SHARD)
+    flat = [_u64_to_i64(w) for k in mine for w in k]
+    allk = allgather_i64(flat, device, group=group)
+    samples = [(_i64_to_u64(a[2 * i]), _i64_to_u64(a[2 * i + 1])) for a in allk for i in range(len(a) // 2)]
+    splitters = pick_splitters(samples, world)
+    counts, nb, d_lens, d_bytes = enc.partition(splitters)
+    lens = _wrap(d_lens, sum(counts) * 4, "<i4", device)
+    byts = _wrap(d_bytes, sum(nb), "|u1", device)
+    _torch_done()
+    rcounts = exchange_counts(counts, device, group=group)
+    rbytes = exchange_counts(nb, device, group=group)
+    got_lens = alltoallv(lens, counts, rcounts, group=group)
+    got_byts = alltoallv(byts, nb, rbytes, group=group)
+    _torch_done()
+    slice_bytes = enc.owner_build(got_lens.data_ptr() if got_lens.numel() else 0, got_byts.data_ptr() if got_byts.numel() else 0,
+                                  got_lens.numel(), got_byts.numel())
+    slices = [a[0] for a in allgather_i64([slice_bytes], device, group=group)]
+    bases, total = range_bases(slices)
+    offs = _wrap(enc.owner_offsets(bases[rank]), sum(rcounts) * 4, "<i4", device)
+    _torch_done()
+    back = alltoallv(offs, rcounts, counts, group=group)
+    _torch_done()
+    enc.set_offsets(back.data_ptr() if back.numel() else 0, back.numel(), total, rank == 0)
+
+
 def allreduce_ranges(mn, mx, seen, device, group=None):
     """RCCL/gloo form of merge_ranges."""
     import torch.distributed as dist
@@ -179,9 +342,14 @@ def exchange_prev_row(last_row, nrows, rank, world, device, group=None):
     return chain_prev_rows(rows, counts)[rank]
 
 
-def encode_shard_dist(enc, rank, world, group=None, fetch=False):
+def encode_shard_dist(enc, rank, world, group=None, fetch=False, merge=None):
     """One rank's part of the block.  Returns (num_rows, dict_section_len, rows_len) with the outputs
-    left in HBM, or host copies when fetch=True."""
+    left in HBM, or host copies when fetch=True.  merge: "partition" (range-partitioned dictionary: this
+    rank's dict section is the piece it owns) or "allgather" (every rank holds the whole dictionary);
+    default from ZDW_SHARD_MERGE, else "partition"."""
+    import os
+    if merge is None:
+        merge = os.environ.get("ZDW_SHARD_MERGE", "partition")
     from . import capi
     device = "cuda:%d" % torch.cuda.current_device()
     rc, p1 = enc.pass1()
@@ -189,11 +357,14 @@ def encode_shard_dist(enc, rank, world, group=None, fetch=False):
         raise capi.ZdwError(rc, "pass 1 failed on rank %d" % rank)
     mn, mx, seen = allreduce_ranges(*enc.export_ranges(), device=device, group=group)
     enc.import_ranges(mn, mx, seen)
-    lens, byts = export_uniques_tensors(enc, device)
-    olens, obyts = allgather_uniques(lens, byts, rank, world, group=group)
-    _torch_done()
-    if olens.numel():
-        enc.import_uniques(olens.data_ptr(), obyts.data_ptr(), olens.numel(), obyts.numel())
+    if merge == "partition":
+        partitioned_dictionary(enc, rank, world, device, group=group)
+    else:
+        lens, byts = export_uniques_tensors(enc, device)
+        olens, obyts = allgather_uniques(lens, byts, rank, world, group=group)
+        _torch_done()
+        if olens.numel():
+            enc.import_uniques(olens.data_ptr(), obyts.data_ptr(), olens.numel(), obyts.numel())
     prev = exchange_prev_row(enc.last_row(), p1.num_rows, rank, world, device, group=group)
     enc.set_prev_row(prev)
     if fetch:
