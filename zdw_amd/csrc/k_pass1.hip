@@ -239,7 +239,9 @@ void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_
                              uint32_t *span_starts, P1Status *st, hipStream_t s)
 {
     if (!nspans) return;
-    const uint32_t grid = nspans < 256u * 32u ? nspans : 256u * 32u;
+    uint32_t cap = 256u * 24u;
+    if (const char *e = getenv("ZDW_SCAN_GRID")) cap = (uint32_t)atoi(e);      // tuning experiments
+    const uint32_t grid = nspans < cap ? nspans : cap;
     hipLaunchKernelGGL(k_count_row_starts, dim3(grid), dim3(64), 0, s, in, n, lo, hi, span0, nspans, span_starts, st);
 }
 
