@@ -70,8 +70,9 @@ def pmc_traffic(kernel, nbytes):
             d = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
-        if abs(d.get("input_bytes", 0) - nbytes) <= 0.02 * nbytes and kernel in d.get("kernels", {}):
-            best = (d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.basename(f))
+        hit = [k for k in d.get("kernels", {}) if kernel and kernel in k]
+        if abs(d.get("input_bytes", 0) - nbytes) <= 0.02 * nbytes and hit:
+            best = (d["kernels"][hit[0]]["hbm_bytes_per_launch"], os.path.basename(f))
     return best if best else (None, None)
 
 
@@ -172,7 +173,7 @@ def main():
         dom_ms = per[dom]
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         b_alg = 2 * nbytes + out_local
-        traffic, traffic_note = pmc_traffic({"pass1": "zdw::k_pass1", "scan_rows": "zdw::k_count_row_starts",
+        traffic, traffic_note = pmc_traffic({"pass1": "zdw::k_pass1<true>", "scan_rows": "zdw::k_count_row_starts",
                                              "pass2_emit": "zdw::k_pass2_emit_cols", "pass2_size": "zdw::k_pass2_size_cols"}.get(dom), nbytes)
         res = {
             "metric": "TSV->ZDW encode throughput (input bytes / wall time, input resident in HBM, raw .zdw left in HBM)",
