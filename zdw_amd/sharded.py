@@ -273,8 +273,8 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
     samples = [(_i64_to_u64(a[2 * i]), _i64_to_u64(a[2 * i + 1])) for a in allk for i in range(len(a) // 2)]
     splitters = pick_splitters(samples, world)
     counts, nb, d_lens, d_bytes = enc.partition(splitters)
-    lens = _wrap(d_lens, sum(counts) * 4, "<i4", device)
-    byts = _wrap(d_bytes, sum(nb), "|u1", device)
+    lens = _wrap(d_lens, sum(counts) * 4, "<i4", device).clone()      # torch-owned copies: the collectives work on memory torch allocated
+    byts = _wrap(d_bytes, sum(nb), "|u1", device).clone()
     _torch_done()
     rcounts = exchange_counts(counts, device, group=group)
     rbytes = exchange_counts(nb, device, group=group)
@@ -285,7 +285,7 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
                                   got_lens.numel(), got_byts.numel())
     slices = [a[0] for a in allgather_i64([slice_bytes], device, group=group)]
     bases, total = range_bases(slices)
-    offs = _wrap(enc.owner_offsets(bases[rank]), sum(rcounts) * 4, "<i4", device)
+    offs = _wrap(enc.owner_offsets(bases[rank]), sum(rcounts) * 4, "<i4", device).clone()
     _torch_done()
     back = alltoallv(offs, rcounts, counts, group=group)
     _torch_done()
