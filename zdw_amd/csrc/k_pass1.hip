@@ -373,16 +373,14 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 w.key = 1; w.s0 = w.s1 = w.s2 = 0;
                 if (pending) w = load_slot(slot);
                 const bool same = pending && w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len;
-                const uint32_t nid = (a.debug_skip & 16u) ? ((uint32_t)i & 0xfffffu) : alloc_ids(ws.ids, pending && !same && w.key == 0, a.st, ID_CHUNK);
+                const uint32_t nid = alloc_ids(ws.ids, pending && !same && w.key == 0, a.st, ID_CHUNK);
                 if (!pending) continue;
                 if (same) {
                     id = (uint32_t)w.key; pending = false;
                 } else if (w.key == 0) {
                     if (nid >= a.id_cap) { a.st->overflow = 1; }
                     else {
-                        const uint64_t old = (a.debug_skip & 8u)
-                            ? claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), 0u, ws.vbase + fs, len, a.uniq_pos, a.uniq_len, c0, c1, c2)
-                            : claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, ws.vbase + fs, len, a.uniq_pos, a.uniq_len, c0, c1, c2);
+                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, ws.vbase + fs, len, a.uniq_pos, a.uniq_len, c0, c1, c2);
                         if (old == 0) { is_new = true; id = nid + 1; } else slow = true;          // lost the race: general form
                     }
                     pending = false;

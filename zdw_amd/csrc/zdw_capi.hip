@@ -671,7 +671,6 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         HIP_TRY(c, hipStreamSynchronize(s));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));
-        if (getenv("ZDW_DEBUG_SKIP")) fprintf(stderr, "[zdw] pass 1: entries=%u ids=%u general-form fields=%u\n", st.entries, st.id_next, st.pad);
         if (st.nul_seen == 2) return fail(c, ZDW_UNKNOWN_ERROR, "a single field of 1 GiB or more is not supported");
         if (!st.overflow) break;
         nslots <<= 4;                       // table too small for this block's uniques: grow and redo the pass
