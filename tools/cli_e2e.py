@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""End-to-end time of the convertDWfile binary on a synthetic table written to local disk (page-cache warm),
+with the compressor child replaced by `cat` and with real gzip.   python tools/cli_e2e.py --gb 1"""
+import argparse, os, shutil, stat, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gb", type=float, default=1.0)
+    args = ap.parse_args()
+    import torch
+    from zdw_amd import build, synth
+    table = synth.DeviceTable(ncols=200, device="cuda:0")
+    rows = table.rows_for_bytes(args.gb * 1e9)
+    buf, nbytes = table.generate(0, rows)
+    d = tempfile.mkdtemp(prefix="zdwcli_")
+    try:
+        with open(os.path.join(d, "t.sql"), "wb") as f:
+            f.write(buf[:nbytes].cpu().numpy().tobytes())
+        with open(os.path.join(d, "t.desc.sql"), "wb") as f:
+            f.write(table.desc)
+        del buf
+        torch.cuda.empty_cache()
+        shim = os.path.join(d, "shim"); os.makedirs(shim)
+        p = os.path.join(shim, "gzip")
+        with open(p, "w") as f:
+            f.write("#!/bin/sh\nexec cat\n")
+        os.chmod(p, os.stat(p).st_mode | stat.S_IXUSR)
+        for label, path in (("cat", shim + os.pathsep + os.environ["PATH"]), ("gzip", os.environ["PATH"])):
+            env = dict(os.environ, PATH=path)
+            t0 = time.perf_counter()
+            r = subprocess.run([build.CLI_EXE, "-q", os.path.join(d, "t.sql")], env=env)
+            dt = time.perf_counter() - t0
+            out = os.path.getsize(os.path.join(d, "t.zdw.gz"))
+            print("%s: rc=%d  %.2f s  %.1f MB/s of input  (%d bytes in, %d out)" % (label, r.returncode, dt, nbytes / 1e6 / dt, nbytes, out))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -170,12 +170,13 @@ void launch_find_effective_end(const uint8_t *in, uint64_t n, uint64_t lo, uint6
 // and the wave adds up once per span.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restrict__ in, uint64_t n, uint64_t lo, uint64_t hi,
-                                                          uint64_t span0, uint32_t nspans, uint32_t *__restrict__ span_starts,
-                                                          P1Status *st)
+                                                          uint64_t span0, uint32_t nspans, uint32_t span_shift,
+                                                          uint32_t *__restrict__ span_starts, P1Status *st)
 {
+    const uint64_t SPAN_BYTES = 1ull << span_shift;
     const uint32_t lane = lane_id();
     for (uint32_t si = blockIdx.x; si < nspans; si += gridDim.x) {
-        const uint64_t s0 = (span0 + si) * (uint64_t)SPAN_BYTES;
+        const uint64_t s0 = (span0 + si) << span_shift;
         const uint64_t ss = s0 > lo ? s0 : lo;
         const uint64_t se = s0 + SPAN_BYTES < hi ? s0 + SPAN_BYTES : hi;
         uint32_t mine = 0, nul = 0;
@@ -235,14 +236,14 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
     }
 }
 
-void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t hi, uint64_t span0, uint32_t nspans,
+void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t hi, uint64_t span0, uint32_t nspans, uint32_t span_shift,
                              uint32_t *span_starts, P1Status *st, hipStream_t s)
 {
     if (!nspans) return;
     uint32_t cap = 256u * 24u;
     if (const char *e = getenv("ZDW_SCAN_GRID")) cap = (uint32_t)atoi(e);      // tuning experiments
     const uint32_t grid = nspans < cap ? nspans : cap;
-    hipLaunchKernelGGL(k_count_row_starts, dim3(grid), dim3(64), 0, s, in, n, lo, hi, span0, nspans, span_starts, st);
+    hipLaunchKernelGGL(k_count_row_starts, dim3(grid), dim3(64), 0, s, in, n, lo, hi, span0, nspans, span_shift, span_starts, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
             new_entries = 0;
             if (seen_total >= a.max_entries) { if (lane == 0) a.st->overflow = 1; break; }
         }
-        const uint64_t s0 = (a.span0 + si) * (uint64_t)SPAN_BYTES;
+        const uint64_t s0 = (a.span0 + si) << a.span_shift, SPAN_BYTES = 1ull << a.span_shift;
         const uint64_t ss = s0 > a.lo ? s0 : a.lo;
         const uint64_t se = s0 + SPAN_BYTES < a.hi ? s0 + SPAN_BYTES : a.hi;
         const uint64_t pos0 = ss & ~(uint64_t)(WROUND - 1);

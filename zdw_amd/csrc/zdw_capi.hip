@@ -559,19 +559,24 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     HIP_TRY(c, c->d_scalar.ensure(64));
 
     uint64_t total_rows = 0;
-    uint32_t nspans = 0;
+    uint32_t nspans = 0, span_shift = SPAN_SHIFT_MIN;
     uint64_t span0 = 0;
     if (hi > lo) {
         StageScope ts(c, ZDW_STAGE_SCAN_ROWS);
-        span0 = lo / SPAN_BYTES;
-        nspans = (uint32_t)((hi + SPAN_BYTES - 1) / SPAN_BYTES - span0);
+        // span size by block size: visits cost a few microseconds of start-up latency each, so large blocks take
+        // 64 KiB spans; small ones keep 16 KiB so that there are enough spans for every resident wave
+        span_shift = SPAN_SHIFT_MIN;
+        while (span_shift < SPAN_SHIFT_MAX && ((hi - lo) >> (span_shift + 1)) >= 80000) ++span_shift;
+        if (const char *e = getenv("ZDW_SPAN_SHIFT")) span_shift = std::min(20u, std::max(12u, (uint32_t)atoi(e)));      // tests / tuning
+        span0 = lo >> span_shift;
+        nspans = (uint32_t)(((hi + (1ull << span_shift) - 1) >> span_shift) - span0);
         HIP_TRY(c, c->span_starts.ensure((nspans + 1ull) * 4));
         HIP_TRY(c, c->span_rowbase.ensure((nspans + 2ull) * 4));
         HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(nspans + 1ull)));
         P1Status init{};
         init.bad_row = 0xFFFFFFFFu; init.split_pos = c->n;
         HIP_TRY(c, hipMemcpyAsync(c->status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
-        launch_count_row_starts(c->d_in, c->n, lo, hi, span0, nspans, c->span_starts.as<uint32_t>(), c->status.as<P1Status>(), s);
+        launch_count_row_starts(c->d_in, c->n, lo, hi, span0, nspans, span_shift, c->span_starts.as<uint32_t>(), c->status.as<P1Status>(), s);
         launch_scan_u32_to_u32(c->span_starts.as<uint32_t>(), c->span_rowbase.as<uint32_t>(), nspans, c->scan_tmp.p,
                                c->d_scalar.as<uint64_t>(), s);
         HIP_TRY(c, hipMemcpyAsync(&total_rows, c->d_scalar.p, 8, hipMemcpyDeviceToHost, s));
@@ -631,7 +636,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         if (hi > lo && total_rows) {
             StageScope ts(c, ZDW_STAGE_PASS1);
             Pass1Args a{};
-            a.in = c->d_in; a.n = c->n; a.lo = lo; a.hi = hi; a.span0 = span0; a.nspans = nspans;
+            a.in = c->d_in; a.n = c->n; a.lo = lo; a.hi = hi; a.span0 = span0; a.nspans = nspans; a.span_shift = span_shift;
             a.span_rowbase = c->span_rowbase.as<uint32_t>();
             a.extra = c->extra.as<uint8_t>();
             a.ncols = c->ncols; a.col_kind = c->d_kind.as<uint8_t>(); a.col_recoff = c->d_recoff.as<uint32_t>();

@@ -39,6 +39,7 @@ struct Pass1Args {
     const uint8_t *in; uint64_t n;        // TSV image and its allocation size
     uint64_t lo, hi;                      // block start; effective end (last row terminator + 1)
     uint64_t span0; uint32_t nspans;      // spans [span0, span0 + nspans) cover [lo, hi)
+    uint32_t span_shift;                  // a span = 2^span_shift bytes
     const uint32_t *span_rowbase;         // exclusive scan of per-span row starts
     const uint8_t *extra;                 // imported strings (multi-GPU merge), NUL terminated
     uint32_t ncols;
@@ -79,7 +80,7 @@ struct Pass2Args {
 
 // ---- launchers (all asynchronous on `s`) ----
 void launch_find_effective_end(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t *d_out, hipStream_t s);
-void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t hi, uint64_t span0, uint32_t nspans,
+void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t hi, uint64_t span0, uint32_t nspans, uint32_t span_shift,
                              uint32_t *span_starts, P1Status *st, hipStream_t s);
 void launch_pass1(const Pass1Args &a, hipStream_t s);
 void launch_pass1_deferred(const Pass1Args &a, uint32_t count, hipStream_t s);
