@@ -76,6 +76,23 @@ def pmc_traffic(kernel, nbytes):
     return best if best else (None, None)
 
 
+def stream_copy_gbps(torch, src):
+    """Device-to-device copy of (up to) 4 GB of the input image: bytes read + bytes written per second."""
+    n = min(int(src.numel()), 4 << 30)
+    dst = torch.empty(n, dtype=src.dtype, device=src.device)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(src[:n])
+    best = 0.0
+    for _ in range(5):
+        a.record()
+        dst.copy_(src[:n])
+        b.record()
+        b.synchronize()
+        best = max(best, 2.0 * n / (a.elapsed_time(b) * 1e-3) / 1e9)
+    del dst
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,10 +163,13 @@ def main():
     enc.enable_timing(True)      # reset stage accumulators after warm-up
     fence()
     t0 = time.perf_counter()
+    step_ends = []
     for _ in range(args.steps):
         nrows, dict_len, rows_len = step()
+        step_ends.append(time.perf_counter())      # a step returns once its lengths are on the host: no extra sync
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted((b - a) * 1e3 for a, b in zip([t0] + step_ends[:-1], step_ends))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,7 +211,12 @@ def main():
                          "whole_encode": {"b_alg": int(b_alg), "achieved": round(b_alg / (ms * 1e-3) / 1e9, 1),
                                           "frac": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}},
             "stage_ms": per,
+            "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "min": round(step_ms[0], 3)},
         }
+        # what a plain streaming copy reaches on this box (quote the fraction of both peaks)
+        copy_gbps = stream_copy_gbps(torch, buf)
+        res["roofline"]["stream_copy"] = {"measured": round(copy_gbps, 1), "unit": "GB/s (read + write)",
+                                          "frac_of_it": round(achieved / copy_gbps, 4) if copy_gbps else None}
         if not args.no_cpu:
             # bounded sample: whole rows from the head of rank 0's table
             want = int(min(args.cpu_mb * 1e6, nbytes))

@@ -60,11 +60,18 @@ const char ConvertToZDW::ERR_CODE_TEXTS[ERR_CODE_COUNT][30] = {
 
 ConvertToZDW::ConvertToZDW(const bool quiet, const bool streaming)
     : compressor(GZIP), statusOutput(defaultStatusOutputCallback), bQuiet(quiet), bTrimTrailingSpaces(false),
-      bStreamingInput(streaming), device(-1)
+      bStreamingInput(streaming), device(-1), formatVersion(CONVERT_ZDW_CURRENT_VERSION)
 {
 }
 
 ConvertToZDW::~ConvertToZDW() {}
+
+bool ConvertToZDW::setFormatVersion(int version)
+{
+    if (version < 9 || version > CONVERT_ZDW_CURRENT_VERSION) return false;
+    formatVersion = version;
+    return true;
+}
 
 void ConvertToZDW::setBlockSplits(const std::vector<uint32_t> &rows, const std::vector<uint32_t> &fields)
 {
@@ -219,6 +226,18 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         return BAD_METADATA_PARAM;
     }
     const size_t numColumns = schema.names.size();
+    // what an older format version cannot hold
+    if (formatVersion < 11 && !metadata.empty()) {
+        statusOutput(ERROR, "File metadata needs format version 11 (writing version %d)\n", formatVersion);
+        return BAD_METADATA_PARAM;
+    }
+    if (formatVersion < 10) {
+        for (size_t c = 0; c < numColumns; ++c)
+            if (schema.types[c] == 17 || schema.types[c] == 18) {      // mediumtext, longtext
+                statusOutput(ERROR, "Column %s needs format version 10 (writing version %d)\n", schema.names[c].c_str(), formatVersion);
+                return BAD_PARAMETER;
+            }
+    }
 
     // ---- output names: <dir>/<base>.zdw<ext>, written as <base>.creating.zdw<ext> first ----
     std::string base;
@@ -270,8 +289,8 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
     }
 
     // ---- file header ----
-    bool ok = out.le(CONVERT_ZDW_CURRENT_VERSION, 2);
-    {
+    bool ok = out.le(formatVersion, 2);
+    if (formatVersion >= 11) {
         uint64_t metaLen = 0;
         for (const auto &kv : metadata) metaLen += kv.first.size() + kv.second.size() + 2;
         ok = ok && out.le(metaLen, 4);

@@ -61,6 +61,11 @@ public:
     // (SURVEY.md Q9): block i holds rows[i] rows and had visited fields[i] fields of the next row.
     void setBlockSplits(const std::vector<uint32_t> &rows, const std::vector<uint32_t> &fields);
     void setDevice(int hipDevice) { device = hipDevice; }
+    // File format version to write: 11 (default), or 10 / 9 for readers that stop there (the JVM readers,
+    // format/.../ZDWHeader.scala:25-39).  Version 10 is version 11 without the header's metadata block
+    // (ConvertToZDW.cpp:673-694); version 9 is version 10 without the mediumtext / longtext column types.
+    // Returns false for any other number.
+    bool setFormatVersion(int version);
     // last GPU/library error text (empty when none)
     const std::string &lastLibraryError() const { return libError; }
 
@@ -85,6 +90,7 @@ private:
     bool bTrimTrailingSpaces;
     const bool bStreamingInput;
     int device;
+    int formatVersion;
     std::vector<uint32_t> splitRows, splitFields;
     std::string libError;
 };

@@ -44,6 +44,8 @@ void usage(const char *executable)
           "\n"
           "\t--help     show this help\n"
           "\t--version  show the version number\n"
+          "\n"
+          "\t--format-version=<9|10|11>  (this build) write an older format version: 10 has no metadata block, 9 also no mediumtext/longtext\n"
           "Input files must have a .sql extension.\n"
           "\n",
           stdout);
@@ -81,7 +83,7 @@ static int runCommandLine(int argc, char *argv[])
     ConvertToZDW::Compressor compressor = ConvertToZDW::GZIP;
     const char *outputDir = NULL, *zArgs = NULL;
     std::map<std::string, std::string> metadata;
-    int files = 0;
+    int files = 0, formatVersion = ConvertToZDW::CONVERT_ZDW_CURRENT_VERSION;
 
     for (int i = 1; i < argc; ++i) {
         const char *a = argv[i];
@@ -129,6 +131,14 @@ static int runCommandLine(int argc, char *argv[])
                 break;
             }
             if (!strncmp(flag, "zargs=", 6)) { zArgs = flag + 6; break; }
+            if (!strncmp(flag, "format-version=", 15)) {
+                // not in the reference tool: write an older header for readers that stop at version 10 (or 9)
+                char *end = NULL;
+                const long ver = strtol(flag + 15, &end, 10);
+                if (end == flag + 15 || *end || ver < 9 || ver > ConvertToZDW::CONVERT_ZDW_CURRENT_VERSION) return badParam(program, a);
+                formatVersion = (int)ver;
+                break;
+            }
             usage(program);
             return badParam(program, a);
         }
@@ -146,6 +156,7 @@ static int runCommandLine(int argc, char *argv[])
         }
         char filestub[1024];
         ConvertToZDW convert(quiet, streaming);
+        convert.setFormatVersion(formatVersion);
         convert.compressor = compressor;
         if (trim) convert.trimTrailingSpaces();
         const ConvertToZDW::ERR_CODE res = convert.convertFile(argv[i], program, validate, filestub, outputDir, zArgs, metadata);

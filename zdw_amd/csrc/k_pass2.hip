@@ -154,12 +154,13 @@ __global__ __launch_bounds__(256) void k_pass2_size_cols(const Pass2Args a)
     const uint32_t nflag = (a.nused + 7) >> 3;
     const uint32_t nbatch = (a.nused + 63) >> 6;
     const uint32_t nchunks = (a.nrows + P2_R - 1) / P2_R;
+    const ColFacts f0 = col_facts(a, 64 * wv + lane);          // the wave's first batch is the same in every chunk
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t row0 = chunk * P2_R;
         const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
         for (uint32_t b = wv; b < nbatch; b += 4) {
             const uint32_t u = 64 * b + lane;
-            const ColFacts f = col_facts(a, u);
+            const ColFacts f = b == wv ? f0 : col_facts(a, u);
             uint64_t v[P2_R + 1];
             load_column(a, f, row0, rows, v);
 #pragma unroll
