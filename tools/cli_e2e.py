@@ -28,7 +28,7 @@ def main():
             f.write("#!/bin/sh\nexec cat\n")
         os.chmod(p, os.stat(p).st_mode | stat.S_IXUSR)
         for label, path in (("cat", shim + os.pathsep + os.environ["PATH"]), ("gzip", os.environ["PATH"])):
-            env = dict(os.environ, PATH=path)
+            env = dict(os.environ, PATH=path, ZDW_CLI_TIMING="1")
             t0 = time.perf_counter()
             r = subprocess.run([build.CLI_EXE, "-q", os.path.join(d, "t.sql")], env=env)
             dt = time.perf_counter() - t0

@@ -13,6 +13,7 @@
 
 #include "zdw_hip.h"
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -209,6 +210,31 @@ struct OutPipe {
     }
 };
 
+// ZDW_CLI_TIMING=1: wall time of the host-side phases of one file, on stderr
+struct PhaseClock {
+    const bool on = getenv("ZDW_CLI_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    std::vector<std::pair<const char *, double> > acc;
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+        for (auto &e : acc) if (!strcmp(e.first, what)) { e.second += ms; return; }
+        acc.push_back(std::make_pair(what, ms));
+    }
+    ~PhaseClock()
+    {
+        if (!on) return;
+        double tot = 0;
+        for (auto &e : acc) tot += e.second;
+        fprintf(stderr, "[zdw timing]");
+        for (auto &e : acc) fprintf(stderr, " %s=%.1fms", e.first, e.second);
+        fprintf(stderr, " total=%.1fms\n", tot);
+    }
+};
+
 struct CtxGuard {
     zdw_ctx *ctx = nullptr;
     ~CtxGuard() { if (ctx) zdw_ctx_destroy(ctx); }
@@ -249,6 +275,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
     const std::string finalName = base + ".zdw" + compressorExtension();
     const std::string tempName = base + ".creating.zdw" + compressorExtension();
 
+    PhaseClock clock;
     // ---- GPU context first: nothing is created on disk when no device is usable ----
     CtxGuard guard;
     {
@@ -267,6 +294,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         }
     }
     zdw_ctx *ctx = guard.ctx;
+    clock.mark("ctx_create");
     const unsigned char *image = hostImage ? hostImage->data() : reinterpret_cast<const unsigned char *>(mappedImage);
     {
         const int rc = zdw_set_input_host(ctx, image, imageLen);
@@ -277,6 +305,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         }
     }
 
+    clock.mark("input_to_gpu");
     std::string cmd = compressorCommand();
     if (zArgs) { cmd += " "; cmd += zArgs; }
     cmd += " > ";
@@ -334,6 +363,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
             hint.partial_fields = 0;
             if (!bQuiet) statusOutput(INFO, "\nDictionary too large for one block: retrying with %u rows\n", hint.max_rows);
         }
+        clock.mark("pass1+dict");
         if (rc == ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW) {
             statusOutput(ERROR, "\nRow %u had the problem\n", p1.bad_row);
             res = WRONG_NUM_OF_COLUMNS_ON_A_ROW;
@@ -361,6 +391,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
                              static_cast<unsigned>(dictSize), static_cast<unsigned>(p1.dict_entries), indexSize ? indexSize : 1);
             }
             ok = ok && out.put(section, sectionLen);
+            clock.mark("write_dict");
             uint32_t used = 0;
             rc = zdw_block_stats(ctx, colSize.data(), colBase.data(), &used);
             if (rc == ZDW_OK) {
@@ -369,7 +400,9 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
                 if (!bQuiet) statusOutput(INFO, "\nWriting rows\n");
                 const uint8_t *rowBytes = NULL; uint64_t rowLen = 0;
                 rc = zdw_block_pass2(ctx, &rowBytes, &rowLen);
+                clock.mark("stats+pass2");
                 if (rc == ZDW_OK) ok = ok && out.put(rowBytes, rowLen);
+                clock.mark("write_rows");
             }
         }
         if (rc != ZDW_OK) {
@@ -386,6 +419,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
 
     const int childStatus = pclose(out.f);
     out.f = NULL;
+    clock.mark("compressor_drain");
     if (res == OK && (!ok || childStatus != 0)) {
         statusOutput(ERROR, "Writing through '%s' failed\n", cmd.c_str());
         res = FILE_CREATION_ERR;
