@@ -13,6 +13,8 @@
 #include "zdw_dict_dev.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace zdw {
 
@@ -50,20 +52,37 @@ __global__ __launch_bounds__(64) void k_radix_hist(const uint64_t *__restrict__ 
 __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                        const uint32_t *__restrict__ dsrc, uint64_t *__restrict__ keys_out,
                                                        uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
-                                                       const uint32_t *__restrict__ offsets, uint32_t nblocks)
+                                                       const uint32_t *__restrict__ rows, const uint32_t *__restrict__ row_tot,
+                                                       uint32_t nblocks)
 {
+    // One wave per block: its LDS operations execute in program order, so the running offsets need no
+    // workgroup barrier (a barrier would also wait for the scattered stores of the step before).
     __shared__ uint32_t offs[256];
     const uint32_t lane = threadIdx.x;
-    for (uint32_t d = lane; d < 256; d += 64) offs[d] = offsets[d * nblocks + blockIdx.x];
-    __syncthreads();
+    {   // where digit d of this block goes = elements with smaller digits + elements of digit d in earlier blocks
+        const uint32_t t0 = row_tot[4 * lane], t1 = row_tot[4 * lane + 1], t2 = row_tot[4 * lane + 2], t3 = row_tot[4 * lane + 3];
+        uint32_t tot;
+        const uint32_t before = wave_excl_sum(t0 + t1 + t2 + t3, lane, tot);
+        offs[4 * lane] = before + rows[(4 * lane) * nblocks + blockIdx.x];
+        offs[4 * lane + 1] = before + t0 + rows[(4 * lane + 1) * nblocks + blockIdx.x];
+        offs[4 * lane + 2] = before + t0 + t1 + rows[(4 * lane + 2) * nblocks + blockIdx.x];
+        offs[4 * lane + 3] = before + t0 + t1 + t2 + rows[(4 * lane + 3) * nblocks + blockIdx.x];
+    }
+    __builtin_amdgcn_wave_barrier();
     const uint32_t beg = blockIdx.x * SORT_CHUNK;
     const uint32_t end = beg + SORT_CHUNK < n ? beg + SORT_CHUNK : n;
+    // the next step's pair (and its digit source) is requested before this step's is ranked
+    uint32_t i = beg + lane;
+    bool valid = i < end;
+    uint64_t key = valid ? keys_in[i] : 0ull;
+    uint32_t val = valid ? vals_in[i] : 0u;
+    uint32_t dw = (valid && dsrc) ? dsrc[val] : 0u;
     for (uint32_t b = beg; b < end; b += 64) {
-        const uint32_t i = b + lane;
-        const bool valid = i < end;
-        const uint64_t key = valid ? keys_in[i] : 0ull;
-        const uint32_t val = valid ? vals_in[i] : 0u;
-        const uint32_t digit = valid ? (dsrc ? (dsrc[val] >> shift) & 255u : (uint32_t)(key >> shift) & 255u) : 0u;
+        const uint32_t i2 = b + 64 + lane;
+        const bool valid2 = i2 < end;
+        const uint64_t key2 = valid2 ? keys_in[i2] : 0ull;
+        const uint32_t val2 = valid2 ? vals_in[i2] : 0u;
+        const uint32_t digit = valid ? (dsrc ? (dw >> shift) & 255u : (uint32_t)(key >> shift) & 255u) : 0u;
         uint64_t mm = __ballot(valid);                 // lanes holding the same digit as this lane
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
@@ -73,11 +92,44 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict
         }
         uint32_t dst = 0;
         if (valid) dst = offs[digit] + popc64(mm & mask_lt((int)lane));
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         if (valid && lane == (uint32_t)highest_bit(mm)) offs[digit] += popc64(mm);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         if (valid) { keys_out[dst] = key; vals_out[dst] = val; }
+        const uint32_t dw2 = (valid2 && dsrc) ? dsrc[val2] : 0u;
+        key = key2; val = val2; valid = valid2; dw = dw2;
     }
+}
+
+// one block per digit: exclusive scan, in place, of the digit's per-block counts; the digit's total goes to row_tot.
+// A thread owns up to 16 consecutive counts, all requested before any is used (one latency per 4096 counts).
+__global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ row_tot)
+{
+    constexpr uint32_t K = 16;
+    __shared__ uint32_t wsum[4];
+    uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < nblocks; b += 256 * K) {
+        const uint32_t i0 = b + threadIdx.x * K;
+        uint32_t x[K], v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) { x[k] = i0 + k < nblocks ? row[i0 + k] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) v += x[k];
+        uint32_t wtot;
+        const uint32_t ex = wave_excl_sum(v, lane, wtot);
+        if (lane == 0) wsum[wv] = wtot;
+        __syncthreads();
+        uint32_t run = carry + ex, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) { const uint32_t t = wsum[w]; if (w < wv) run += t; all += t; }
+#pragma unroll
+        for (uint32_t k = 0; k < K; ++k) { if (i0 + k < nblocks) row[i0 + k] = run; run += x[k]; }
+        carry += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_tot[blockIdx.x] = carry;
 }
 
 // sorts by bits [bit_lo, bit_hi) of the key (or of dsrc[value]); result lands in (*keys, *vals) (pointers are swapped as needed)
@@ -87,10 +139,9 @@ static void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **keys_a
     const uint32_t nb = sort_blocks(n);
     for (uint32_t shift = bit_lo; shift < bit_hi; shift += 8) {
         hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, n, shift, hist, nb);
-        // exclusive scan in place is not used: scan into the second half of the histogram buffer
-        uint32_t *offsets = hist + (size_t)256 * nb + 1;
-        launch_scan_u32_to_u32(hist, offsets, (uint64_t)256 * nb, scan_tmp, nullptr, s);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, *keys_alt, *vals_alt, n, shift, offsets, nb);
+        uint32_t *row_tot = hist + (size_t)256 * nb;
+        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, hist, nb, row_tot);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, *keys_alt, *vals_alt, n, shift, hist, row_tot, nb);
         uint64_t *tk = *keys; *keys = *keys_alt; *keys_alt = tk;
         uint32_t *tv = *vals; *vals = *vals_alt; *vals_alt = tv;
     }
@@ -188,6 +239,7 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     uint32_t *group_next = tmp + n;
     for (uint32_t depth = 0; m > 1; ++depth) {
         ++rounds;
+        if (getenv("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] depth %u: m = %u of n = %u\n", depth, m, n);
         const uint32_t gb = (m + 255) / 256;
         uint64_t *keys = b.key_a, *keys_alt = b.key_b;
         uint32_t *vals = b.val_a, *vals_alt = b.val_b;

@@ -119,14 +119,6 @@ __device__ __forceinline__ void classify16(const uint8_t *in, uint64_t lo, uint6
     }
 }
 
-__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane, uint32_t &total)
-{
-    (void)lane;
-    const uint32_t inc = wave_incl_sum(v);
-    total = lane_value(inc, 63);
-    return inc - v;
-}
-
 // ------------------------------------------------------------------------------------------
 // effective end of the image = last row terminator + 1 (an unterminated tail is dropped,
 // getnextrow.cpp:67-69).  One wave walks backwards; normally the first round finds it.

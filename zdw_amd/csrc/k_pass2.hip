@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
 // ------------------------------------------------------------------------------------------
 // Lane = column, so "the row above" is the value the lane loaded one step earlier: the record matrix is
 // read once, and all loads of a chunk (P2_R + 1 per lane) are in flight together.
-constexpr uint32_t P2_R = 16;                    // rows per chunk
+constexpr uint32_t P2_R_SIZE = 16;              // rows per chunk, size kernel
+constexpr uint32_t P2_R_MAX = 16;               // rows per chunk, emit kernel: 16 or 8 (chosen at launch)
 constexpr uint32_t P2_LDS_BUDGET = 40 * 1024;    // output image of one row chunk (emit)
 
 struct ColFacts { uint32_t off; uint32_t sz; bool text; bool ok; };
@@ -137,6 +138,7 @@ __device__ __forceinline__ uint64_t raw_at(const uint8_t *rowp, const ColFacts &
     return f.text ? (x & 0xffffffffull) : x;
 }
 // raw values of column f for rows row0 - 1 .. row0 + rows - 1 in v[0 .. rows]; v[0] = 0 for the block's first row
+template <uint32_t P2_R>
 __device__ __forceinline__ void load_column(const Pass2Args &a, const ColFacts &f, uint32_t row0, uint32_t rows, uint64_t (&v)[P2_R + 1])
 {
     const uint8_t *rp = a.rec + (uint64_t)row0 * a.rec_stride;
@@ -145,11 +147,49 @@ __device__ __forceinline__ void load_column(const Pass2Args &a, const ColFacts &
     for (uint32_t r = 0; r < P2_R; ++r) v[r + 1] = (f.ok && r < rows) ? raw_at(rp + (uint64_t)r * a.rec_stride, f) : 0ull;
 }
 
+// ---- staged form: the workgroup streams the chunk's records (rows row0 - 1 .. row0 + rows - 1, one contiguous
+// piece of the matrix) into LDS with coalesced 16-byte loads and the lanes pick their columns from there.  Lane =
+// column loads straight from HBM reach half the rate of a streaming read (8 bytes per lane at a 4..8-byte pitch).
+constexpr uint32_t P2_STAGE_BUDGET = 48 * 1024;   // staged when (P2_R + 1) rows of records fit in this much LDS
+
+__host__ __device__ inline uint32_t p2_stage_bytes(uint32_t rows, uint32_t rec_stride) { return (rows + 1) * rec_stride + 32u; }
+
+// returns the LDS offset (inside `stage`) of row row0's record; callers __syncthreads() before reading
+__device__ __forceinline__ uint32_t stage_chunk(const Pass2Args &a, uint8_t *stage, uint32_t row0, uint32_t rows)
+{
+    const uint32_t first = row0 ? row0 - 1 : 0;
+    const uint8_t *src = a.rec + (uint64_t)first * a.rec_stride;
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
+    const uint32_t nbytes = mis + (row0 + rows - first) * a.rec_stride;        // from the aligned start
+    const uint8_t *src16 = src - mis;
+    for (uint32_t o = threadIdx.x * 16u; o < nbytes; o += 256u * 16u)
+        *reinterpret_cast<uint4 *>(stage + o) = *reinterpret_cast<const uint4 *>(src16 + o);     // may run up to 15 bytes past the piece: the matrix has slack
+    return mis + (row0 - first) * a.rec_stride;
+}
+// a record field from the staged copy (fields sit at multiples of 4)
+__device__ __forceinline__ uint64_t staged_at(const uint8_t *stage, uint32_t at, const ColFacts &f)
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(stage + at + f.off);
+    const uint32_t lo = q[0], hi = q[1];
+    return f.text ? (uint64_t)lo : (((uint64_t)hi << 32) | lo);
+}
+template <uint32_t P2_R>
+__device__ __forceinline__ void load_column_staged(const uint8_t *stage, uint32_t at0, uint32_t stride, const ColFacts &f, uint32_t row0, uint32_t rows,
+                                                   uint64_t (&v)[P2_R + 1])
+{
+    v[0] = (f.ok && row0) ? staged_at(stage, at0 - stride, f) : 0ull;
+#pragma unroll
+    for (uint32_t r = 0; r < P2_R; ++r) v[r + 1] = (f.ok && r < rows) ? staged_at(stage, at0 + r * stride, f) : 0ull;
+}
+
 // row lengths + for every (row, 64-column batch) the value bytes the batches before it take in that row
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_pass2_size_cols(const Pass2Args a)
 {
+    constexpr uint32_t P2_R = P2_R_SIZE;
     extern __shared__ __attribute__((aligned(16))) uint8_t p2s_lds[];
     uint16_t *tot = reinterpret_cast<uint16_t *>(p2s_lds);          // [P2_R][nbatch]
+    uint8_t *stage = p2s_lds + ((P2_R * ((a.nused + 63) >> 6) * 2u + 15u) & ~15u);
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nflag = (a.nused + 7) >> 3;
     const uint32_t nbatch = (a.nused + 63) >> 6;
@@ -158,11 +198,14 @@ __global__ __launch_bounds__(256) void k_pass2_size_cols(const Pass2Args a)
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t row0 = chunk * P2_R;
         const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
+        uint32_t at0 = 0;
+        if (STAGED) { at0 = stage_chunk(a, stage, row0, rows); __syncthreads(); }
         for (uint32_t b = wv; b < nbatch; b += 4) {
             const uint32_t u = 64 * b + lane;
             const ColFacts f = b == wv ? f0 : col_facts(a, u);
             uint64_t v[P2_R + 1];
-            load_column(a, f, row0, rows, v);
+            if (STAGED) load_column_staged<P2_R>(stage, at0, a.rec_stride, f, row0, rows, v);
+            else load_column<P2_R>(a, f, row0, rows, v);
 #pragma unroll
             for (uint32_t r = 0; r < P2_R; ++r) {
                 bool flag = v[r + 1] != v[r];
@@ -192,9 +235,12 @@ struct __attribute__((packed)) PackedL16 { uint16_t v; };
 
 // emit: the workgroup assembles P2_R consecutive rows in LDS (at the byte offset that makes LDS and global
 // 16-byte phases agree) and copies the image out with aligned vector stores
+template <bool STAGED, uint32_t P2_R>
 __global__ __launch_bounds__(256) void k_pass2_emit_cols(const Pass2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t p2_lds[];
+    uint8_t *stage = p2_lds + ((P2_R * a.out_row_max + 32u + 15u) & ~15u);
+
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nflag = (a.nused + 7) >> 3;
     const uint32_t nbatch = (a.nused + 63) >> 6;
@@ -205,11 +251,14 @@ __global__ __launch_bounds__(256) void k_pass2_emit_cols(const Pass2Args a)
         const uint64_t base = a.row_off[row0];
         const uint32_t nbytes = (uint32_t)(a.row_off[row0 + rows] - base);
         const uint32_t shift = (uint32_t)base & 15u;
+        uint32_t at0 = 0;
+        if (STAGED) { at0 = stage_chunk(a, stage, row0, rows); __syncthreads(); }
         for (uint32_t b = wv; b < nbatch; b += 4) {
             const uint32_t u = 64 * b + lane;
             const ColFacts f = col_facts(a, u);
             uint64_t v[P2_R + 1];
-            load_column(a, f, row0, rows, v);
+            if (STAGED) load_column_staged<P2_R>(stage, at0, a.rec_stride, f, row0, rows, v);
+            else load_column<P2_R>(a, f, row0, rows, v);
             // where each row's bytes of this batch begin in the image
             uint32_t my_at = 0;
             if (lane < rows) my_at = (uint32_t)(a.row_off[row0 + lane] - base) + shift;
@@ -276,27 +325,45 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
     if (!a.nrows) return;
     uint32_t g = 1;
     while (g < 64 && g < a.nused) g <<= 1;
-    if (g == 64 && P2_R * a.out_row_max + 32u <= P2_LDS_BUDGET && a.batch_pre) {
+    if (g == 64 && P2_R_MAX * a.out_row_max + 32u <= P2_LDS_BUDGET && a.batch_pre) {
         // wide schema: persistent grids sized to what is resident
         int dev = 0, cus = 256, occ = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const uint64_t want = ((uint64_t)a.nrows + P2_R - 1) / P2_R;
         const uint32_t nbatch = (a.nused + 63) / 64;
+        const bool direct = getenv("ZDW_P2_DIRECT") != nullptr;      // (the variables here: A/B measurements)
         if (!EMIT) {
-            const uint32_t lds = P2_R * nbatch * 2u + 16u;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pass2_size_cols, 256, lds) != hipSuccess || occ < 1) occ = 1;
+            const bool staged = !direct && p2_stage_bytes(P2_R_SIZE, a.rec_stride) <= P2_STAGE_BUDGET;
+            const uint64_t want = ((uint64_t)a.nrows + P2_R_SIZE - 1) / P2_R_SIZE;
+            const uint32_t lds = ((P2_R_SIZE * nbatch * 2u + 15u) & ~15u) + (staged ? p2_stage_bytes(P2_R_SIZE, a.rec_stride) : 0u);
+            const void *fn = staged ? (const void *)k_pass2_size_cols<true> : (const void *)k_pass2_size_cols<false>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
             uint32_t per_cu = std::min(6u, (uint32_t)occ);      // six workgroups per CU measured best (8: 1.36x the time)
-            if (const char *e = getenv("ZDW_P2_SIZE_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));   // tuning experiments
+            if (const char *e = getenv("ZDW_P2_SIZE_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
-            hipLaunchKernelGGL(k_pass2_size_cols, dim3(grid), dim3(256), lds, s, a);
+            if (staged) hipLaunchKernelGGL(k_pass2_size_cols<true>, dim3(grid), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL(k_pass2_size_cols<false>, dim3(grid), dim3(256), lds, s, a);
         } else {
-            const uint32_t lds = P2_R * a.out_row_max + 32u;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_pass2_emit_cols, 256, lds) != hipSuccess || occ < 1) occ = 1;
-            uint32_t per_cu = std::min(6u, (uint32_t)occ);
-            if (const char *e = getenv("ZDW_P2_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));   // tuning experiments
+            uint32_t R = 8;
+            if (const char *e = getenv("ZDW_P2_EMIT_ROWS")) R = atoi(e) == 16 ? 16u : 8u;
+            bool staged = !direct && p2_stage_bytes(R, a.rec_stride) <= P2_STAGE_BUDGET;
+            if (getenv("ZDW_P2_EMIT_DIRECT")) staged = false;
+            const uint64_t want = ((uint64_t)a.nrows + R - 1) / R;
+            const uint32_t lds = ((R * a.out_row_max + 32u + 15u) & ~15u) + (staged ? p2_stage_bytes(R, a.rec_stride) : 0u);
+            const void *fn = R == 16 ? (staged ? (const void *)k_pass2_emit_cols<true, 16> : (const void *)k_pass2_emit_cols<false, 16>)
+                                     : (staged ? (const void *)k_pass2_emit_cols<true, 8> : (const void *)k_pass2_emit_cols<false, 8>);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
+            // measured (10 GB x 200 columns): staged 8-row chunks 5 / 6 / 7 / 8 workgroups per CU = 5.5 / 4.9 / 4.5 / 6.7 ms
+            uint32_t per_cu = std::min(staged ? 7u : 6u, (uint32_t)occ);
+            if (const char *e = getenv("ZDW_P2_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
-            hipLaunchKernelGGL(k_pass2_emit_cols, dim3(grid), dim3(256), lds, s, a);
+            if (R == 16) {
+                if (staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_emit_cols<true, 16>), dim3(grid), dim3(256), lds, s, a);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_emit_cols<false, 16>), dim3(grid), dim3(256), lds, s, a);
+            } else {
+                if (staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_emit_cols<true, 8>), dim3(grid), dim3(256), lds, s, a);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_emit_cols<false, 8>), dim3(grid), dim3(256), lds, s, a);
+            }
         }
         return;
     }

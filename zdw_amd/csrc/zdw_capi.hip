@@ -94,6 +94,7 @@ struct zdw_ctx {
     DevBuf uniq_pos, uniq_len, key_a, key_b, val_a, val_b, order, group, active_a, active_b, flags, hist, lenp1, off_excl,
         slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
     uint64_t nuniq = 0, dict_size = 0, extra_bytes = 0;
+    uint32_t nids = 0;            // unique ids handed out in this block (holes included): entries of id_off
     uint32_t id_cap = 0;                   // capacity of uniq_pos / uniq_len (unique ids, holes included)
     // range-partitioned dictionary (multi-GPU): this shard as a requester ...
     DevBuf my_order, part_idx, part_keys, part_bounds, part_split, part_lens;
@@ -179,7 +180,7 @@ void reset_block(zdw_ctx *c)
 {
     c->p1_done = c->dict_done = c->stats_done = c->p2_done = false;
     c->uniques_sorted = c->own_built = false;
-    c->nrows = 0; c->nuniq = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
+    c->nrows = 0; c->nuniq = 0; c->nids = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
     c->have_prev = false;
 }
 
@@ -279,6 +280,7 @@ int ensure_dict(zdw_ctx *c)
         if (st.max_len > max_len) max_len = st.max_len;
         if (count > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", count, c->id_cap);
         c->nuniq = st.entries;
+        c->nids = count;
     }
     const uint64_t u = count;
     {
@@ -377,7 +379,7 @@ int prepare_pass2(zdw_ctx *c, Pass2Args &a)
     a.rec = c->rec.as<uint8_t>();
     a.used_recoff = c->d_used_recoff.as<uint32_t>(); a.used_kind = c->d_used_kind.as<uint8_t>();
     a.used_size = c->d_used_size.as<uint8_t>(); a.used_base = c->d_used_base.as<uint64_t>();
-    a.id_off = c->slot_off.as<uint32_t>(); a.prev0 = c->d_prev0.as<uint64_t>();
+    a.id_off = c->slot_off.as<uint32_t>(); a.nids = c->nids; a.prev0 = c->d_prev0.as<uint64_t>();
     a.last_stored = c->d_last.as<uint64_t>();
     return ZDW_OK;
 }
@@ -612,7 +614,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     }
     { uint64_t p2 = 1; while (p2 < nslots) p2 <<= 1; nslots = p2; }
     HIP_TRY(c, c->col_min.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_max.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_seen.ensure(c->ncols + 8));
-    HIP_TRY(c, c->rec.ensure((uint64_t)nrows * c->rec_stride + 16));
+    HIP_TRY(c, c->rec.ensure((uint64_t)nrows * c->rec_stride + 64));      // slack: 8-byte reads of 4-byte fields, 16-byte staging reads
     const uint64_t blk_bytes = hi > lo ? hi - lo : 0;
     const uint32_t long_cap = (uint32_t)std::min<uint64_t>(blk_bytes / (FIRST_ROW_CAP - 1) + 2, 1u << 26);
     HIP_TRY(c, c->long_rows.ensure((uint64_t)long_cap * sizeof(LongRow)));

@@ -73,6 +73,14 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
     v += dpp_or_zero<DPP_ROW_BCAST31, 0xc>(v);      // lane 31 into rows 2 and 3
     return v;
 }
+// exclusive prefix sum over the wave; total = the wave's sum
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane, uint32_t &total)
+{
+    (void)lane;
+    const uint32_t inc = wave_incl_sum(v);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    return inc - v;
+}
 // the value held by lane - 1 (0 in lane 0)
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return dpp_or_zero<DPP_WAVE_SHR1, 0xf>(v); }
 // wave-uniform read of one lane's value (v_readlane_b32; the lane index must be wave-uniform)

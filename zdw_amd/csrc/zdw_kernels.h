@@ -70,6 +70,7 @@ struct Pass2Args {
     const uint8_t *used_size;      // bytes stored per value
     const uint64_t *used_base;     // column base (min - 1; 0 for text)
     const uint32_t *id_off;        // dictionary offset per unique id
+    uint32_t nids;                 // entries of id_off
     const uint64_t *prev0;         // stored values of the row before row 0 (per used column)
     uint32_t *row_len;             // out (size kernel)
     uint16_t *batch_pre;           // wide schemas, size kernel -> emit kernel: per (row, 64-column batch) the value bytes of the batches before it
