@@ -235,12 +235,80 @@ struct __attribute__((packed)) PackedL16 { uint16_t v; };
 
 // emit: the workgroup assembles P2_R consecutive rows in LDS (at the byte offset that makes LDS and global
 // 16-byte phases agree) and copies the image out with aligned vector stores
+// one wave, one 64-column batch of a chunk: flags, dictionary gathers, flag bytes and values into the LDS image
+template <uint32_t P2_R>
+__device__ __forceinline__ void emit_batch(const Pass2Args &a, uint8_t *img, uint32_t b, uint32_t lane, const ColFacts &f, uint64_t (&v)[P2_R + 1],
+                                           uint32_t row0, uint32_t rows, uint64_t base, uint32_t shift, uint32_t nflag, uint32_t nbatch)
+{
+    const uint32_t u = 64 * b + lane;
+    // where each row's bytes of this batch begin in the image
+    uint32_t my_at = 0;
+    if (lane < rows) my_at = (uint32_t)(a.row_off[row0 + lane] - base) + shift;
+    uint32_t my_pre = 0;
+    if (lane < rows) my_pre = a.batch_pre[(uint64_t)(row0 + lane) * nbatch + b];
+    // flags first, then every dictionary gather of the chunk in flight together
+    uint32_t flags = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < P2_R; ++r) flags |= (v[r + 1] != v[r] ? 1u : 0u) << r;
+    if (row0 == 0 && f.ok) {     // the halo row arrives as stored values
+        const uint64_t s0 = stored_from_raw(a, v[1], u, f.text);
+        flags = (flags & ~1u) | (s0 != a.prev0[u] ? 1u : 0u);
+    }
+    if (!f.ok) flags = 0;
+    const uint64_t basev = f.ok && !f.text ? a.used_base[u] : 0ull;
+#pragma unroll
+    for (uint32_t r = 0; r < P2_R; ++r) {
+        uint64_t x = v[r + 1];
+        if ((flags >> r) & 1u) x = f.text ? (x ? (uint64_t)a.id_off[(uint32_t)x - 1] : 0ull) : (x ? x - basev : 0ull);
+        v[r + 1] = x;
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < P2_R; ++r) {
+        if (r >= rows) continue;
+        const bool flag = (flags >> r) & 1u;
+        const uint32_t mine = flag ? f.sz : 0u;
+        const uint32_t inc = wave_incl_sum(mine);
+        const uint64_t bal = __ballot(flag);
+        const uint32_t at = lane_value(my_at, r), pre = lane_value(my_pre, r);
+        if (lane < 8 && 64 * b + 8 * lane < a.nused) img[at + 8 * b + lane] = (uint8_t)(bal >> (8 * lane));
+        if (flag) {
+            // little-endian truncating store in at most three pieces (4 + 2 + 1 bytes; LDS stores are unaligned-capable)
+            uint8_t *q = img + at + nflag + pre + (inc - mine);
+            const uint32_t sz = f.sz;
+            uint64_t x = v[r + 1];
+            if (sz == 8) { reinterpret_cast<PackedL64 *>(q)->v = x; }
+            else {
+                if (sz & 4u) { reinterpret_cast<PackedL32 *>(q)->v = (uint32_t)x; q += 4; x >>= 32; }
+                if (sz & 2u) { reinterpret_cast<PackedL16 *>(q)->v = (uint16_t)x; q += 2; x >>= 16; }
+                if (sz & 1u) *q = (uint8_t)x;
+            }
+        }
+    }
+}
+
+// image [shift, shift + nbytes) -> out[base, base + nbytes): whole 16-byte vectors where they are covered
+__device__ __forceinline__ void copy_image_out(const Pass2Args &a, const uint8_t *img, uint64_t base, uint32_t shift, uint32_t nbytes)
+{
+    uint8_t *gdst = a.out + (base - shift);              // 16-byte aligned
+    const uint32_t endb = shift + nbytes;
+    for (uint32_t o = threadIdx.x * 16u; o < endb; o += 256u * 16u) {
+        if (o >= shift && o + 16u <= endb) {
+            *reinterpret_cast<uint4 *>(gdst + o) = *reinterpret_cast<const uint4 *>(img + o);
+        } else {
+            const uint32_t lo = o > shift ? o : shift, hi = o + 16u < endb ? o + 16u : endb;
+            for (uint32_t k = lo; k < hi; ++k) gdst[k] = img[k];
+        }
+    }
+}
+
+// emit: the workgroup assembles P2_R consecutive rows in LDS (at the byte offset that makes LDS and global
+// 16-byte phases agree) and copies the image out with aligned vector stores.
+// STAGED: the chunk's records come through LDS (stage_chunk) instead of lane = column loads from HBM.
 template <bool STAGED, uint32_t P2_R>
 __global__ __launch_bounds__(256) void k_pass2_emit_cols(const Pass2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t p2_lds[];
     uint8_t *stage = p2_lds + ((P2_R * a.out_row_max + 32u + 15u) & ~15u);
-
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nflag = (a.nused + 7) >> 3;
     const uint32_t nbatch = (a.nused + 63) >> 6;
@@ -254,67 +322,68 @@ __global__ __launch_bounds__(256) void k_pass2_emit_cols(const Pass2Args a)
         uint32_t at0 = 0;
         if (STAGED) { at0 = stage_chunk(a, stage, row0, rows); __syncthreads(); }
         for (uint32_t b = wv; b < nbatch; b += 4) {
-            const uint32_t u = 64 * b + lane;
-            const ColFacts f = col_facts(a, u);
+            const ColFacts f = col_facts(a, 64 * b + lane);
             uint64_t v[P2_R + 1];
             if (STAGED) load_column_staged<P2_R>(stage, at0, a.rec_stride, f, row0, rows, v);
             else load_column<P2_R>(a, f, row0, rows, v);
-            // where each row's bytes of this batch begin in the image
-            uint32_t my_at = 0;
-            if (lane < rows) my_at = (uint32_t)(a.row_off[row0 + lane] - base) + shift;
-            uint32_t my_pre = 0;
-            if (lane < rows) my_pre = a.batch_pre[(uint64_t)(row0 + lane) * nbatch + b];
-            // flags first, then every dictionary gather of the chunk in flight together
-            uint32_t flags = 0;
-#pragma unroll
-            for (uint32_t r = 0; r < P2_R; ++r) flags |= (v[r + 1] != v[r] ? 1u : 0u) << r;
-            if (row0 == 0 && f.ok) {     // the halo row arrives as stored values
-                const uint64_t s0 = stored_from_raw(a, v[1], u, f.text);
-                flags = (flags & ~1u) | (s0 != a.prev0[u] ? 1u : 0u);
-            }
-            if (!f.ok) flags = 0;
-            const uint64_t basev = f.ok && !f.text ? a.used_base[u] : 0ull;
-#pragma unroll
-            for (uint32_t r = 0; r < P2_R; ++r) {
-                uint64_t x = v[r + 1];
-                if ((flags >> r) & 1u) x = f.text ? (x ? (uint64_t)a.id_off[(uint32_t)x - 1] : 0ull) : (x ? x - basev : 0ull);
-                v[r + 1] = x;
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < P2_R; ++r) {
-                if (r >= rows) continue;
-                const bool flag = (flags >> r) & 1u;
-                const uint32_t mine = flag ? f.sz : 0u;
-                const uint32_t inc = wave_incl_sum(mine);
-                const uint64_t bal = __ballot(flag);
-                const uint32_t at = lane_value(my_at, r), pre = lane_value(my_pre, r);
-                if (lane < 8 && 64 * b + 8 * lane < a.nused) p2_lds[at + 8 * b + lane] = (uint8_t)(bal >> (8 * lane));
-                if (flag) {
-                    // little-endian truncating store in at most three pieces (4 + 2 + 1 bytes; LDS stores are unaligned-capable)
-                    uint8_t *q = p2_lds + at + nflag + pre + (inc - mine);
-                    const uint32_t sz = f.sz;
-                    uint64_t x = v[r + 1];
-                    if (sz == 8) { reinterpret_cast<PackedL64 *>(q)->v = x; }
-                    else {
-                        if (sz & 4u) { reinterpret_cast<PackedL32 *>(q)->v = (uint32_t)x; q += 4; x >>= 32; }
-                        if (sz & 2u) { reinterpret_cast<PackedL16 *>(q)->v = (uint16_t)x; q += 2; x >>= 16; }
-                        if (sz & 1u) *q = (uint8_t)x;
-                    }
-                }
-            }
+            emit_batch<P2_R>(a, p2_lds, b, lane, f, v, row0, rows, base, shift, nflag, nbatch);
         }
         __syncthreads();
-        // image [shift, shift + nbytes) -> out[base, base + nbytes): whole 16-byte vectors where they are covered
-        uint8_t *gdst = a.out + (base - shift);              // 16-byte aligned
-        const uint32_t endb = shift + nbytes;
-        for (uint32_t o = threadIdx.x * 16u; o < endb; o += 256u * 16u) {
-            if (o >= shift && o + 16u <= endb) {
-                *reinterpret_cast<uint4 *>(gdst + o) = *reinterpret_cast<const uint4 *>(p2_lds + o);
-            } else {
-                const uint32_t lo = o > shift ? o : shift, hi = o + 16u < endb ? o + 16u : endb;
-                for (uint32_t k = lo; k < hi; ++k) gdst[k] = p2_lds[k];
-            }
-        }
+        copy_image_out(a, p2_lds, base, shift, nbytes);
+        __syncthreads();
+    }
+}
+
+// The staged form for at most four batches (one per wave) and at most 16 KiB of records per chunk: the staging
+// buffer is free as soon as every wave holds its columns, so the next chunk's records are requested right then and
+// arrive while this chunk's gathers, image writes and copy-out run.
+template <uint32_t P2_R>
+__global__ __launch_bounds__(256, P2_R == 8 ? 7 : 4) void k_pass2_emit_cols_piped(const Pass2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t p2_lds[];
+    uint8_t *stage = p2_lds + ((P2_R * a.out_row_max + 32u + 15u) & ~15u);
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t nflag = (a.nused + 7) >> 3;
+    const uint32_t nbatch = (a.nused + 63) >> 6;
+    const uint32_t nchunks = (a.nrows + P2_R - 1) / P2_R;
+    if (blockIdx.x >= nchunks) return;
+    const ColFacts f = col_facts(a, 64 * wv + lane);           // the wave's batch is the same in every chunk
+    uint32_t at0 = stage_chunk(a, stage, blockIdx.x * P2_R, a.nrows - blockIdx.x * P2_R < P2_R ? a.nrows - blockIdx.x * P2_R : P2_R);
+    __syncthreads();
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t row0 = chunk * P2_R;
+        const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
+        const uint64_t base = a.row_off[row0];
+        const uint32_t nbytes = (uint32_t)(a.row_off[row0 + rows] - base);
+        const uint32_t shift = (uint32_t)base & 15u;
+        uint64_t v[P2_R + 1];
+        load_column_staged<P2_R>(stage, at0, a.rec_stride, f, row0, rows, v);
+        __syncthreads();
+        // request the next chunk's records (into registers; committed to LDS after the copy-out)
+        const uint32_t next = chunk + gridDim.x;
+        const bool more = next < nchunks;
+        const uint32_t nrow0 = more ? next * P2_R : row0;
+        const uint32_t nrows = a.nrows - nrow0 < P2_R ? a.nrows - nrow0 : P2_R;
+        const uint32_t nfirst = nrow0 ? nrow0 - 1 : 0;
+        const uint8_t *src = a.rec + (uint64_t)nfirst * a.rec_stride;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
+        const uint32_t sbytes = more ? mis + (nrow0 + nrows - nfirst) * a.rec_stride : 0u;
+        const uint8_t *src16 = src - mis;
+        uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0;
+        const uint32_t o0 = threadIdx.x * 16u;
+        if (o0 < sbytes) g0 = *reinterpret_cast<const uint4 *>(src16 + o0);
+        if (o0 + 4096u < sbytes) g1 = *reinterpret_cast<const uint4 *>(src16 + o0 + 4096u);
+        if (o0 + 8192u < sbytes) g2 = *reinterpret_cast<const uint4 *>(src16 + o0 + 8192u);
+        if (o0 + 12288u < sbytes) g3 = *reinterpret_cast<const uint4 *>(src16 + o0 + 12288u);
+
+        if (wv < nbatch) emit_batch<P2_R>(a, p2_lds, wv, lane, f, v, row0, rows, base, shift, nflag, nbatch);
+        __syncthreads();
+        copy_image_out(a, p2_lds, base, shift, nbytes);
+        if (o0 < sbytes) *reinterpret_cast<uint4 *>(stage + o0) = g0;
+        if (o0 + 4096u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 4096u) = g1;
+        if (o0 + 8192u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 8192u) = g2;
+        if (o0 + 12288u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 12288u) = g3;
+        at0 = mis + (nrow0 - nfirst) * a.rec_stride;
         __syncthreads();
     }
 }
@@ -346,24 +415,23 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
         } else {
             uint32_t R = 8;
             if (const char *e = getenv("ZDW_P2_EMIT_ROWS")) R = atoi(e) == 16 ? 16u : 8u;
-            bool staged = !direct && p2_stage_bytes(R, a.rec_stride) <= P2_STAGE_BUDGET;
-            if (getenv("ZDW_P2_EMIT_DIRECT")) staged = false;
+            uint32_t mode = 0;
+            if (!direct && !getenv("ZDW_P2_EMIT_DIRECT") && p2_stage_bytes(R, a.rec_stride) <= P2_STAGE_BUDGET) {
+                mode = 1;
+                if (nbatch <= 4 && p2_stage_bytes(R, a.rec_stride) <= 4u * 4096u && !getenv("ZDW_P2_EMIT_NOPIPE")) mode = 2;
+            }
             const uint64_t want = ((uint64_t)a.nrows + R - 1) / R;
-            const uint32_t lds = ((R * a.out_row_max + 32u + 15u) & ~15u) + (staged ? p2_stage_bytes(R, a.rec_stride) : 0u);
-            const void *fn = R == 16 ? (staged ? (const void *)k_pass2_emit_cols<true, 16> : (const void *)k_pass2_emit_cols<false, 16>)
-                                     : (staged ? (const void *)k_pass2_emit_cols<true, 8> : (const void *)k_pass2_emit_cols<false, 8>);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
+            const uint32_t lds = ((R * a.out_row_max + 32u + 15u) & ~15u) + (mode ? p2_stage_bytes(R, a.rec_stride) : 0u);
+            typedef void (*EmitFn)(const Pass2Args);
+            static const EmitFn fns[2][3] = {{k_pass2_emit_cols<false, 8>, k_pass2_emit_cols<true, 8>, k_pass2_emit_cols_piped<8>},
+                                             {k_pass2_emit_cols<false, 16>, k_pass2_emit_cols<true, 16>, k_pass2_emit_cols_piped<16>}};
+            const EmitFn fn = fns[R == 16][mode];
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
             // measured (10 GB x 200 columns): staged 8-row chunks 5 / 6 / 7 / 8 workgroups per CU = 5.5 / 4.9 / 4.5 / 6.7 ms
-            uint32_t per_cu = std::min(staged ? 7u : 6u, (uint32_t)occ);
+            uint32_t per_cu = std::min(mode ? 7u : 6u, (uint32_t)occ);
             if (const char *e = getenv("ZDW_P2_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
-            if (R == 16) {
-                if (staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_emit_cols<true, 16>), dim3(grid), dim3(256), lds, s, a);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_emit_cols<false, 16>), dim3(grid), dim3(256), lds, s, a);
-            } else {
-                if (staged) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_emit_cols<true, 8>), dim3(grid), dim3(256), lds, s, a);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_emit_cols<false, 8>), dim3(grid), dim3(256), lds, s, a);
-            }
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a);
         }
         return;
     }
