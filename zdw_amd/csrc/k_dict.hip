@@ -27,13 +27,9 @@ constexpr uint32_t SORT_CHUNK = 2048;
 
 uint32_t sort_blocks(uint64_t n) { return (uint32_t)((n + SORT_CHUNK - 1) / SORT_CHUNK); }
 
-// The digit of element i comes from its key, or -- when `dsrc` is given -- from dsrc[vals[i]] (a second,
-// more significant sort key looked up through the value; the pairs themselves keep travelling).
-__device__ __forceinline__ uint32_t radix_digit(const uint64_t *keys, const uint32_t *vals, const uint32_t *dsrc, uint32_t i, uint32_t shift)
-{
-    return dsrc ? (dsrc[vals[i]] >> shift) & 255u : (uint32_t)(keys[i] >> shift) & 255u;
-}
-
+// The digit of an element comes from its key, or -- DSRC -- from dsrc[value] (a second, more significant sort
+// key looked up through the value; the pairs themselves keep travelling).
+template <bool DSRC>
 __global__ __launch_bounds__(64) void k_radix_hist(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                     const uint32_t *__restrict__ dsrc, uint32_t n, uint32_t shift,
                                                     uint32_t *__restrict__ hist, uint32_t nblocks)
@@ -41,14 +37,38 @@ __global__ __launch_bounds__(64) void k_radix_hist(const uint64_t *__restrict__ 
     __shared__ uint32_t h[256];
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < 256; i += 64) h[i] = 0;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();          // one wave per block: LDS operations execute in order
     const uint32_t beg = blockIdx.x * SORT_CHUNK;
     const uint32_t end = beg + SORT_CHUNK < n ? beg + SORT_CHUNK : n;
-    for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&h[radix_digit(keys, vals, dsrc, i, shift)], 1u);
-    __syncthreads();
+    constexpr uint32_t STEPS = SORT_CHUNK / 64;
+    // all loads of the chunk in flight before the first count
+    uint32_t dig[STEPS];
+    if (DSRC) {
+        uint32_t v[STEPS];
+#pragma unroll
+        for (uint32_t k = 0; k < STEPS; ++k) { const uint32_t i = beg + 64 * k + lane; v[k] = i < end ? vals[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < STEPS; ++k) { const uint32_t i = beg + 64 * k + lane; dig[k] = i < end ? (dsrc[v[k]] >> shift) & 255u : 0u; }
+    } else {
+        // the digit's byte of the key only
+        const uint8_t *kb = reinterpret_cast<const uint8_t *>(keys) + (shift >> 3);
+#pragma unroll
+        for (uint32_t k = 0; k < STEPS; ++k) { const uint32_t i = beg + 64 * k + lane; dig[k] = i < end ? kb[8ull * i] : 0u; }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < STEPS; ++k)
+        if (beg + 64 * k + lane < end) atomicAdd(&h[dig[k]], 1u);
+    __builtin_amdgcn_wave_barrier();
     for (uint32_t d = lane; d < 256; d += 64) hist[d * nblocks + blockIdx.x] = h[d];
 }
 
+// DSRC: the digit comes from dsrc[value] instead of the key.  The chunk is handled in two halves of SORT_STEPS
+// 64-element steps; all loads of a half are issued before its first step is ranked (a step's rank needs the
+// running offsets of the step before, so the steps themselves are sequential).
+constexpr uint32_t SORT_STEPS = 16;
+static_assert(SORT_CHUNK % (64 * SORT_STEPS) == 0, "a chunk is a whole number of half-chunks");
+
+template <bool DSRC>
 __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                        const uint32_t *__restrict__ dsrc, uint64_t *__restrict__ keys_out,
                                                        uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
@@ -71,33 +91,39 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict
     __builtin_amdgcn_wave_barrier();
     const uint32_t beg = blockIdx.x * SORT_CHUNK;
     const uint32_t end = beg + SORT_CHUNK < n ? beg + SORT_CHUNK : n;
-    // the next step's pair (and its digit source) is requested before this step's is ranked
-    uint32_t i = beg + lane;
-    bool valid = i < end;
-    uint64_t key = valid ? keys_in[i] : 0ull;
-    uint32_t val = valid ? vals_in[i] : 0u;
-    uint32_t dw = (valid && dsrc) ? dsrc[val] : 0u;
-    for (uint32_t b = beg; b < end; b += 64) {
-        const uint32_t i2 = b + 64 + lane;
-        const bool valid2 = i2 < end;
-        const uint64_t key2 = valid2 ? keys_in[i2] : 0ull;
-        const uint32_t val2 = valid2 ? vals_in[i2] : 0u;
-        const uint32_t digit = valid ? (dsrc ? (dw >> shift) & 255u : (uint32_t)(key >> shift) & 255u) : 0u;
-        uint64_t mm = __ballot(valid);                 // lanes holding the same digit as this lane
+    for (uint32_t hb = beg; hb < end; hb += 64 * SORT_STEPS) {
+        uint64_t key[SORT_STEPS];
+        uint32_t val[SORT_STEPS], dig[SORT_STEPS];
 #pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const bool one = (digit >> bit) & 1u;
-            const uint64_t vote = __ballot(one);
-            mm &= one ? vote : ~vote;
+        for (uint32_t k = 0; k < SORT_STEPS; ++k) {
+            const uint32_t i = hb + 64 * k + lane;
+            key[k] = i < end ? keys_in[i] : 0ull;
+            val[k] = i < end ? vals_in[i] : 0u;
         }
-        uint32_t dst = 0;
-        if (valid) dst = offs[digit] + popc64(mm & mask_lt((int)lane));
-        __builtin_amdgcn_wave_barrier();
-        if (valid && lane == (uint32_t)highest_bit(mm)) offs[digit] += popc64(mm);
-        __builtin_amdgcn_wave_barrier();
-        if (valid) { keys_out[dst] = key; vals_out[dst] = val; }
-        const uint32_t dw2 = (valid2 && dsrc) ? dsrc[val2] : 0u;
-        key = key2; val = val2; valid = valid2; dw = dw2;
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_STEPS; ++k) {
+            const uint32_t i = hb + 64 * k + lane;
+            if (DSRC) dig[k] = i < end ? (dsrc[val[k]] >> shift) & 255u : 0u;
+            else dig[k] = (uint32_t)(key[k] >> shift) & 255u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_STEPS; ++k) {
+            const bool valid = hb + 64 * k + lane < end;
+            const uint32_t digit = dig[k];
+            uint64_t mm = __ballot(valid);                 // lanes holding the same digit as this lane
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (digit >> bit) & 1u;
+                const uint64_t vote = __ballot(one);
+                mm &= one ? vote : ~vote;
+            }
+            uint32_t dst = 0;
+            if (valid) dst = offs[digit] + popc64(mm & mask_lt((int)lane));
+            __builtin_amdgcn_wave_barrier();
+            if (valid && lane == (uint32_t)highest_bit(mm)) offs[digit] += popc64(mm);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) { keys_out[dst] = key[k]; vals_out[dst] = val[k]; }
+        }
     }
 }
 
@@ -138,10 +164,12 @@ static void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **keys_a
 {
     const uint32_t nb = sort_blocks(n);
     for (uint32_t shift = bit_lo; shift < bit_hi; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, n, shift, hist, nb);
+        if (dsrc) hipLaunchKernelGGL(k_radix_hist<true>, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, n, shift, hist, nb);
+        else hipLaunchKernelGGL(k_radix_hist<false>, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, n, shift, hist, nb);
         uint32_t *row_tot = hist + (size_t)256 * nb;
         hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, hist, nb, row_tot);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, *keys_alt, *vals_alt, n, shift, hist, row_tot, nb);
+        if (dsrc) hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, *keys_alt, *vals_alt, n, shift, hist, row_tot, nb);
+        else hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, *keys_alt, *vals_alt, n, shift, hist, row_tot, nb);
         uint64_t *tk = *keys; *keys = *keys_alt; *keys_alt = tk;
         uint32_t *tv = *vals; *vals = *vals_alt; *vals_alt = tv;
     }
