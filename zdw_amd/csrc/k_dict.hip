@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ i
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    const uint32_t u = order[active[j]];
+    const uint32_t u = order ? order[active[j]] : j;          // first round: everything is in place (order = active = identity)
     const uint32_t len = uniq_len[u];
     // a hole (length 0) sorts before every string (first byte >= 1) and apart from every other hole
     const uint64_t pos = uniq_pos[u];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint32_t *__restrict_
                                                       const uint32_t *__restrict__ vals, uint32_t m, uint32_t *__restrict__ tmp)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < m) tmp[j] = order[active[vals[j]]];
+    if (j < m) tmp[j] = order ? order[active[vals[j]]] : vals[j];
 }
 
 // writes the round's result back and flags what is still tied:
@@ -271,7 +271,8 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
         const uint32_t gb = (m + 255) / 256;
         uint64_t *keys = b.key_a, *keys_alt = b.key_b;
         uint32_t *vals = b.val_a, *vals_alt = b.val_b;
-        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, b.order, active, m, depth, keys, vals);
+        const uint32_t *order_in = depth ? b.order : nullptr;      // identity in the first round
+        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active, m, depth, keys, vals);
         radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, 64, b.hist, b.scan_tmp, s);
         if (depth > 0) {
             // stable, more significant key: the tie group of the element's old position (labels are < m + 1)
@@ -279,7 +280,7 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
             while (bits < 32 && (1ull << bits) <= (uint64_t)m + 1) ++bits;
             radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
         }
-        hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, b.order, active, vals, m, tmp);
+        hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active, vals, m, tmp);
         hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active, group, tmp, (const uint64_t *)keys, m, head, still);
         launch_scan_u32_to_u32(head, head_scan, m, b.scan_tmp, nullptr, s);
         launch_scan_u32_to_u32(still, still_scan, m, b.scan_tmp, nullptr, s);
