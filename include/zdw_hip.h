@@ -158,10 +158,12 @@ int zdw_shard_set_prev_row(zdw_ctx *ctx, const uint64_t *stored /* ncols, NULL =
 
 /* Range-partitioned dictionary (instead of export / import of the union): the node-wide dictionary is sorted
  * once, 1/N of it on every rank.  Per shard, after zdw_block_pass1 and the range exchange:
- *   zdw_shard_sort_uniques    sort this shard's unique strings (count = how many)
- *   zdw_shard_sample_keys     nsamples evenly spaced 16-byte prefix keys (2 big-endian u64 each) -> the caller
- *                             gathers all shards' samples and picks N-1 splitters (the same on every shard)
- *   zdw_shard_partition       strings in sorted order as lens + NUL-terminated bytes; part p = keys in
+ *   zdw_shard_sort_uniques    take stock of this shard's unique strings (count = how many).  Despite the name a
+ *                             shard does not sort them (ZDW_SHARD_PRESORT=1 brings the sorting form back)
+ *   zdw_shard_sample_keys     nsamples 16-byte prefix keys of its strings (2 big-endian u64 each; all ones = no
+ *                             string) -> the caller gathers all shards' samples and picks N-1 splitters (the
+ *                             same on every shard)
+ *   zdw_shard_partition       strings grouped by part as lens + NUL-terminated bytes; part p = keys in
  *                             [splitter[p-1], splitter[p]); counts / nbytes per part -> all-to-all
  *   zdw_owner_build           (as owner of range r) dedupe + sort + lay out the strings received for it
  *   zdw_owner_offsets         dictionary offset of every received string, in arrival order -> all-to-all back

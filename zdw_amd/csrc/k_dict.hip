@@ -400,6 +400,55 @@ __global__ __launch_bounds__(64) void k_key16_at(const uint8_t *in, uint64_t in_
     key16_of(in, in_bytes, extra, uniq_pos, uniq_len, order[idx[i]], keys[2 * i], keys[2 * i + 1]);
 }
 
+// the same for unsorted uniques: sample i = the first real string at or after id idx[i] (within 256 ids; ~0 when none)
+__global__ __launch_bounds__(64) void k_key16_sample(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos,
+                                                      const uint32_t *uniq_len, const uint32_t *idx, uint32_t n, uint32_t nids, uint64_t *keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t id = idx[i];
+    for (uint32_t k = 0; k < 256 && id < nids && uniq_len[id] == 0; ++k) ++id;
+    if (id >= nids || uniq_len[id] == 0) { keys[2 * i] = keys[2 * i + 1] = ~0ull; return; }
+    key16_of(in, in_bytes, extra, uniq_pos, uniq_len, id, keys[2 * i], keys[2 * i + 1]);
+}
+
+// bucket of every unique id for the range partition: 0 = hole, 1 + (number of splitters <= the string's 16-byte key)
+__global__ __launch_bounds__(256) void k_bucket_of(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *__restrict__ uniq_pos,
+                                                    const uint32_t *__restrict__ uniq_len, uint32_t nids, const uint64_t *__restrict__ splitters,
+                                                    uint32_t nsplit, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nids) return;
+    uint32_t b = 0;
+    if (uniq_len[id]) {
+        uint64_t k0, k1;
+        key16_of(in, in_bytes, extra, uniq_pos, uniq_len, id, k0, k1);
+        uint32_t lo = 0, hi = nsplit;          // first splitter greater than the key
+        while (lo < hi) {
+            const uint32_t m = (lo + hi) >> 1;
+            const uint64_t s0 = splitters[2 * m], s1 = splitters[2 * m + 1];
+            const bool greater = s0 > k0 || (s0 == k0 && s1 > k1);
+            if (greater) hi = m; else lo = m + 1;
+        }
+        b = 1 + lo;
+    }
+    keys[id] = b;
+    vals[id] = id;
+}
+
+// bounds[j] = first position whose key is >= j, for j = 0 .. nq - 1 (keys ascending)
+__global__ __launch_bounds__(64) void k_lower_bounds(const uint64_t *__restrict__ keys, uint32_t n, uint32_t nq, uint32_t *__restrict__ bounds)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nq) return;
+    uint32_t a = 0, b = n;
+    while (a < b) {
+        const uint32_t m = a + (b - a) / 2;
+        if (keys[m] < j) a = m + 1; else b = m;
+    }
+    bounds[j] = a;
+}
+
 // bounds[j] = first sorted position p in [lo, hi) whose 16-byte key is >= splitter j (hi when none)
 __global__ __launch_bounds__(64) void k_partition_search(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos,
                                                           const uint32_t *uniq_len, const uint32_t *order, uint32_t lo, uint32_t hi,
@@ -437,6 +486,26 @@ void launch_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra,
                      const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys, hipStream_t s)
 {
     if (n) hipLaunchKernelGGL(k_key16_at, dim3((n + 63) / 64), dim3(64), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order, idx, n, keys);
+}
+void launch_key16_sample(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                         const uint32_t *idx, uint32_t n, uint32_t nids, uint64_t *keys, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_key16_sample, dim3((n + 63) / 64), dim3(64), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, idx, n, nids, keys);
+}
+// Groups the unique ids by range: order[0 .. bounds[1]) = holes, order[bounds[p + 1] .. bounds[p + 2]) = the strings of part p
+// (ids ascending inside a group); bounds has nparts + 2 entries (device).  One stable radix pass on the bucket number.
+void launch_bucket_partition(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                             uint32_t nids, const uint64_t *splitters, uint32_t nparts, SortBuffers &b, uint32_t *order_out, uint32_t *bounds,
+                             hipStream_t s)
+{
+    if (!nids) { (void)hipMemsetAsync(bounds, 0, (nparts + 2) * 4, s); return; }
+    uint64_t *keys = b.key_a, *keys_alt = b.key_b;
+    uint32_t *vals = b.val_a, *vals_alt = b.val_b;
+    hipLaunchKernelGGL(k_bucket_of, dim3((nids + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, nids, splitters, nparts - 1,
+                       keys, vals);
+    radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, nids, 0, nparts + 1 <= 256 ? 8 : 16, b.hist, b.scan_tmp, s);
+    hipLaunchKernelGGL(k_lower_bounds, dim3((nparts + 2 + 63) / 64), dim3(64), 0, s, (const uint64_t *)keys, nids, nparts + 2, bounds);
+    (void)hipMemcpyAsync(order_out, vals, (size_t)nids * 4, hipMemcpyDeviceToDevice, s);
 }
 void launch_partition_search(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                              const uint32_t *order, uint32_t lo, uint32_t hi, const uint64_t *splitters, uint32_t nsplit, uint32_t *bounds,

@@ -99,7 +99,7 @@ struct zdw_ctx {
     // range-partitioned dictionary (multi-GPU): this shard as a requester ...
     DevBuf my_order, part_idx, part_keys, part_bounds, part_split, part_lens;
     uint64_t sorted_n = 0, sorted_holes = 0;
-    bool uniques_sorted = false;
+    bool uniques_sorted = false, presorted = false;
     // ... and as the owner of one key range of the node-wide dictionary
     DevBuf own_slots, own_upos, own_ulen, own_status, own_extra, own_lens, own_offs, own_ids, own_idoff, own_blob, own_out;
     uint64_t own_count = 0, own_slice = 0;
@@ -238,12 +238,9 @@ int after_input(zdw_ctx *c)
     return ZDW_OK;
 }
 
-// exact string sort of u strings (by id: pos / len, length 0 = hole) into c->order (holes first)
-int sort_strings(zdw_ctx *c, const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *upos, const uint32_t *ulen, uint64_t u,
-                 uint32_t max_len)
+// the buffers of the radix sort for u pairs
+int sort_buffers(zdw_ctx *c, uint64_t u, SortBuffers &b)
 {
-    hipStream_t s = c->stream;
-    StageScope ts(c, ZDW_STAGE_DICT_SORT);
     const size_t nb = sort_blocks(u ? u : 1);
     HIP_TRY(c, c->key_a.ensure((u + 1) * 8)); HIP_TRY(c, c->key_b.ensure((u + 1) * 8));
     HIP_TRY(c, c->val_a.ensure((u + 1) * 4)); HIP_TRY(c, c->val_b.ensure((u + 1) * 4));
@@ -252,13 +249,24 @@ int sort_strings(zdw_ctx *c, const uint8_t *in, uint64_t in_bytes, const uint8_t
     HIP_TRY(c, c->flags.ensure((6 * u + 8) * 4));
     HIP_TRY(c, c->hist.ensure((2 * (256 * nb + 1) + 8) * 4));
     HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(std::max<uint64_t>(256 * nb + 1, std::max<uint64_t>(u + 1, c->nrows + 1ull)))));
-    SortBuffers b{};
     b.key_a = c->key_a.as<uint64_t>(); b.key_b = c->key_b.as<uint64_t>();
     b.val_a = c->val_a.as<uint32_t>(); b.val_b = c->val_b.as<uint32_t>();
     b.order = c->order.as<uint32_t>(); b.group = c->group.as<uint32_t>();
     b.active_a = c->active_a.as<uint32_t>(); b.active_b = c->active_b.as<uint32_t>();
     b.flags = c->flags.as<uint32_t>(); b.hist = c->hist.as<uint32_t>();
     b.scan_tmp = c->scan_tmp.p; b.counter = c->d_scalar.as<uint32_t>();
+    return ZDW_OK;
+}
+
+// exact string sort of u strings (by id: pos / len, length 0 = hole) into c->order (holes first)
+int sort_strings(zdw_ctx *c, const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *upos, const uint32_t *ulen, uint64_t u,
+                 uint32_t max_len)
+{
+    hipStream_t s = c->stream;
+    StageScope ts(c, ZDW_STAGE_DICT_SORT);
+    SortBuffers b{};
+    int rcb = sort_buffers(c, u, b);
+    if (rcb) return rcb;
     const int e = dict_sort(in, in_bytes, extra, upos, ulen, u, b, s, &c->sort_rounds, max_len);
     if (e) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary sort: %s", hipGetErrorString((hipError_t)e));
     return ZDW_OK;
@@ -948,6 +956,17 @@ int zdw_shard_sort_uniques(zdw_ctx *c, uint64_t *count)
     HIP_TRY(c, hipStreamSynchronize(s));
     if (st.id_next > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", st.id_next, c->id_cap);
     const uint64_t u = st.id_next;
+    c->presorted = getenv("ZDW_SHARD_PRESORT") != nullptr;      // the first form of this path (A/B measurements): full sort of the own uniques
+    if (!c->presorted) {
+        // The owners sort; a shard only has to know which range each of its strings falls in (zdw_shard_partition).
+        if (st.entries > u) return fail(c, ZDW_UNKNOWN_ERROR, "more dictionary entries (%u) than unique ids (%u)", st.entries, st.id_next);
+        HIP_TRY(c, c->my_order.ensure((u + 1) * 4));
+        c->sorted_n = u;
+        c->sorted_holes = u - st.entries;
+        c->uniques_sorted = true;
+        if (count) *count = st.entries;
+        return ZDW_OK;
+    }
     int rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u,
                           std::max<uint32_t>(24, st.max_len));
     if (rc) return rc;
@@ -981,9 +1000,20 @@ int zdw_shard_sample_keys(zdw_ctx *c, uint32_t nsamples, uint64_t *keys)
     for (uint32_t i = 0; i < 2 * nsamples; ++i) keys[i] = ~0ull;           // a shard without strings samples "infinity"
     if (!real || !nsamples) return ZDW_OK;
     std::vector<uint32_t> idx(nsamples);
+    HIP_TRY(c, c->part_idx.ensure(nsamples * 4)); HIP_TRY(c, c->part_keys.ensure(nsamples * 16));
+    if (!c->presorted) {
+        // unsorted uniques: ids at a fixed stride (ids follow first appearance in the shard, which says nothing about
+        // a string's place in the order), each moved on to the next real string
+        for (uint32_t i = 0; i < nsamples; ++i) idx[i] = (uint32_t)(((2ull * i + 1) * c->sorted_n) / (2ull * nsamples));
+        HIP_TRY(c, hipMemcpyAsync(c->part_idx.p, idx.data(), nsamples * 4, hipMemcpyHostToDevice, s));
+        launch_key16_sample(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), c->part_idx.as<uint32_t>(),
+                            nsamples, (uint32_t)c->sorted_n, c->part_keys.as<uint64_t>(), s);
+        HIP_TRY(c, hipMemcpyAsync(keys, c->part_keys.p, nsamples * 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        return ZDW_OK;
+    }
     for (uint32_t i = 0; i < nsamples; ++i) idx[i] = (uint32_t)(c->sorted_holes + (uint64_t)(i + 1) * real / (nsamples + 1));
     for (auto &x : idx) if (x >= c->sorted_n) x = (uint32_t)c->sorted_n - 1;
-    HIP_TRY(c, c->part_idx.ensure(nsamples * 4)); HIP_TRY(c, c->part_keys.ensure(nsamples * 16));
     HIP_TRY(c, hipMemcpyAsync(c->part_idx.p, idx.data(), nsamples * 4, hipMemcpyHostToDevice, s));
     launch_key16_at(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), c->my_order.as<uint32_t>(),
                     c->part_idx.as<uint32_t>(), nsamples, c->part_keys.as<uint64_t>(), s);
@@ -1000,16 +1030,31 @@ int zdw_shard_partition(zdw_ctx *c, uint32_t nparts, const uint64_t *splitters, 
     (void)hipSetDevice(c->device);
     hipStream_t s = c->stream;
     const uint64_t real = c->sorted_n - c->sorted_holes;
-    const uint32_t *order = c->my_order.as<uint32_t>() + c->sorted_holes;      // the real strings, sorted
+    std::vector<uint32_t> bounds(nparts + 1, 0);
+    bounds[nparts] = (uint32_t)real;
+    if (!c->presorted) {
+        // group the ids by range (holes first, then part 0, 1, ...): one stable radix pass on the range number
+        SortBuffers b{};
+        int rcb = sort_buffers(c, c->sorted_n, b);
+        if (rcb) return rcb;
+        HIP_TRY(c, c->part_split.ensure(nparts * 16 + 16)); HIP_TRY(c, c->part_bounds.ensure((nparts + 2) * 4));
+        if (nparts > 1) HIP_TRY(c, hipMemcpyAsync(c->part_split.p, splitters, (nparts - 1) * 16, hipMemcpyHostToDevice, s));
+        launch_bucket_partition(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), (uint32_t)c->sorted_n,
+                                c->part_split.as<uint64_t>(), nparts, b, c->my_order.as<uint32_t>(), c->part_bounds.as<uint32_t>(), s);
+        std::vector<uint32_t> gb(nparts + 2, 0);
+        HIP_TRY(c, hipMemcpyAsync(gb.data(), c->part_bounds.p, (nparts + 2) * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (gb[1] != c->sorted_holes) return fail(c, ZDW_UNKNOWN_ERROR, "unique-id holes (%u) do not match the entry count", gb[1]);
+        for (uint32_t p = 0; p < nparts; ++p) bounds[p] = gb[p + 1] - gb[1];
+    }
+    const uint32_t *order = c->my_order.as<uint32_t>() + c->sorted_holes;      // the real strings, grouped by range
     HIP_TRY(c, c->lenp1.ensure((real + 1) * 4)); HIP_TRY(c, c->off_excl.ensure((real + 2) * 8));
     HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(real + 1)));
     HIP_TRY(c, c->part_lens.ensure((real + 1) * 4));
     launch_dict_lengths(order, c->uniq_len.as<uint32_t>(), real, c->lenp1.as<uint32_t>(), s);
     launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), real, c->scan_tmp.p, nullptr, s);
-    // part boundaries: first sorted position whose 16-byte key reaches each splitter
-    std::vector<uint32_t> bounds(nparts + 1, 0);
-    bounds[nparts] = (uint32_t)real;
-    if (nparts > 1) {
+    // part boundaries (sorted uniques): first sorted position whose 16-byte key reaches each splitter
+    if (c->presorted && nparts > 1) {
         HIP_TRY(c, c->part_split.ensure((nparts - 1) * 16)); HIP_TRY(c, c->part_bounds.ensure((nparts - 1) * 4));
         HIP_TRY(c, hipMemcpyAsync(c->part_split.p, splitters, (nparts - 1) * 16, hipMemcpyHostToDevice, s));
         launch_partition_search(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), order, 0,

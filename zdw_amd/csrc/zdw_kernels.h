@@ -121,6 +121,12 @@ void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64
 // range-partitioned dictionary (multi-GPU)
 void launch_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                      const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys, hipStream_t s);
+void launch_key16_sample(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                         const uint32_t *idx, uint32_t n, uint32_t nids, uint64_t *keys, hipStream_t s);
+struct SortBuffers;
+void launch_bucket_partition(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                             uint32_t nids, const uint64_t *splitters, uint32_t nparts, SortBuffers &b, uint32_t *order_out, uint32_t *bounds,
+                             hipStream_t s);
 void launch_partition_search(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                              const uint32_t *order, uint32_t lo, uint32_t hi, const uint64_t *splitters, uint32_t nsplit, uint32_t *bounds,
                              hipStream_t s);

@@ -5,8 +5,8 @@ block's bytes must not depend on the number of shards, so three things are excha
 shard's pass 1:
 
   1. column ranges   min / max / seen per column     -> element-wise min / max / or   (all-reduce)
-  2. dictionary      range-partitioned (default): every shard sorts its own unique strings, 16-byte prefix
-                     samples are all-gathered and give N-1 splitters, strings travel to the owner of their key
+  2. dictionary      range-partitioned (default): 16-byte prefix samples of every shard's unique strings
+                     are all-gathered and give N-1 splitters, strings travel to the owner of their key
                      range (all-to-all-v), the owner dedupes + sorts its range, range sizes are all-gathered and
                      every string's offset travels back (all-to-all-v): the node-wide dictionary is sorted once.
                      merge="allgather": every shard's unique strings -> union on every shard (all-gather-v);
@@ -65,7 +65,8 @@ def pick_splitters(samples, nparts):
     shard because they are a pure function of the multiset of samples."""
     if nparts <= 1:
         return []
-    srt = sorted(samples)
+    inf = ((1 << 64) - 1, (1 << 64) - 1)
+    srt = sorted(x for x in samples if tuple(x) != inf) or [inf]      # "no string here" samples carry no information
     n = len(srt)
     return [srt[min(n - 1, (j * n) // nparts)] for j in range(1, nparts)]
 
@@ -154,7 +155,7 @@ def encode_shards_local(encoders, device="cuda"):
     return blocks
 
 
-SAMPLES_PER_SHARD = 64
+SAMPLES_PER_SHARD = 256
 
 
 def _split(t, counts):
