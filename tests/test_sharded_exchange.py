@@ -35,6 +35,8 @@ def _worker(rank, world, port, q):
     send_counts = [rank + 1 + peer for peer in range(world)]
     payload = torch.tensor([1000 * rank + 10 * peer + k for peer in range(world) for k in range(send_counts[peer])], dtype=torch.int32)
     recv_counts = sharded.exchange_counts(send_counts, "cpu")
+    two = sharded.exchange_counts(send_counts, "cpu", None, [3 * x + rank for x in send_counts])      # two lists, one all-to-all
+    assert two[0] == recv_counts and two[1] == [3 * (peer + 1 + rank) + peer for peer in range(world)]
     got = sharded.alltoallv(payload, send_counts, recv_counts)
     gathered = sharded.allgather_i64([rank * 7, -rank], "cpu")
     q.put((rank, r, ol.tolist(), ob.tolist(), prev, recv_counts, got.tolist(), gathered))

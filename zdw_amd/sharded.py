@@ -237,14 +237,20 @@ def alltoallv(t, send_counts, recv_counts, group=None):
     return out.to(dev)
 
 
-def exchange_counts(vals, device, group=None):
-    """vals[r] = a number for rank r.  Returns what every rank has for me: got[q] = rank q's vals[me]."""
+def exchange_counts(vals, device, group=None, *more):
+    """vals[r] = a number for rank r.  Returns what every rank has for me: got[q] = rank q's vals[me].
+    With further lists in `more` (same length) all of them travel in ONE all-to-all; returns a list per input."""
     import torch.distributed as dist
-    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    lists = [vals] + list(more)
+    k = len(lists)
+    flat = [int(l[r]) for r in range(len(vals)) for l in lists]           # k numbers per destination rank
+    t = torch.tensor(flat, dtype=torch.int64, device=device)
     src = _staged(t, group)
     out = torch.empty_like(src)
     dist.all_to_all_single(out, src, group=group)
-    return [int(x) for x in out.cpu().tolist()]
+    got = [int(x) for x in out.cpu().tolist()]
+    res = [got[j::k] for j in range(k)]
+    return res if more else res[0]
 
 
 def allgather_i64(vals, device, group=None):
@@ -277,8 +283,7 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
     lens = _wrap(d_lens, sum(counts) * 4, "<i4", device).clone()      # torch-owned copies: the collectives work on memory torch allocated
     byts = _wrap(d_bytes, sum(nb), "|u1", device).clone()
     _torch_done()
-    rcounts = exchange_counts(counts, device, group=group)
-    rbytes = exchange_counts(nb, device, group=group)
+    rcounts, rbytes = exchange_counts(counts, device, group, nb)
     got_lens = alltoallv(lens, counts, rcounts, group=group)
     got_byts = alltoallv(byts, nb, rbytes, group=group)
     _torch_done()
@@ -294,15 +299,16 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
 
 
 def allreduce_ranges(mn, mx, seen, device, group=None):
-    """RCCL/gloo form of merge_ranges."""
+    """RCCL/gloo form of merge_ranges: ONE all-reduce (max) over [~min, max, seen] -- ~x reverses the order of
+    int64, so the maximum of the complements is the complement of the minimum."""
     import torch.distributed as dist
-    tmn = u64_to_ordered_i64(mn).to(device)
-    tmx = u64_to_ordered_i64(mx).to(device)
-    ts = torch.tensor(seen, dtype=torch.int32, device=device)
-    dist.all_reduce(tmn, op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(tmx, op=dist.ReduceOp.MAX, group=group)
-    dist.all_reduce(ts, op=dist.ReduceOp.MAX, group=group)
-    return ordered_i64_to_u64(tmn.cpu()), ordered_i64_to_u64(tmx.cpu()), [int(x) for x in ts.cpu().tolist()]
+    tmn = u64_to_ordered_i64(mn)
+    tmx = u64_to_ordered_i64(mx)
+    n = tmn.numel()
+    t = torch.cat([torch.bitwise_not(tmn), tmx, torch.tensor(seen, dtype=torch.int64)]).to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    t = t.cpu()
+    return ordered_i64_to_u64(torch.bitwise_not(t[:n])), ordered_i64_to_u64(t[n:2 * n]), [int(x) for x in t[2 * n:].tolist()]
 
 
 def allgather_uniques(lens, byts, rank, world, group=None):
