@@ -238,14 +238,10 @@ struct __attribute__((packed)) PackedL16 { uint16_t v; };
 // one wave, one 64-column batch of a chunk: flags, dictionary gathers, flag bytes and values into the LDS image
 template <uint32_t P2_R>
 __device__ __forceinline__ void emit_batch(const Pass2Args &a, uint8_t *img, uint32_t b, uint32_t lane, const ColFacts &f, uint64_t (&v)[P2_R + 1],
-                                           uint32_t row0, uint32_t rows, uint64_t base, uint32_t shift, uint32_t nflag, uint32_t nbatch)
+                                           uint32_t row0, uint32_t rows, uint32_t my_at, uint32_t my_pre, uint32_t nflag)
 {
+    // my_at / my_pre (lanes 0 .. rows - 1): where row `lane` begins in the image; the value bytes the batches before b take in it
     const uint32_t u = 64 * b + lane;
-    // where each row's bytes of this batch begin in the image
-    uint32_t my_at = 0;
-    if (lane < rows) my_at = (uint32_t)(a.row_off[row0 + lane] - base) + shift;
-    uint32_t my_pre = 0;
-    if (lane < rows) my_pre = a.batch_pre[(uint64_t)(row0 + lane) * nbatch + b];
     // flags first, then every dictionary gather of the chunk in flight together
     uint32_t flags = 0;
 #pragma unroll
@@ -326,7 +322,12 @@ __global__ __launch_bounds__(256) void k_pass2_emit_cols(const Pass2Args a)
             uint64_t v[P2_R + 1];
             if (STAGED) load_column_staged<P2_R>(stage, at0, a.rec_stride, f, row0, rows, v);
             else load_column<P2_R>(a, f, row0, rows, v);
-            emit_batch<P2_R>(a, p2_lds, b, lane, f, v, row0, rows, base, shift, nflag, nbatch);
+            uint32_t my_at = 0, my_pre = 0;
+            if (lane < rows) {
+                my_at = (uint32_t)(a.row_off[row0 + lane] - base) + shift;
+                my_pre = a.batch_pre[(uint64_t)(row0 + lane) * nbatch + b];
+            }
+            emit_batch<P2_R>(a, p2_lds, b, lane, f, v, row0, rows, my_at, my_pre, nflag);
         }
         __syncthreads();
         copy_image_out(a, p2_lds, base, shift, nbytes);
@@ -334,9 +335,14 @@ __global__ __launch_bounds__(256) void k_pass2_emit_cols(const Pass2Args a)
     }
 }
 
-// The staged form for at most four batches (one per wave) and at most 16 KiB of records per chunk: the staging
-// buffer is free as soon as every wave holds its columns, so the next chunk's records are requested right then and
-// arrive while this chunk's gathers, image writes and copy-out run.
+// all LDS operations of the workgroup so far are done and visible; global stores and loads stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The staged form for at most four batches (one per wave) and at most 16 KiB of records per chunk.  A wave holds
+// its columns in registers right after the chunk starts, so the next chunk's records, row offsets and batch
+// prefixes are requested then and arrive while this chunk's gathers and image writes run; they are committed to
+// LDS between the image barrier and the copy-out.  The barriers order LDS only: the copy-out stores are never
+// waited for inside the loop.
 template <uint32_t P2_R>
 __global__ __launch_bounds__(256, P2_R == 8 ? 7 : 4) void k_pass2_emit_cols_piped(const Pass2Args a)
 {
@@ -347,19 +353,28 @@ __global__ __launch_bounds__(256, P2_R == 8 ? 7 : 4) void k_pass2_emit_cols_pipe
     const uint32_t nbatch = (a.nused + 63) >> 6;
     const uint32_t nchunks = (a.nrows + P2_R - 1) / P2_R;
     if (blockIdx.x >= nchunks) return;
+    const bool have = wv < nbatch;
     const ColFacts f = col_facts(a, 64 * wv + lane);           // the wave's batch is the same in every chunk
-    uint32_t at0 = stage_chunk(a, stage, blockIdx.x * P2_R, a.nrows - blockIdx.x * P2_R < P2_R ? a.nrows - blockIdx.x * P2_R : P2_R);
-    __syncthreads();
+    uint32_t at0;
+    uint64_t ro;            // lane l <= rows: row_off[row0 + l]
+    uint32_t pre;           // lane l < rows: batch_pre[row0 + l][wv]
+    {
+        const uint32_t row0 = blockIdx.x * P2_R, rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
+        at0 = stage_chunk(a, stage, row0, rows);
+        ro = lane <= rows ? a.row_off[row0 + lane] : 0ull;
+        pre = (have && lane < rows) ? a.batch_pre[(uint64_t)(row0 + lane) * nbatch + wv] : 0u;
+        __syncthreads();
+    }
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t row0 = chunk * P2_R;
         const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
-        const uint64_t base = a.row_off[row0];
-        const uint32_t nbytes = (uint32_t)(a.row_off[row0 + rows] - base);
+        const uint64_t base = ((uint64_t)lane_value((uint32_t)(ro >> 32), 0) << 32) | lane_value((uint32_t)ro, 0);
+        const uint32_t nbytes = lane_value((uint32_t)ro, (int)rows) - (uint32_t)base;        // a chunk is far below 4 GiB
         const uint32_t shift = (uint32_t)base & 15u;
+        const uint32_t my_at = (uint32_t)ro - (uint32_t)base + shift, my_pre = pre;
         uint64_t v[P2_R + 1];
         load_column_staged<P2_R>(stage, at0, a.rec_stride, f, row0, rows, v);
-        __syncthreads();
-        // request the next chunk's records (into registers; committed to LDS after the copy-out)
+        // request the next chunk's records, row offsets and prefixes
         const uint32_t next = chunk + gridDim.x;
         const bool more = next < nchunks;
         const uint32_t nrow0 = more ? next * P2_R : row0;
@@ -375,16 +390,18 @@ __global__ __launch_bounds__(256, P2_R == 8 ? 7 : 4) void k_pass2_emit_cols_pipe
         if (o0 + 4096u < sbytes) g1 = *reinterpret_cast<const uint4 *>(src16 + o0 + 4096u);
         if (o0 + 8192u < sbytes) g2 = *reinterpret_cast<const uint4 *>(src16 + o0 + 8192u);
         if (o0 + 12288u < sbytes) g3 = *reinterpret_cast<const uint4 *>(src16 + o0 + 12288u);
+        ro = (more && lane <= nrows) ? a.row_off[nrow0 + lane] : 0ull;
+        pre = (more && have && lane < nrows) ? a.batch_pre[(uint64_t)(nrow0 + lane) * nbatch + wv] : 0u;
 
-        if (wv < nbatch) emit_batch<P2_R>(a, p2_lds, wv, lane, f, v, row0, rows, base, shift, nflag, nbatch);
-        __syncthreads();
-        copy_image_out(a, p2_lds, base, shift, nbytes);
+        if (have) emit_batch<P2_R>(a, p2_lds, wv, lane, f, v, row0, rows, my_at, my_pre, nflag);
+        lds_barrier();          // the image is complete; every wave has read its columns from the staging buffer
         if (o0 < sbytes) *reinterpret_cast<uint4 *>(stage + o0) = g0;
         if (o0 + 4096u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 4096u) = g1;
         if (o0 + 8192u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 8192u) = g2;
         if (o0 + 12288u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 12288u) = g3;
         at0 = mis + (nrow0 - nfirst) * a.rec_stride;
-        __syncthreads();
+        copy_image_out(a, p2_lds, base, shift, nbytes);
+        lds_barrier();          // the image has been read, the next chunk's records are in place
     }
 }
 
