@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--word-maxlen", type=int, default=24, help="longest vocabulary word (24 = BASELINE's table; more: not a valid bench line)")
     ap.add_argument("--pass1-only", action="store_true", help="profiling: time pass 1 alone (not a valid bench line)")
     args = ap.parse_args()
 
@@ -124,7 +125,7 @@ def main():
             dist.init_process_group(args.backend)
 
     # ---- synthetic table, generated in HBM; rank r holds rows [r*R, (r+1)*R) ----
-    table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local)
+    table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local, word_maxlen=args.word_maxlen)
     rows_per_rank = table.rows_for_bytes(args.gb * 1e9)
     buf, nbytes = table.generate(rank * rows_per_rank, rows_per_rank)
     torch.cuda.synchronize()

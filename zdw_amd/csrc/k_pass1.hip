@@ -35,6 +35,7 @@
 namespace zdw {
 
 constexpr uint32_t WROUND = 1024;                 // bytes per wave round (16 per lane)
+constexpr uint32_t DQ_CHUNK = 256;                // deferred-queue entries a wave takes per atomic
 constexpr uint32_t QCAP = 512;                    // descriptor ring entries per wave (u32 each); a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
 constexpr uint32_t BYTE_RING = 2048;              // two rounds of input bytes per wave
 constexpr uint32_t RING_TAIL = 32;                // copy of the byte ring's first bytes behind its end: 24-byte reads never wrap
@@ -246,7 +247,7 @@ void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_
 //   bytes  P1_WPB x (2 KiB + 32)   byte rings, each followed by a copy of its first 32 bytes
 //   lut    25 x 32 B        byte masks "first L bytes are 0xff" for L = 0..24
 //   meta / mn / mx / seen   column tables shared by the waves of the workgroup (cols_in_lds)
-struct P1Lds { uint32_t desc, bytes, lut, meta, mn, mx, seen, total; };
+struct P1Lds { uint32_t desc, bytes, lut, dqs, meta, mn, mx, seen, total; };
 
 __host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool cols_in_lds)
 {
@@ -254,7 +255,8 @@ __host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool c
     L.desc = 0;
     L.bytes = P1_WPB * QCAP * 4u;
     L.lut = L.bytes + P1_WPB * (BYTE_RING + RING_TAIL);
-    L.meta = L.lut + LUT_ROWS * 32u;
+    L.dqs = L.lut + LUT_ROWS * 32u;              // P1_WPB x {cur, end}: kept here, not in registers (the main loop has none to spare)
+    L.meta = L.dqs + P1_WPB * 8u;
     uint32_t end = L.meta;
     L.mn = L.mx = L.seen = end;
     if (cols_in_lds) {
@@ -429,9 +431,23 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     const uint64_t sm = __ballot(slow);
     if (sm) {
         if (DEFER) {
-            uint32_t qb = 0;
-            if (lane == (uint32_t)lowest_bit(sm)) qb = atomicAdd(&a.st->deferred, popc64(sm));
-            qb = lane_value(qb, lowest_bit(sm)) + mbcnt64(sm);
+            // Queue entries come from the wave's chunk (one returning atomic on the queue counter per call would bound a
+            // block full of such fields: a single address takes about 30 M of them a second).  What is left of a chunk
+            // that cannot take this call's fields is filled with blanks (length field all ones), which the second kernel skips.
+            const uint32_t k = popc64(sm);
+            const uint32_t qs = L.dqs + (ws.desc >> 8);                      // ws.desc = wave index x 2048
+            uint32_t cur = lds_u32(qs), end = lds_u32(qs + 4u);
+            if (end - cur < k) {
+                const uint32_t left = end - cur;
+                if (lane < left && cur + lane < a.dq_cap) a.dq[2ull * (cur + lane) + 1] = ~0ull;
+                uint32_t fresh = 0;
+                if (lane == 0) fresh = atomicAdd(&a.st->deferred, DQ_CHUNK);
+                cur = lane_value(fresh, 0);
+                end = cur + DQ_CHUNK;
+                if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + qs + 4u) = end;
+            }
+            const uint32_t qb = cur + mbcnt64(sm);
+            if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + qs) = cur + k;
             if (slow) {
                 if (qb < a.dq_cap) {
                     a.dq[2ull * qb] = (ws.vbase + fs) | ((uint64_t)col << 40);
@@ -481,6 +497,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
     ws.bytes = L.bytes + wv * (BYTE_RING + RING_TAIL);
     ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.first_pending = false; ws.vbase = 0;
     ws.ids.cur = ws.ids.end = 0;
+    if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
     d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st;
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
@@ -692,6 +709,11 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
         }
     }
     retire_ids(ws.ids, a.uniq_len, a.id_cap);
+    if (DEFER) {
+        const uint32_t qs = L.dqs + (ws.desc >> 8);
+        for (uint32_t q = lds_u32(qs) + lane; q < lds_u32(qs + 4u); q += 64)
+            if (q < a.dq_cap) a.dq[2ull * q + 1] = ~0ull;
+    }
     __syncthreads();
     if (new_entries && lane == 0) {
         const uint32_t total = atomicAdd(&a.st->entries, new_entries) + new_entries;
@@ -730,14 +752,16 @@ __global__ __launch_bounds__(256) void k_pass1_deferred(const Pass1Args a, uint3
     for (uint32_t g = wave * 64; g < count; g += nwaves * 64) {
         const uint32_t i = g + lane;
         bool is_new = false;
-        const bool mine = i < count;
+        bool mine = i < count;
+        uint64_t w0 = 0, w1 = ~0ull;
+        if (mine) { w0 = a.dq[2ull * i]; w1 = a.dq[2ull * i + 1]; }
+        mine = mine && w1 != ~0ull;            // blanks: the unused tail of a wave's chunk
         const uint64_t mm = __ballot(mine);
         if (mine) {
-            const uint64_t w0 = a.dq[2ull * i], w1 = a.dq[2ull * i + 1];
             const uint32_t row = (uint32_t)(w1 >> 32);
             process_field_general(a, t, d, al, w0 & POS_MASK, (uint32_t)w1, (uint32_t)(w0 >> 40), row, row < a.row_limit, is_new);
         }
-        adopt_ids(al, mm);
+        if (mm) adopt_ids(al, mm);
         created += popc64(__ballot(is_new));
     }
     retire_ids(al, a.uniq_len, a.id_cap);

@@ -39,9 +39,12 @@ __device__ inline uint32_t put_fixed(uint8_t *q, uint64_t v, uint32_t digits)
     return digits;
 }
 
+// `vocab_and_len`: bits 0..23 = vocabulary size; bits 24..31 = how far the longest word exceeds 24 characters (0 = the
+// benchmark's table: 4..24)
 template <bool WRITE>
-__device__ inline uint32_t emit_field(uint8_t *q, uint64_t seed, uint64_t row, uint32_t col, uint32_t gen, uint32_t vocab)
+__device__ inline uint32_t emit_field(uint8_t *q, uint64_t seed, uint64_t row, uint32_t col, uint32_t gen, uint32_t vocab_and_len)
 {
+    const uint32_t vocab = vocab_and_len & 0xFFFFFFu, span = 21u + (vocab_and_len >> 24);
     // repeat chain: walk up while this field repeats the row above
     uint32_t steps = 0;
     while (row > 0 && steps < 64 && (cell_hash(seed, row, col, 1) & 0xFFFF) < 19661) { --row; ++steps; }   // 0.3 * 65536
@@ -58,7 +61,7 @@ __device__ inline uint32_t emit_field(uint8_t *q, uint64_t seed, uint64_t row, u
         if (rank < 1) rank = 1;
         if (rank > vocab) rank = vocab;
         uint64_t w = mix(seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)rank));
-        const uint32_t len = 4 + (uint32_t)(w % 21);
+        const uint32_t len = 4 + (uint32_t)(w % span);
         for (uint32_t j = 0; j < len; ++j) {
             w = mix(w + j + 1);
             if (WRITE) q[j] = (uint8_t)"abcdefghijklmnopqrstuvwxyz0123456789_"[w % 37];

@@ -104,7 +104,8 @@ struct zdw_ctx {
     DevBuf own_slots, own_upos, own_ulen, own_status, own_extra, own_lens, own_offs, own_ids, own_idoff, own_blob, own_out;
     uint64_t own_count = 0, own_slice = 0;
     bool own_built = false;
-    bool p1_all_in_one = false;            // an earlier block overflowed the deferred-field queue: use the all-in-one kernel
+    bool p1_all_in_one = false;            // the deferred-field queue would outgrow its budget: use the all-in-one kernel
+    uint64_t dq_learned = 0;               // queue entries an earlier pass of this context needed
     uint8_t index_size = 0;
     uint64_t dict_sec_off = 0, dict_sec_len = 0;
     uint32_t sort_rounds = 0;
@@ -627,6 +628,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     const uint32_t long_cap = (uint32_t)std::min<uint64_t>(blk_bytes / (FIRST_ROW_CAP - 1) + 2, 1u << 26);
     HIP_TRY(c, c->long_rows.ensure((uint64_t)long_cap * sizeof(LongRow)));
     P1Status st{};
+    bool dq_grown = false;
     for (int attempt = 0;; ++attempt) {
         if (nslots > (1ull << 31)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary needs more than 2^31 table slots; split the block");
         HIP_TRY(c, c->slots.ensure(nslots * 32));
@@ -662,11 +664,16 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
             // Fields that need the general form (-t, long strings, signed / padded numbers, contended slots) are
-            // queued by the main kernel and handled by a second one; a block with more than about 1 % of them
-            // (or a schema whose tables do not fit LDS) runs the all-in-one kernel instead.
+            // queued by the main kernel (16 bytes each) and handled by a second one.  The queue starts at about 1 %
+            // of the block's fields; a pass that needs more says how many and is run again with that (the context
+            // remembers), up to one queue byte per input byte -- beyond that, with -t, or with a schema whose tables do
+            // not fit LDS, the all-in-one kernel runs instead.  (10 GB x 200 columns with words of 4..32 / 4..96
+            // characters: queue 19 / 27 ms, all-in-one 34 / 42 ms.)
             const bool defer = lds_ranges && !c->trim && !c->p1_all_in_one && !getenv("ZDW_P1_ALL_IN_ONE");
             if (defer) {
-                const uint64_t cap = std::min<uint64_t>((hi - lo) / 1024 + 65536, 1ull << 26);
+                uint64_t dq_div = 1024;
+                if (const char *e = getenv("ZDW_DQ_DIV")) dq_div = std::max<uint64_t>(8, strtoull(e, nullptr, 10));      // experiments
+                const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>((hi - lo) / dq_div + 65536, c->dq_learned), 1ull << 31);
                 HIP_TRY(c, c->deferred_q.ensure(cap * 16));
                 a.dq = c->deferred_q.as<uint64_t>(); a.dq_cap = (uint32_t)cap;
             }
@@ -674,8 +681,14 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             if (defer) {
                 HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
-                if (st.deferred_lost) {             // too many for the queue: this block (and the context's later ones) all in one
-                    c->p1_all_in_one = true;
+                if (st.deferred_lost) {
+                    const uint64_t need = (uint64_t)st.deferred + st.deferred / 8 + 65536;       // (a re-run hands out its chunks differently)
+                    if (!dq_grown && need * 16 <= (hi - lo) + (64ull << 20) && need > a.dq_cap && need < (1ull << 31) && !st.overflow) {
+                        c->dq_learned = need;
+                        dq_grown = true;              // once per block: a second loss goes to the all-in-one kernel
+                    } else {
+                        c->p1_all_in_one = true;      // this block and the context's later ones
+                    }
                     --attempt;
                     continue;
                 }

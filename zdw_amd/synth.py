@@ -145,9 +145,12 @@ def _synth_lib():
 class DeviceTable:
     """Generates rows [row0, row0 + nrows) of the synthetic table into a torch uint8 CUDA tensor."""
 
-    def __init__(self, ncols=200, seed=SEED, vocab=VOCAB, device="cuda"):
+    def __init__(self, ncols=200, seed=SEED, vocab=VOCAB, device="cuda", word_maxlen=24):
+        """word_maxlen: longest vocabulary word (24 = the benchmark's table; up to 279 for tables with long strings)"""
         import torch
         self.torch = torch
+        assert vocab < (1 << 24) + 1 and 24 <= word_maxlen <= 279
+        vocab = min(vocab, (1 << 24) - 1) | ((word_maxlen - 24) << 24)
         self.ncols, self.seed, self.vocab, self.device = ncols, seed, vocab, device
         self.desc, self.types, self.gens = schema(ncols)
         self.d_gens = torch.tensor(self.gens, dtype=torch.uint8, device=device)
