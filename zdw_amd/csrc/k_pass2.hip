@@ -147,6 +147,10 @@ __device__ __forceinline__ void load_column(const Pass2Args &a, const ColFacts &
     for (uint32_t r = 0; r < P2_R; ++r) v[r + 1] = (f.ok && r < rows) ? raw_at(rp + (uint64_t)r * a.rec_stride, f) : 0ull;
 }
 
+// Fewer than three 64-column batches: the four waves of a workgroup share them, 4 or 2 waves per batch, each
+// taking its own rows of a chunk that is as many times longer (no wave idles on schemas of 33..128 columns).
+__host__ __device__ inline uint32_t p2_waves_per_batch(uint32_t nbatch) { return nbatch <= 1 ? 4u : (nbatch == 2 ? 2u : 1u); }
+
 // ---- staged form: the workgroup streams the chunk's records (rows row0 - 1 .. row0 + rows - 1, one contiguous
 // piece of the matrix) into LDS with coalesced 16-byte loads and the lanes pick their columns from there.  Lane =
 // column loads straight from HBM reach half the rate of a streaming read (8 bytes per lane at a 4..8-byte pitch).
@@ -188,42 +192,49 @@ __global__ __launch_bounds__(256) void k_pass2_size_cols(const Pass2Args a)
 {
     constexpr uint32_t P2_R = P2_R_SIZE;
     extern __shared__ __attribute__((aligned(16))) uint8_t p2s_lds[];
-    uint16_t *tot = reinterpret_cast<uint16_t *>(p2s_lds);          // [P2_R][nbatch]
-    uint8_t *stage = p2s_lds + ((P2_R * ((a.nused + 63) >> 6) * 2u + 15u) & ~15u);
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nflag = (a.nused + 7) >> 3;
     const uint32_t nbatch = (a.nused + 63) >> 6;
-    const uint32_t nchunks = (a.nrows + P2_R - 1) / P2_R;
-    const ColFacts f0 = col_facts(a, 64 * wv + lane);          // the wave's first batch is the same in every chunk
+    const uint32_t wpb = p2_waves_per_batch(nbatch), nbe = 4u / wpb;      // waves per batch; batches handled side by side
+    const uint32_t CR = P2_R * wpb;                                          // rows per chunk
+    uint16_t *tot = reinterpret_cast<uint16_t *>(p2s_lds);                  // [CR][nbatch]
+    uint8_t *stage = p2s_lds + ((CR * nbatch * 2u + 15u) & ~15u);
+    const uint32_t nchunks = (a.nrows + CR - 1) / CR;
+    const uint32_t b0 = wv % nbe, sub = wv / nbe;
+    const ColFacts f0 = col_facts(a, 64 * b0 + lane);          // the wave's first batch is the same in every chunk
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const uint32_t row0 = chunk * P2_R;
-        const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
+        const uint32_t crow0 = chunk * CR;
+        const uint32_t crows = a.nrows - crow0 < CR ? a.nrows - crow0 : CR;
         uint32_t at0 = 0;
-        if (STAGED) { at0 = stage_chunk(a, stage, row0, rows); __syncthreads(); }
-        for (uint32_t b = wv; b < nbatch; b += 4) {
+        if (STAGED) { at0 = stage_chunk(a, stage, crow0, crows); __syncthreads(); }
+        // this wave's rows of the chunk
+        const uint32_t r0 = sub * P2_R;
+        const uint32_t row0 = crow0 + r0;
+        const uint32_t rows = crows > r0 ? (crows - r0 < P2_R ? crows - r0 : P2_R) : 0u;
+        for (uint32_t b = b0; b < nbatch && rows; b += nbe) {
             const uint32_t u = 64 * b + lane;
-            const ColFacts f = b == wv ? f0 : col_facts(a, u);
+            const ColFacts f = b == b0 ? f0 : col_facts(a, u);
             uint64_t v[P2_R + 1];
-            if (STAGED) load_column_staged<P2_R>(stage, at0, a.rec_stride, f, row0, rows, v);
+            if (STAGED) load_column_staged<P2_R>(stage, at0 + r0 * a.rec_stride, a.rec_stride, f, row0, rows, v);
             else load_column<P2_R>(a, f, row0, rows, v);
 #pragma unroll
             for (uint32_t r = 0; r < P2_R; ++r) {
                 bool flag = v[r + 1] != v[r];
                 if (row0 + r == 0 && f.ok) flag = stored_from_raw(a, v[1], u, f.text) != a.prev0[u];     // the halo row arrives as stored values
                 const uint32_t t = lane_value(wave_incl_sum(flag ? f.sz : 0u), 63);
-                if (lane == 0) tot[r * nbatch + b] = (uint16_t)t;
+                if (lane == 0) tot[(r0 + r) * nbatch + b] = (uint16_t)t;
             }
         }
         __syncthreads();
-        if (threadIdx.x < rows) {
+        if (threadIdx.x < crows) {
             const uint32_t r = threadIdx.x;
             uint32_t run = 0;
             for (uint32_t b = 0; b < nbatch; ++b) {
                 const uint32_t t = tot[r * nbatch + b];
-                a.batch_pre[(uint64_t)(row0 + r) * nbatch + b] = (uint16_t)run;
+                a.batch_pre[(uint64_t)(crow0 + r) * nbatch + b] = (uint16_t)run;
                 run += t;
             }
-            a.row_len[row0 + r] = nflag + run;
+            a.row_len[crow0 + r] = nflag + run;
         }
         __syncthreads();
     }
@@ -347,42 +358,54 @@ template <uint32_t P2_R>
 __global__ __launch_bounds__(256, P2_R == 8 ? 7 : 4) void k_pass2_emit_cols_piped(const Pass2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t p2_lds[];
-    uint8_t *stage = p2_lds + ((P2_R * a.out_row_max + 32u + 15u) & ~15u);
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nflag = (a.nused + 7) >> 3;
     const uint32_t nbatch = (a.nused + 63) >> 6;
-    const uint32_t nchunks = (a.nrows + P2_R - 1) / P2_R;
+    const uint32_t wpb = p2_waves_per_batch(nbatch), nbe = 4u / wpb;      // waves per batch; batches side by side
+    const uint32_t CR = P2_R * wpb;                                          // rows per chunk
+    uint8_t *stage = p2_lds + ((CR * a.out_row_max + 32u + 15u) & ~15u);
+    const uint32_t nchunks = (a.nrows + CR - 1) / CR;
     if (blockIdx.x >= nchunks) return;
-    const bool have = wv < nbatch;
-    const ColFacts f = col_facts(a, 64 * wv + lane);           // the wave's batch is the same in every chunk
+    const uint32_t b = wv % nbe, sub = wv / nbe, r0 = sub * P2_R;           // this wave: batch b, rows r0 .. r0 + P2_R - 1 of a chunk
+    const bool have = b < nbatch;
+    const ColFacts f = col_facts(a, 64 * b + lane);            // the wave's batch is the same in every chunk
+    // per chunk, per lane: ro = row_off[first row of the wave + lane] for lane <= rows of the wave; lanes 62 / 63: the chunk's
+    // first and end offsets.  pre = batch_pre[row][b] for lane < rows of the wave.
+    auto chunk_rows = [&](uint32_t crow0) { return a.nrows - crow0 < CR ? a.nrows - crow0 : CR; };
+    auto wave_rows = [&](uint32_t crows) { return crows > r0 ? (crows - r0 < P2_R ? crows - r0 : P2_R) : 0u; };
+    auto load_ro = [&](uint32_t crow0, uint32_t crows, uint32_t rows) -> uint64_t {
+        if (lane == 62) return a.row_off[crow0];
+        if (lane == 63) return a.row_off[crow0 + crows];
+        return (rows && lane <= rows) ? a.row_off[crow0 + r0 + lane] : 0ull;
+    };
     uint32_t at0;
-    uint64_t ro;            // lane l <= rows: row_off[row0 + l]
-    uint32_t pre;           // lane l < rows: batch_pre[row0 + l][wv]
+    uint64_t ro;
+    uint32_t pre;
     {
-        const uint32_t row0 = blockIdx.x * P2_R, rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
-        at0 = stage_chunk(a, stage, row0, rows);
-        ro = lane <= rows ? a.row_off[row0 + lane] : 0ull;
-        pre = (have && lane < rows) ? a.batch_pre[(uint64_t)(row0 + lane) * nbatch + wv] : 0u;
+        const uint32_t crow0 = blockIdx.x * CR, crows = chunk_rows(crow0), rows = wave_rows(crows);
+        at0 = stage_chunk(a, stage, crow0, crows);
+        ro = load_ro(crow0, crows, rows);
+        pre = (have && lane < rows) ? a.batch_pre[(uint64_t)(crow0 + r0 + lane) * nbatch + b] : 0u;
         __syncthreads();
     }
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const uint32_t row0 = chunk * P2_R;
-        const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
-        const uint64_t base = ((uint64_t)lane_value((uint32_t)(ro >> 32), 0) << 32) | lane_value((uint32_t)ro, 0);
-        const uint32_t nbytes = lane_value((uint32_t)ro, (int)rows) - (uint32_t)base;        // a chunk is far below 4 GiB
+        const uint32_t crow0 = chunk * CR, crows = chunk_rows(crow0);
+        const uint32_t row0 = crow0 + r0, rows = wave_rows(crows);
+        const uint64_t base = ((uint64_t)lane_value((uint32_t)(ro >> 32), 62) << 32) | lane_value((uint32_t)ro, 62);
+        const uint32_t nbytes = lane_value((uint32_t)ro, 63) - (uint32_t)base;        // a chunk is far below 4 GiB
         const uint32_t shift = (uint32_t)base & 15u;
         const uint32_t my_at = (uint32_t)ro - (uint32_t)base + shift, my_pre = pre;
         uint64_t v[P2_R + 1];
-        load_column_staged<P2_R>(stage, at0, a.rec_stride, f, row0, rows, v);
+        load_column_staged<P2_R>(stage, at0 + r0 * a.rec_stride, a.rec_stride, f, row0, rows, v);
         // request the next chunk's records, row offsets and prefixes
         const uint32_t next = chunk + gridDim.x;
         const bool more = next < nchunks;
-        const uint32_t nrow0 = more ? next * P2_R : row0;
-        const uint32_t nrows = a.nrows - nrow0 < P2_R ? a.nrows - nrow0 : P2_R;
-        const uint32_t nfirst = nrow0 ? nrow0 - 1 : 0;
+        const uint32_t ncrow0 = more ? next * CR : crow0;
+        const uint32_t ncrows = chunk_rows(ncrow0), nrows_w = wave_rows(ncrows);
+        const uint32_t nfirst = ncrow0 ? ncrow0 - 1 : 0;
         const uint8_t *src = a.rec + (uint64_t)nfirst * a.rec_stride;
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u);
-        const uint32_t sbytes = more ? mis + (nrow0 + nrows - nfirst) * a.rec_stride : 0u;
+        const uint32_t sbytes = more ? mis + (ncrow0 + ncrows - nfirst) * a.rec_stride : 0u;
         const uint8_t *src16 = src - mis;
         uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0;
         const uint32_t o0 = threadIdx.x * 16u;
@@ -390,16 +413,16 @@ __global__ __launch_bounds__(256, P2_R == 8 ? 7 : 4) void k_pass2_emit_cols_pipe
         if (o0 + 4096u < sbytes) g1 = *reinterpret_cast<const uint4 *>(src16 + o0 + 4096u);
         if (o0 + 8192u < sbytes) g2 = *reinterpret_cast<const uint4 *>(src16 + o0 + 8192u);
         if (o0 + 12288u < sbytes) g3 = *reinterpret_cast<const uint4 *>(src16 + o0 + 12288u);
-        ro = (more && lane <= nrows) ? a.row_off[nrow0 + lane] : 0ull;
-        pre = (more && have && lane < nrows) ? a.batch_pre[(uint64_t)(nrow0 + lane) * nbatch + wv] : 0u;
+        ro = more ? load_ro(ncrow0, ncrows, nrows_w) : 0ull;
+        pre = (more && have && lane < nrows_w) ? a.batch_pre[(uint64_t)(ncrow0 + r0 + lane) * nbatch + b] : 0u;
 
-        if (have) emit_batch<P2_R>(a, p2_lds, wv, lane, f, v, row0, rows, my_at, my_pre, nflag);
+        if (have && rows) emit_batch<P2_R>(a, p2_lds, b, lane, f, v, row0, rows, my_at, my_pre, nflag);
         lds_barrier();          // the image is complete; every wave has read its columns from the staging buffer
         if (o0 < sbytes) *reinterpret_cast<uint4 *>(stage + o0) = g0;
         if (o0 + 4096u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 4096u) = g1;
         if (o0 + 8192u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 8192u) = g2;
         if (o0 + 12288u < sbytes) *reinterpret_cast<uint4 *>(stage + o0 + 12288u) = g3;
-        at0 = mis + (nrow0 - nfirst) * a.rec_stride;
+        at0 = mis + (ncrow0 - nfirst) * a.rec_stride;
         copy_image_out(a, p2_lds, base, shift, nbytes);
         lds_barrier();          // the image has been read, the next chunk's records are in place
     }
@@ -419,9 +442,10 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
         const uint32_t nbatch = (a.nused + 63) / 64;
         const bool direct = getenv("ZDW_P2_DIRECT") != nullptr;      // (the variables here: A/B measurements)
         if (!EMIT) {
-            const bool staged = !direct && p2_stage_bytes(P2_R_SIZE, a.rec_stride) <= P2_STAGE_BUDGET;
-            const uint64_t want = ((uint64_t)a.nrows + P2_R_SIZE - 1) / P2_R_SIZE;
-            const uint32_t lds = ((P2_R_SIZE * nbatch * 2u + 15u) & ~15u) + (staged ? p2_stage_bytes(P2_R_SIZE, a.rec_stride) : 0u);
+            const uint32_t CR = P2_R_SIZE * p2_waves_per_batch(nbatch);          // rows per chunk
+            const bool staged = !direct && p2_stage_bytes(CR, a.rec_stride) <= P2_STAGE_BUDGET;
+            const uint64_t want = ((uint64_t)a.nrows + CR - 1) / CR;
+            const uint32_t lds = ((CR * nbatch * 2u + 15u) & ~15u) + (staged ? p2_stage_bytes(CR, a.rec_stride) : 0u);
             const void *fn = staged ? (const void *)k_pass2_size_cols<true> : (const void *)k_pass2_size_cols<false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
             uint32_t per_cu = std::min(6u, (uint32_t)occ);      // six workgroups per CU measured best (8: 1.36x the time)
@@ -432,13 +456,15 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
         } else {
             uint32_t R = 8;
             if (const char *e = getenv("ZDW_P2_EMIT_ROWS")) R = atoi(e) == 16 ? 16u : 8u;
-            uint32_t mode = 0;
+            uint32_t mode = 0, CR = R;                                  // rows per chunk
             if (!direct && !getenv("ZDW_P2_EMIT_DIRECT") && p2_stage_bytes(R, a.rec_stride) <= P2_STAGE_BUDGET) {
                 mode = 1;
-                if (nbatch <= 4 && p2_stage_bytes(R, a.rec_stride) <= 4u * 4096u && !getenv("ZDW_P2_EMIT_NOPIPE")) mode = 2;
+                const uint32_t CRp = R * p2_waves_per_batch(nbatch);
+                if (nbatch <= 4 && p2_stage_bytes(CRp, a.rec_stride) <= 4u * 4096u && CRp * a.out_row_max + 32u <= P2_LDS_BUDGET &&
+                    !getenv("ZDW_P2_EMIT_NOPIPE")) { mode = 2; CR = CRp; }
             }
-            const uint64_t want = ((uint64_t)a.nrows + R - 1) / R;
-            const uint32_t lds = ((R * a.out_row_max + 32u + 15u) & ~15u) + (mode ? p2_stage_bytes(R, a.rec_stride) : 0u);
+            const uint64_t want = ((uint64_t)a.nrows + CR - 1) / CR;
+            const uint32_t lds = ((CR * a.out_row_max + 32u + 15u) & ~15u) + (mode ? p2_stage_bytes(CR, a.rec_stride) : 0u);
             typedef void (*EmitFn)(const Pass2Args);
             static const EmitFn fns[2][3] = {{k_pass2_emit_cols<false, 8>, k_pass2_emit_cols<true, 8>, k_pass2_emit_cols_piped<8>},
                                              {k_pass2_emit_cols<false, 16>, k_pass2_emit_cols<true, 16>, k_pass2_emit_cols_piped<16>}};
