@@ -9,12 +9,14 @@
 //
 // Two launches: row lengths (then an exclusive scan gives each row's output offset), then emit.
 //
-// Wide schemas (more than 32 used columns, G = 64): one wave per row, lane = column.  All of a row's
-// loads (this row and the one above, up to 256 columns) are issued before anything is looked at; the
-// dictionary gathers of the row likewise.  The emit kernel assembles a chunk of rows in LDS and writes
-// it out with aligned 16-byte stores (the byte-granular scatter of the values stays inside the LDS).
+// Column kernels (17 or more used columns; the size kernel from 8): a workgroup takes a chunk of rows, a wave a
+// 64-column batch of it (lane = column; with fewer than three batches several waves share one and split the rows),
+// so "the row above" is what the lane read one step earlier.  The chunk's records are streamed through LDS with
+// coalesced 16-byte loads; the dictionary gathers of a chunk are in flight together; the emit kernel assembles the
+// chunk's rows in LDS and writes them out with aligned 16-byte stores (the byte-granular scatter of the values
+// stays inside the LDS) while the next chunk's records are on their way.
 //
-// Narrow schemas: a row is handled by G = pow2 >= used columns adjacent lanes (64/G rows per wave):
+// Very narrow schemas: a row is handled by G = pow2 >= used columns adjacent lanes (64/G rows per wave):
 // flag bits come from one wave ballot, the byte position of each value from a G-lane prefix sum.
 #include "zdw_dev.h"
 #include "zdw_kernels.h"
@@ -434,7 +436,12 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
     if (!a.nrows) return;
     uint32_t g = 1;
     while (g < 64 && g < a.nused) g <<= 1;
-    if (g == 64 && P2_R_MAX * a.out_row_max + 32u <= P2_LDS_BUDGET && a.batch_pre) {
+    // Which kernels: the lane = column kernels need not be full to win.  Measured per 4 GB, G-lanes-per-row kernels vs column
+    // kernels: 32 columns 1.9 + 3.0 vs 0.85 + 2.1 ms (size + emit), 20: 2.9 + 4.5 vs 1.1 + 3.1, 16: 1.9 + 3.0 vs 1.4 + 3.8,
+    // 9: 3.2 + 4.8 vs 2.2 + 6.3, 6: 2.7 + 3.8 vs 3.4 + 9.3.
+    uint32_t min_cols = EMIT ? 17u : 8u;
+    if (const char *e = getenv("ZDW_P2_COLS_MIN")) min_cols = (uint32_t)atoi(e);      // (A/B measurements)
+    if (a.nused >= min_cols && P2_R_MAX * a.out_row_max + 32u <= P2_LDS_BUDGET && a.batch_pre) {
         // wide schema: persistent grids sized to what is resident
         int dev = 0, cus = 256, occ = 0;
         (void)hipGetDevice(&dev);
