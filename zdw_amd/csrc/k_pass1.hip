@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void k_pass1_deferred(const Pass1Args a, uint3
         const uint64_t mm = __ballot(mine);
         if (mine) {
             const uint32_t row = (uint32_t)(w1 >> 32);
-            process_field_general(a, t, d, al, w0 & POS_MASK, (uint32_t)w1, (uint32_t)(w0 >> 40), row, row < a.row_limit, is_new);
+            process_field_general<true>(a, t, d, al, w0 & POS_MASK, (uint32_t)w1, (uint32_t)(w0 >> 40), row, row < a.row_limit, is_new);
         }
         if (mm) adopt_ids(al, mm);
         created += popc64(__ballot(is_new));

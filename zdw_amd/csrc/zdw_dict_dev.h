@@ -52,6 +52,18 @@ __device__ __forceinline__ uint64_t str_word(const uint8_t *p, uint32_t len, uin
     return i < len ? load_upto8(p + i, len - i < 8 ? len - i : 8u, end) : 0ull;
 }
 
+// The same without a branch (for loads that are to be in flight together): always one 8-byte load; when it would
+// cross `end` it is moved back to end - 8 and shifted (the allocation must hold at least 8 bytes).
+__device__ __forceinline__ uint64_t str_word_nb(const uint8_t *p, uint32_t len, uint32_t i, const uint8_t *end)
+{
+    const uint8_t *p8 = p + i;
+    const uint8_t *q = p8 + 8 <= end ? p8 : end - 8;
+    const uint64_t w = load8(q) >> ((8u * (uint32_t)(p8 - q)) & 63u);
+    const uint32_t want = i < len ? (len - i < 8u ? len - i : 8u) : 0u;
+    const uint64_t mask = want >= 8u ? ~0ull : ((1ull << (8u * want)) - 1ull);
+    return w & mask;
+}
+
 // ---- placement hash: NH (UMAC) over the zero-padded string, 24 bytes per step -------------------
 // (a + k)(b + k') on dword pairs costs one 32x32->64 multiply per EIGHT bytes; pass 1 evaluates the
 // first (for most strings: only) step from registers.
@@ -198,11 +210,38 @@ struct DictTable {
     P1Status *st;
 };
 
+// BULK: the string is read 96 bytes at a time with all twelve loads of a round in flight together, hashed and
+// compared from registers; the plain form reads 8 bytes at a time and waits for each (one memory latency per step:
+// 72 dependent loads per 60-byte string in a kernel that does nothing else).  Costs ~40 VGPRs: for kernels that
+// only do this.
+constexpr uint32_t BULK_WORDS = 12;           // 96 bytes = four 24-byte hash steps per round
+template <bool BULK = false>
 __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, const uint8_t *in, uint64_t n, const uint8_t *extra, uint64_t hi,
                                        const DictTable &d, IdAlloc &al, uint32_t id_extra, uint64_t pos, uint32_t len, bool trim, bool &is_new)
 {
-    const uint64_t c0 = str_word(p, len, 0, end), c1 = str_word(p, len, 8, end), c2 = str_word(p, len, 16, end);
-    const uint64_t acc = nh_string(p, len, end, c0, c1, c2);
+    const bool bulk = BULK && end - p >= 8 && n >= 8;          // (the branch-free loads need 8 bytes of allocation)
+    uint64_t c0, c1, c2, acc;
+    if (BULK && bulk) {
+        c0 = c1 = c2 = acc = 0;
+        for (uint32_t base = 0; base < len; base += 8u * BULK_WORDS) {
+            uint64_t cw[BULK_WORDS];
+#pragma unroll
+            for (uint32_t k = 0; k < BULK_WORDS; ++k) cw[k] = base + 8u * k < len ? str_word_nb(p, len, base + 8u * k, end) : 0ull;
+            if (base == 0) { c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; }
+#pragma unroll
+            for (uint32_t j = 0; j < BULK_WORDS / 3; ++j) {
+                const uint32_t off = base + 24u * j;
+                if (off == 0) acc = nh24(cw[0], cw[1], cw[2]);
+                else if (off < len) {
+                    acc = (acc ^ (acc >> 31)) * 0xff51afd7ed558ccdull;
+                    acc += nh24(cw[3 * j], cw[3 * j + 1], cw[3 * j + 2]);
+                }
+            }
+        }
+    } else {
+        c0 = str_word(p, len, 0, end); c1 = str_word(p, len, 8, end); c2 = str_word(p, len, 16, end);
+        acc = nh_string(p, len, end, c0, c1, c2);
+    }
     const uint32_t tag = hash_tag(acc), len8 = len < 255u ? len : 255u;
     if (len > 24u && len > d.st->max_len) atomicMax(&d.st->max_len, len);
     uint64_t i = hash_place(acc) & d.slot_mask;
@@ -241,9 +280,20 @@ __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, con
                     const uint8_t *q = string_at(in, extra, sp);
                     const uint8_t *q_end = is_extra ? q + len + 16 : in + n;      // imported strings carry >= 16 bytes of slack
                     bool eq = true;
-                    for (uint32_t k = from; k < len && eq; k += 8) {
-                        const uint32_t want = len - k < 8 ? len - k : 8u;
-                        eq = load_upto8(q + k, want, q_end) == load_upto8(p + k, want, end);
+                    if (BULK && bulk) {
+                        // bytes [24, len) of both strings, a round of up to 96 bytes of each in flight at a time
+                        uint64_t diff = 0;
+                        for (uint32_t base = 24; base < len && diff == 0; base += 8u * BULK_WORDS) {
+#pragma unroll
+                            for (uint32_t k = 0; k < BULK_WORDS; ++k)
+                                diff |= base + 8u * k < len ? str_word_nb(q, len, base + 8u * k, q_end) ^ str_word_nb(p, len, base + 8u * k, end) : 0ull;
+                        }
+                        eq = diff == 0;
+                    } else {
+                        for (uint32_t k = from; k < len && eq; k += 8) {
+                            const uint32_t want = len - k < 8 ? len - k : 8u;
+                            eq = load_upto8(q + k, want, q_end) == load_upto8(p + k, want, end);
+                        }
                     }
                     if (eq && len8 == 255u) {
                         if (is_extra) eq = q[len] == 0;

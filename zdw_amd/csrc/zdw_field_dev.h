@@ -91,6 +91,7 @@ __device__ __forceinline__ void mark_seen(const Pass1Args &a, const ColTables &t
 // ------------------------------------------------------------------------------------------
 // one field, general form (field bytes in global memory at a.in + fs)
 // ------------------------------------------------------------------------------------------
+template <bool BULK = false>
 __device__ inline void process_field_general(const Pass1Args &a, const ColTables &t, const DictTable &d, IdAlloc &al, uint64_t fs, uint32_t len,
                                              uint32_t col, uint32_t row, bool in_block, bool &is_new)
 {
@@ -113,7 +114,7 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
     if (__ballot(want)) {
         uint32_t id = 0;
         const uint64_t wm = __ballot(want);
-        if (want) id = dict_insert(p, a.in + a.n, a.in, a.n, a.extra, a.hi, d, al, ID_CHUNK, fs, len, a.trim != 0, is_new);
+        if (want) id = dict_insert<BULK>(p, a.in + a.n, a.in, a.n, a.extra, a.hi, d, al, ID_CHUNK, fs, len, a.trim != 0, is_new);
         adopt_ids(al, wm);
         if (want && in_block) *reinterpret_cast<uint32_t *>(recp) = id;
     }
