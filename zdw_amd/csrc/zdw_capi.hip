@@ -26,8 +26,11 @@ struct DevBuf {
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap && p) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes < 256 ? 256 : bytes;
+        // A buffer that has to grow gets an eighth more than asked: sizes that follow the number of unique ids jitter
+        // by a few hundred from pass to pass (which wave wins which race), and every regrowth is a hipFree (a device
+        // synchronisation) plus a hipMalloc in the middle of a block.
+        if (p) { want += want / 8; (void)hipFree(p); p = nullptr; cap = 0; }
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want; else p = nullptr;
         return e;
