@@ -182,15 +182,28 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
                 const uint4 v = nxt;
                 nxt = load_round16(in, pos + WROUND, lane, n);            // next round in flight while this one is counted
                 const uint64_t lp = pos + 16ull * lane;
-                {
-                    // common case -- the round lies inside the span and holds no backslash: count in place on the
-                    // bit-7 flags of the SWAR compares (no compaction to 16-bit sets)
+                if (pos >= ss && pos + WROUND <= se) {
+                    // common case -- the round lies inside the span and no newline of it follows a backslash (so every
+                    // newline is a row terminator): count in place on the bit-7 flags of the SWAR compares (no compaction
+                    // to 16-bit sets)
                     const uint32_t H = 0x80808080u, L1 = 0x01010101u;
+                    const uint32_t n0 = ~nz7b(v.x ^ 0x0a0a0a0au) & H, n1 = ~nz7b(v.y ^ 0x0a0a0a0au) & H, n2 = ~nz7b(v.z ^ 0x0a0a0a0au) & H,
+                                   n3 = ~nz7b(v.w ^ 0x0a0a0a0au) & H;                           // bit 7 of a byte: it is a newline
                     const uint32_t b0 = v.x ^ 0x5c5c5c5cu, b1 = v.y ^ 0x5c5c5c5cu, b2 = v.z ^ 0x5c5c5c5cu, b3 = v.w ^ 0x5c5c5c5cu;
                     const uint32_t anybs = (((b0 - L1) & ~b0) | ((b1 - L1) & ~b1) | ((b2 - L1) & ~b2) | ((b3 - L1) & ~b3)) & H;     // exact for "some byte is a backslash"
-                    if (!(__ballot(anybs != 0) | bs_carry) && pos >= ss && pos + WROUND <= se) {
-                        const uint32_t n0 = ~nz7b(v.x ^ 0x0a0a0a0au) & H, n1 = ~nz7b(v.y ^ 0x0a0a0a0au) & H, n2 = ~nz7b(v.z ^ 0x0a0a0a0au) & H,
-                                       n3 = ~nz7b(v.w ^ 0x0a0a0a0au) & H;                       // bit 7 of a byte: it is a newline
+                    bool plain = true;
+                    uint32_t carry_next = 0;
+                    if (__ballot(anybs != 0) | bs_carry) {
+                        // backslashes about: is one of them right before a newline?
+                        const uint32_t s0 = ~nz7b(b0) & H, s1 = ~nz7b(b1) & H, s2 = ~nz7b(b2) & H, s3 = ~nz7b(b3) & H;   // bit 7: the byte is a backslash
+                        uint32_t sbefore = wave_shr1(s3);
+                        if (lane == 0) sbefore = bs_carry ? 0x80000000u : 0u;
+                        const uint32_t hit = (n0 & __builtin_amdgcn_alignbit(s0, sbefore, 24)) | (n1 & __builtin_amdgcn_alignbit(s1, s0, 24)) |
+                                             (n2 & __builtin_amdgcn_alignbit(s2, s1, 24)) | (n3 & __builtin_amdgcn_alignbit(s3, s2, 24));
+                        plain = __ballot(hit != 0) == 0;
+                        carry_next = lane_value(s3 >> 31, 63);
+                    }
+                    if (plain) {
                         uint32_t before = wave_shr1(n3);                                          // the byte before my first one
                         if (lane == 0) before = prev_term ? 0x80000000u : 0u;
                         // "the previous byte is a newline" for each of my bytes, then: a row starts where that holds and the byte is none
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
                               + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n3, n2, 24) & ~n3);
                         nul |= (((v.x - L1) & ~v.x) | ((v.y - L1) & ~v.y) | ((v.z - L1) & ~v.z) | ((v.w - L1) & ~v.w)) & H;        // exact for "some byte is NUL"
                         prev_term = lane_value(n3 >> 31, 63);
+                        bs_carry = carry_next;
                         continue;
                     }
                 }
