@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
 // Lane = column, so "the row above" is the value the lane loaded one step earlier: the record matrix is
 // read once, and all loads of a chunk (P2_R + 1 per lane) are in flight together.
 constexpr uint32_t P2_R_SIZE = 16;              // rows per chunk, size kernel
-constexpr uint32_t P2_R_MAX = 16;               // rows per chunk, emit kernel: 16 or 8 (chosen at launch)
+                                                // (emit kernel: 8 rows per wave, 4 for very wide rows, 16 on request: chosen at launch)
 constexpr uint32_t P2_LDS_BUDGET = 40 * 1024;    // output image of one row chunk (emit)
 
 struct ColFacts { uint32_t off; uint32_t sz; bool text; bool ok; };
@@ -357,7 +357,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // LDS between the image barrier and the copy-out.  The barriers order LDS only: the copy-out stores are never
 // waited for inside the loop.
 template <uint32_t P2_R>
-__global__ __launch_bounds__(256, P2_R == 8 ? 7 : 4) void k_pass2_emit_cols_piped(const Pass2Args a)
+__global__ __launch_bounds__(256, P2_R <= 8 ? 7 : 4) void k_pass2_emit_cols_piped(const Pass2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t p2_lds[];
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
@@ -441,7 +441,9 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
     // 9: 3.2 + 4.8 vs 2.2 + 6.3, 6: 2.7 + 3.8 vs 3.4 + 9.3.
     uint32_t min_cols = EMIT ? 17u : 8u;
     if (const char *e = getenv("ZDW_P2_COLS_MIN")) min_cols = (uint32_t)atoi(e);      // (A/B measurements)
-    if (a.nused >= min_cols && P2_R_MAX * a.out_row_max + 32u <= P2_LDS_BUDGET && a.batch_pre) {
+    // (the emit kernel's LDS image: 8 rows of output, or 4 when rows are very wide; the size kernel has none)
+    const uint32_t size_tot_lds = P2_R_SIZE * p2_waves_per_batch((a.nused + 63) / 64) * ((a.nused + 63) / 64) * 2u;      // size kernel: u16 per (row, batch)
+    if (a.nused >= min_cols && a.batch_pre && (EMIT ? 4u * a.out_row_max + 32u <= P2_LDS_BUDGET : size_tot_lds <= P2_LDS_BUDGET)) {
         // wide schema: persistent grids sized to what is resident
         int dev = 0, cus = 256, occ = 0;
         (void)hipGetDevice(&dev);
@@ -462,7 +464,9 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
             else hipLaunchKernelGGL(k_pass2_size_cols<false>, dim3(grid), dim3(256), lds, s, a);
         } else {
             uint32_t R = 8;
-            if (const char *e = getenv("ZDW_P2_EMIT_ROWS")) R = atoi(e) == 16 ? 16u : 8u;
+            if (8u * a.out_row_max + 32u > P2_LDS_BUDGET) R = 4;     // very wide rows: fewer of them per chunk
+            // (1000 columns, 4 GB: 8 rows straight from HBM 2.08 ms, 4 rows staged 2.78, G-lanes-per-row kernel 2.52)
+            if (const char *e = getenv("ZDW_P2_EMIT_ROWS")) R = atoi(e) == 16 ? 16u : (atoi(e) == 4 ? 4u : 8u);
             uint32_t mode = 0, CR = R;                                  // rows per chunk
             if (!direct && !getenv("ZDW_P2_EMIT_DIRECT") && p2_stage_bytes(R, a.rec_stride) <= P2_STAGE_BUDGET) {
                 mode = 1;
@@ -473,9 +477,10 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
             const uint64_t want = ((uint64_t)a.nrows + CR - 1) / CR;
             const uint32_t lds = ((CR * a.out_row_max + 32u + 15u) & ~15u) + (mode ? p2_stage_bytes(CR, a.rec_stride) : 0u);
             typedef void (*EmitFn)(const Pass2Args);
-            static const EmitFn fns[2][3] = {{k_pass2_emit_cols<false, 8>, k_pass2_emit_cols<true, 8>, k_pass2_emit_cols_piped<8>},
-                                             {k_pass2_emit_cols<false, 16>, k_pass2_emit_cols<true, 16>, k_pass2_emit_cols_piped<16>}};
-            const EmitFn fn = fns[R == 16][mode];
+            static const EmitFn fns[3][3] = {{k_pass2_emit_cols<false, 8>, k_pass2_emit_cols<true, 8>, k_pass2_emit_cols_piped<8>},
+                                             {k_pass2_emit_cols<false, 16>, k_pass2_emit_cols<true, 16>, k_pass2_emit_cols_piped<16>},
+                                             {k_pass2_emit_cols<false, 4>, k_pass2_emit_cols<true, 4>, k_pass2_emit_cols_piped<4>}};
+            const EmitFn fn = fns[R == 16 ? 1 : (R == 4 ? 2 : 0)][mode];
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
             // measured (10 GB x 200 columns): staged 8-row chunks 5 / 6 / 7 / 8 workgroups per CU = 5.5 / 4.9 / 4.5 / 6.7 ms
             uint32_t per_cu = std::min(mode ? 7u : 6u, (uint32_t)occ);
