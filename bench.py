@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--word-maxlen", type=int, default=24, help="longest vocabulary word (24 = BASELINE's table; more: not a valid bench line)")
+    ap.add_argument("--independent-blocks", action="store_true",
+                    help="N > 1: every rank writes its rows as its own ZDW block (own dictionary, no exchange; a different, equally valid file: "
+                         "SURVEY 8f-3) instead of one block row-sharded over the ranks")
     ap.add_argument("--pass1-only", action="store_true", help="profiling: time pass 1 alone (not a valid bench line)")
     args = ap.parse_args()
 
@@ -141,6 +144,9 @@ def main():
     enc.enable_timing(True)
 
     def step():
+        if world > 1 and args.independent_blocks:
+            blocks = sharded.encode_independent_blocks_dist(enc, rank, world, fetch=False)
+            return sum(b[0] for b in blocks), sum(b[1] for b in blocks), sum(b[2] for b in blocks)
         if world > 1:
             return sharded.encode_shard_dist(enc, rank, world, merge=merge)
         rc, p1 = enc.pass1()
@@ -205,7 +211,8 @@ def main():
                                    % (nbytes / 1e9, args.cols),
                        "rows_per_gpu": int(nrows), "input_bytes_per_gpu": int(nbytes), "zdw_bytes_per_gpu": int(out_local),
                        "compression_ratio": round(nbytes / max(1, out_local), 3),
-                       "parallelism": "one ZDW block row-sharded over %d GPU(s)" % world},
+                       "parallelism": ("one ZDW block per GPU, %d GPUs, independent dictionaries (not the single-block file)" % world)
+                                      if (world > 1 and args.independent_blocks) else "one ZDW block row-sharded over %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": int(alg),

@@ -93,3 +93,9 @@ def test_pure_merges():
     assert t.tolist() == sorted(t.tolist())              # unsigned order survives as signed order
     assert sharded.ordered_i64_to_u64(t) == vals
     assert sharded.chain_prev_rows([[1], [2], [3]], [4, 0, 5]) == [None, [1], [1]]
+
+
+def test_chain_longest_lines():
+    """the reference's line buffer only grows: block i's header carries the largest of shards 0..i"""
+    assert sharded.chain_longest_lines([16384, 65536, 16384, 32768, 131072, 16384]) == [16384, 65536, 65536, 65536, 131072, 131072]
+    assert sharded.chain_longest_lines([]) == []

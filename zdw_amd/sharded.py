@@ -155,6 +155,81 @@ def encode_shards_local(encoders, device="cuda"):
     return blocks
 
 
+# ------------------------------------------------------------------------------------------------
+# Independent blocks: every shard's rows become their own ZDW block(s) with their own dictionary.
+# No dictionary exchange at all; the file is NOT the one the reference writes for the whole input in one block
+# (it is the one it writes when it ends a block at every shard boundary, which its memory limit may do anywhere),
+# and every ZDW reader takes it: several blocks per file are part of the format.
+def chain_longest_lines(own):
+    """own[i] = m_LongestLine after shard i's rows alone.  The reference's line buffer only ever grows (doubling
+    from 16384 until a row fits, ConvertToZDW.cpp:965), so after shard i it holds the largest of shards 0..i."""
+    out, cur = [], 0
+    for v in own:
+        cur = max(cur, int(v))
+        out.append(cur)
+    return out
+
+
+def encode_independent_blocks_one(enc, fetch=True):
+    """All blocks of one shard's rows (normally one; more when its dictionary outgrows a block).
+    Returns ([capi.Block] or [(num_rows, dict_len, rows_len)], [Pass1Result])."""
+    from . import capi
+    blocks, p1s = [], []
+    while True:
+        if fetch:
+            rc, blk, p1 = enc.encode_block()
+            if rc:
+                raise capi.ZdwError(rc, "block encode failed")
+            if blk is None:
+                break
+            blocks.append(blk)
+        else:
+            rc, p1 = enc.pass1()
+            if rc:
+                raise capi.ZdwError(rc, "pass 1 failed")
+            if p1.num_rows == 0:
+                break
+            _, dlen, _ = enc.dict_section_device()
+            enc.stats()
+            _, rlen = enc.pass2_device()
+            blocks.append((p1.num_rows, dlen, rlen))
+        p1s.append(p1)
+        if p1.is_last_block:
+            break
+        enc.next_block()
+    return blocks, p1s
+
+
+def encode_independent_blocks_local(encoders):
+    """All shards in this process.  Returns the file's blocks in order (capi.Block, `is_last` and `longest_line`
+    as the one file needs them)."""
+    per = [encode_independent_blocks_one(e) for e in encoders]
+    flat = [b for blocks, _ in per for b in blocks]
+    caps = chain_longest_lines([b.longest_line for b in flat])
+    for i, b in enumerate(flat):
+        b.longest_line = caps[i]
+        b.is_last = i + 1 == len(flat)
+    return flat
+
+
+def encode_independent_blocks_dist(enc, rank, world, group=None, fetch=False):
+    """One rank's blocks.  One all-gather (block count and line-buffer size per rank) fixes the headers; the
+    data path has no collective.  Returns the rank's blocks (capi.Block with final headers when fetch=True,
+    else (num_rows, dict_len, rows_len) tuples with the outputs of the LAST block left in HBM)."""
+    device = "cuda:%d" % torch.cuda.current_device()
+    blocks, p1s = encode_independent_blocks_one(enc, fetch=fetch)
+    own_cap = max([p.longest_line for p in p1s] + [0])
+    allv = allgather_i64([len(blocks), own_cap], device, group=group)
+    before = max([v[1] for v in allv[:rank]] + [0])
+    last_rank_with_rows = max([r for r in range(world) if allv[r][0]] + [-1])
+    if fetch:
+        caps = chain_longest_lines([before] + [b.longest_line for b in blocks])[1:]
+        for i, b in enumerate(blocks):
+            b.longest_line = caps[i]
+            b.is_last = rank == last_rank_with_rows and i + 1 == len(blocks)
+    return blocks
+
+
 SAMPLES_PER_SHARD = 256
 
 
