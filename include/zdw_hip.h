@@ -138,6 +138,15 @@ int zdw_block_pass2(zdw_ctx *ctx, const uint8_t **rows, uint64_t *rows_len);
 int zdw_block_dict_device(zdw_ctx *ctx, const void **d_section, uint64_t *section_len, uint8_t *index_size);
 int zdw_block_pass2_device(zdw_ctx *ctx, const void **d_rows, uint64_t *rows_len);
 
+/* The same two outputs handed to a writer piece by piece (the reference writes them straight into the compressor's
+ * pipe, dictionary.cpp:76-111 and ConvertToZDW.cpp:486-606): `write` is called in order with consecutive pieces
+ * (host memory, valid during the call) and returns 0 to go on; while it runs, the next piece is already on its way
+ * from the device.  No host buffer of the output's size is needed.  A non-zero return of `write` stops the
+ * transfer and is returned as ZDW_UNKNOWN_ERROR (20). */
+typedef int (*zdw_write_fn)(void *user, const uint8_t *bytes, uint64_t len);
+int zdw_block_dict_write(zdw_ctx *ctx, zdw_write_fn write, void *user, uint64_t *section_len, uint8_t *index_size);
+int zdw_block_pass2_write(zdw_ctx *ctx, zdw_write_fn write, void *user, uint64_t *rows_len);
+
 /* uniques.clear(): drop the block's state; the next zdw_block_pass1 continues at bytes_consumed. */
 int zdw_block_next(zdw_ctx *ctx);
 

@@ -235,6 +235,13 @@ struct PhaseClock {
     }
 };
 
+// zdw_write_fn for the streamed outputs: straight into the compressor's pipe
+int writeToPipe(void *user, const uint8_t *bytes, uint64_t len)
+{
+    OutPipe *out = static_cast<OutPipe *>(user);
+    return out->put(bytes, static_cast<size_t>(len)) ? 0 : 1;
+}
+
 struct CtxGuard {
     zdw_ctx *ctx = nullptr;
     ~CtxGuard() { if (ctx) zdw_ctx_destroy(ctx); }
@@ -349,14 +356,14 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         bool forced = static_cast<size_t>(blocks - 1) < splitRows.size();
         if (forced) { hint.max_rows = splitRows[blocks - 1]; hint.partial_fields = splitFields[blocks - 1]; }
         zdw_pass1_result p1;
-        const uint8_t *section = NULL; uint64_t sectionLen = 0; uint8_t indexSize = 0;
+        uint64_t sectionLen = 0; uint8_t indexSize = 0;
         int rc;
         // A block whose dictionary outgrows its limit is redone with half the rows (the reference ends a
         // block for the same reason -- memory -- at a point that depends on the machine).
         for (;;) {
             rc = zdw_block_pass1(ctx, forced ? &hint : NULL, &p1);
             if (rc != ZDW_OK || p1.num_rows == 0) break;
-            rc = zdw_block_dict(ctx, &section, &sectionLen, &indexSize);
+            rc = zdw_block_dict_device(ctx, NULL, &sectionLen, &indexSize);     // built and measured on the device; written below
             if (rc != ZDW_OUT_OF_MEMORY || p1.num_rows < 2) break;
             forced = true;
             hint.max_rows = p1.num_rows / 2;
@@ -390,7 +397,8 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
                 statusOutput(INFO, "\nWriting dictionary:\n%u bytes being stored for %u unique entries.  Generating %d-byte offsets...\n",
                              static_cast<unsigned>(dictSize), static_cast<unsigned>(p1.dict_entries), indexSize ? indexSize : 1);
             }
-            ok = ok && out.put(section, sectionLen);
+            rc = zdw_block_dict_write(ctx, writeToPipe, &out, NULL, NULL);
+            if (rc != ZDW_OK) ok = false;
             clock.mark("write_dict");
             uint32_t used = 0;
             rc = zdw_block_stats(ctx, colSize.data(), colBase.data(), &used);
@@ -398,10 +406,9 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
                 ok = ok && out.put(colSize.data(), numColumns);
                 for (uint32_t u = 0; u < used; ++u) ok = ok && out.le(colBase[u], 8);
                 if (!bQuiet) statusOutput(INFO, "\nWriting rows\n");
-                const uint8_t *rowBytes = NULL; uint64_t rowLen = 0;
-                rc = zdw_block_pass2(ctx, &rowBytes, &rowLen);
+                rc = zdw_block_pass2_device(ctx, NULL, NULL);
                 clock.mark("stats+pass2");
-                if (rc == ZDW_OK) ok = ok && out.put(rowBytes, rowLen);
+                if (rc == ZDW_OK && zdw_block_pass2_write(ctx, writeToPipe, &out, NULL) != ZDW_OK) ok = false;
                 clock.mark("write_rows");
             }
         }

@@ -122,6 +122,8 @@ struct zdw_ctx {
     bool have_prev = false;
     uint64_t rows_len = 0;
     HostBuf h_dict, h_rows;
+    HostBuf h_piece[2];                    // zdw_block_*_write: two pinned pieces, one being written while the other arrives
+    hipEvent_t piece_ev[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
     std::vector<TimedSpan> spans;
@@ -505,6 +507,7 @@ void zdw_ctx_destroy(zdw_ctx *c)
                       &c->d_used_base, &c->d_prev0, &c->d_last, &c->row_len, &c->row_off, &c->rows_out, &c->batch_pre};
     for (DevBuf *b : bufs) b->release();
     c->h_dict.release(); c->h_rows.release();
+    for (int i = 0; i < 2; ++i) { c->h_piece[i].release(); if (c->piece_ev[i]) (void)hipEventDestroy(c->piece_ev[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -827,6 +830,63 @@ int zdw_block_pass2(zdw_ctx *c, const uint8_t **rows, uint64_t *rows_len)
     if (rows) *rows = static_cast<const uint8_t *>(c->h_rows.p);
     if (rows_len) *rows_len = len;
     return ZDW_OK;
+}
+
+namespace {
+constexpr uint64_t PIECE_BYTES = 32ull << 20;
+
+// device bytes [d, d + len) to `write`, double-buffered through pinned memory
+int stream_out(zdw_ctx *c, const uint8_t *d, uint64_t len, zdw_write_fn write, void *user)
+{
+    if (!len) return ZDW_OK;
+    hipStream_t s = c->stream;
+    const uint64_t piece = std::min<uint64_t>(PIECE_BYTES, len);
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(c, c->h_piece[i].ensure(piece));
+        if (!c->piece_ev[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->piece_ev[i], hipEventDisableTiming));
+    }
+    StageScope ts(c, ZDW_STAGE_D2H);
+    const uint64_t n = (len + piece - 1) / piece;
+    auto issue = [&](uint64_t k) -> hipError_t {
+        const uint64_t off = k * piece, m = std::min<uint64_t>(piece, len - off);
+        hipError_t e = hipMemcpyAsync(c->h_piece[k & 1].p, d + off, m, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(c->piece_ev[k & 1], s);
+    };
+    HIP_TRY(c, issue(0));
+    for (uint64_t k = 0; k < n; ++k) {
+        if (k + 1 < n) HIP_TRY(c, issue(k + 1));
+        HIP_TRY(c, hipEventSynchronize(c->piece_ev[k & 1]));
+        const uint64_t off = k * piece, m = std::min<uint64_t>(piece, len - off);
+        if (write(user, static_cast<const uint8_t *>(c->h_piece[k & 1].p), m) != 0) {
+            (void)hipStreamSynchronize(s);
+            return fail(c, ZDW_UNKNOWN_ERROR, "the writer refused %llu bytes of output", (unsigned long long)m);
+        }
+    }
+    return ZDW_OK;
+}
+}  // namespace
+
+int zdw_block_dict_write(zdw_ctx *c, zdw_write_fn write, void *user, uint64_t *section_len, uint8_t *index_size)
+{
+    if (!c || !write) return ZDW_UNKNOWN_ERROR;
+    const void *d = nullptr;
+    uint64_t len = 0;
+    int rc = zdw_block_dict_device(c, &d, &len, index_size);
+    if (rc) return rc;
+    if (section_len) *section_len = len;
+    return stream_out(c, static_cast<const uint8_t *>(d), len, write, user);
+}
+
+int zdw_block_pass2_write(zdw_ctx *c, zdw_write_fn write, void *user, uint64_t *rows_len)
+{
+    if (!c || !write) return ZDW_UNKNOWN_ERROR;
+    const void *d = nullptr;
+    uint64_t len = 0;
+    int rc = zdw_block_pass2_device(c, &d, &len);
+    if (rc) return rc;
+    if (rows_len) *rows_len = len;
+    return stream_out(c, static_cast<const uint8_t *>(d), len, write, user);
 }
 
 int zdw_block_next(zdw_ctx *c)
