@@ -27,9 +27,10 @@ struct DevBuf {
     {
         if (bytes <= cap && p) return hipSuccess;
         size_t want = bytes < 256 ? 256 : bytes;
-        // A buffer that has to grow gets an eighth more than asked: sizes that follow the number of unique ids jitter
-        // by a few hundred from pass to pass (which wave wins which race), and every regrowth is a hipFree (a device
-        // synchronisation) plus a hipMalloc in the middle of a block.
+        // Sizes that follow the number of unique ids jitter by a few hundred from pass to pass (which wave wins which
+        // race), and every regrowth is a hipFree (a device synchronisation) plus a hipMalloc in the middle of a block:
+        // a large buffer gets 3 % more than asked, one that has to grow an eighth more.
+        if (want >= (1u << 20)) want += want / 32;
         if (p) { want += want / 8; (void)hipFree(p); p = nullptr; cap = 0; }
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want; else p = nullptr;
