@@ -200,7 +200,7 @@ def main():
         dom_ms = per[dom]
         achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms else 0.0
         b_alg = 2 * nbytes + out_local
-        traffic, traffic_note = pmc_traffic({"pass1": "zdw::k_pass1<true>", "scan_rows": "zdw::k_count_row_starts",
+        traffic, traffic_note = pmc_traffic({"pass1": "zdw::k_pass1<true", "scan_rows": "zdw::k_count_row_starts",
                                              "pass2_emit": "zdw::k_pass2_emit_cols", "pass2_size": "zdw::k_pass2_size_cols"}.get(dom), nbytes)
         res = {
             "metric": "TSV->ZDW encode throughput (input bytes / wall time, input resident in HBM, raw .zdw left in HBM)",

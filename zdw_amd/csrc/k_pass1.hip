@@ -311,7 +311,8 @@ struct WaveState {
 // Handles `cnt` (1..64) descriptors from the ring head, one per lane.  Returns how many new dictionary
 // entries were created.  DEFER: fields that need the general form are queued for k_pass1_deferred instead of
 // being handled here (the general form costs this kernel a fifth of its registers and a wave per SIMD).
-template <bool DEFER>
+// TRIM: convertDWfile -t -- trailing blanks are cut off every field before anything else looks at it (ConvertToZDW.cpp:295-313).
+template <bool DEFER, bool TRIM>
 __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const DictTable &d, const P1Lds &L, WaveState &ws, uint32_t cnt,
                                             uint32_t lane)
 {
@@ -321,7 +322,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     const uint32_t pe = lds_u32(ws.desc | (((di - 1u) << 2) & (QCAP * 4u - 1u)));
     const bool e_nl = live && (e >> 31) != 0;
     const uint32_t e_pos = e & ~DESC_NL, fs = (pe & ~DESC_NL) + 1u;      // a field begins one byte after its predecessor's end
-    const uint32_t len = e_pos - fs;
+    const uint32_t raw_len = e_pos - fs;
+    uint32_t len = raw_len;
     const bool sentinel = ws.first_pending && lane == 0;
     const bool blank = e_nl && (pe >> 31) != 0 && len == 0;              // line end right after a line end: no row (getnextrow.cpp:38-43)
     const bool ends_row = e_nl && !blank && !sentinel;
@@ -351,9 +353,23 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     uint32_t meta = 0;
     if (is_field && t.cols_in_lds) meta = lds_u32(t.meta + 4u * col);
     const uint32_t kind = meta & 3u;
-    bool slow = is_field && (!t.cols_in_lds || a.trim != 0 || fs < ws.ring_lo);
-    const bool fast = is_field && !slow;
+    bool slow = is_field && (!t.cols_in_lds || (!TRIM && a.trim != 0) || fs < ws.ring_lo);
     const uint32_t ra = ws.bytes + (fs & (BYTE_RING - 1u));
+    if (TRIM) {
+        if (is_field && !slow && len) {
+            if (len > 32u) slow = true;                   // beyond what the byte ring's tail copy lets this path read in one piece
+            else {
+                // blanks at the end of the field: its last 8 bytes (or what precedes it, never counted: k <= len)
+                const uint64_t x = lds_u64(ra + len - 8u) ^ 0x2020202020202020ull;
+                const uint64_t f = (((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & 0x8080808080808080ull;      // bit 7 of a byte: it is no blank
+                uint32_t k = f ? (uint32_t)__builtin_clzll(f) >> 3 : 8u;
+                if (k > len) k = len;
+                if (k == 8u && len > 8u) slow = true;       // there may be more of them: general form
+                else len -= k;
+            }
+        }
+    }
+    const bool fast = is_field && !slow;
     uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + (meta >> 16);
     bool is_new = false;
 
@@ -465,20 +481,20 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (slow) {
                 if (qb < a.dq_cap) {
                     a.dq[2ull * qb] = (ws.vbase + fs) | ((uint64_t)col << 40);
-                    a.dq[2ull * qb + 1] = (uint64_t)len | ((uint64_t)row << 32);
+                    a.dq[2ull * qb + 1] = (uint64_t)raw_len | ((uint64_t)row << 32);
                 } else {
                     a.st->deferred_lost = 1;
                 }
             }
         } else {
-            if (slow) process_field_general(a, t, d, ws.ids, ws.vbase + fs, len, col, row, in_block, is_new);
+            if (slow) process_field_general(a, t, d, ws.ids, ws.vbase + fs, raw_len, col, row, in_block, is_new);
             adopt_ids(ws.ids, sm);
         }
     }
     return popc64(__ballot(is_new));
 }
 
-template <bool DEFER>
+template <bool DEFER, bool TRIM>
 __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass1Args a)
 {
     const uint32_t wv = threadIdx.x >> 6;
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
                 ws.q_count += nb_total;
                 __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
                 while (ws.q_count >= 64) {
-                    if (!(a.debug_skip & 32u)) new_entries += consume<DEFER>(a, t, d, L, ws, 64u, lane);      // 32: profiling only, the producer alone
+                    if (!(a.debug_skip & 32u)) new_entries += consume<DEFER, TRIM>(a, t, d, L, ws, 64u, lane);      // 32: profiling only, the producer alone
                     ws.q_head += 64;
                     ws.q_count -= 64;
                 }
@@ -691,7 +707,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
                     __builtin_amdgcn_wave_barrier();
                     while (drain ? ws.q_count > 0 : ws.q_count >= 64) {
                         const uint32_t cnt = ws.q_count < 64 ? ws.q_count : 64u;
-                        new_entries += consume<DEFER>(a, t, d, L, ws, cnt, lane);
+                        new_entries += consume<DEFER, TRIM>(a, t, d, L, ws, cnt, lane);
                         ws.q_head += cnt;
                         ws.q_count -= cnt;
                     }
@@ -802,7 +818,11 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     int per_cu = 0, dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const void *fn = defer ? (const void *)k_pass1<true> : (const void *)k_pass1<false>;
+    const bool trim = a.trim != 0;
+    typedef void (*P1Fn)(const Pass1Args);
+    static const P1Fn fns[2][2] = {{k_pass1<false, false>, k_pass1<false, true>}, {k_pass1<true, false>, k_pass1<true, true>}};
+    const P1Fn kfn = fns[defer][trim];
+    const void *fn = (const void *)kfn;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
     const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules
     if ((size_t)per_cu > by_lds && by_lds >= 1) per_cu = (int)by_lds;
@@ -811,8 +831,7 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / P1_WPB;   // tuning experiments
     const uint32_t want_blocks = (a.nspans + P1_WPB - 1) / P1_WPB;
     const uint32_t grid = want_blocks < max_blocks ? want_blocks : (max_blocks ? max_blocks : 1u);
-    if (defer) hipLaunchKernelGGL(k_pass1<true>, dim3(grid), dim3(64 * P1_WPB), lds, s, a);
-    else hipLaunchKernelGGL(k_pass1<false>, dim3(grid), dim3(64 * P1_WPB), lds, s, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * P1_WPB), lds, s, a);
 }
 
 }  // namespace zdw

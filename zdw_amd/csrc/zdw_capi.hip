@@ -687,13 +687,13 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::max(16384u, (uint32_t)strtoul(e, nullptr, 10));   // tests
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
-            // Fields that need the general form (-t, long strings, signed / padded numbers, contended slots) are
+            // Fields that need the general form (long strings, signed / padded numbers, contended slots) are
             // queued by the main kernel (16 bytes each) and handled by a second one.  The queue starts at about 1 %
             // of the block's fields; a pass that needs more says how many and is run again with that (the context
-            // remembers), up to one queue byte per input byte -- beyond that, with -t, or with a schema whose tables do
+            // remembers), up to one queue byte per input byte -- beyond that, or with a schema whose tables do
             // not fit LDS, the all-in-one kernel runs instead.  (10 GB x 200 columns with words of 4..32 / 4..96
             // characters: queue 19 / 27 ms, all-in-one 34 / 42 ms.)
-            const bool defer = lds_ranges && !c->trim && !c->p1_all_in_one && !getenv("ZDW_P1_ALL_IN_ONE");
+            const bool defer = lds_ranges && !c->p1_all_in_one && !getenv("ZDW_P1_ALL_IN_ONE");
             if (defer) {
                 uint64_t dq_div = 1024;
                 if (const char *e = getenv("ZDW_DQ_DIV")) dq_div = std::max<uint64_t>(8, strtoull(e, nullptr, 10));      // experiments
