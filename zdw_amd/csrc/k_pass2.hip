@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
 }
 
 // ------------------------------------------------------------------------------------------
-// wide schemas: a wave owns 64 columns of a chunk of rows
+// column kernels: a wave owns 64 columns of (its share of) a chunk of rows
 // ------------------------------------------------------------------------------------------
 // Lane = column, so "the row above" is the value the lane loaded one step earlier: the record matrix is
 // read once, and all loads of a chunk (P2_R + 1 per lane) are in flight together.

@@ -73,7 +73,7 @@ struct Pass2Args {
     uint32_t nids;                 // entries of id_off
     const uint64_t *prev0;         // stored values of the row before row 0 (per used column)
     uint32_t *row_len;             // out (size kernel)
-    uint16_t *batch_pre;           // wide schemas, size kernel -> emit kernel: per (row, 64-column batch) the value bytes of the batches before it
+    uint16_t *batch_pre;           // column kernels, size kernel -> emit kernel: per (row, 64-column batch) the value bytes of the batches before it
     const uint64_t *row_off;       // in (emit kernel): exclusive scan of row_len
     uint8_t *out;
     uint64_t *last_stored;         // k_last_row only: stored values of the last row (per used column)
