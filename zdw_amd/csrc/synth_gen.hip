@@ -40,7 +40,10 @@ __device__ inline uint32_t put_fixed(uint8_t *q, uint64_t v, uint32_t digits)
 }
 
 // `vocab_and_len`: bits 0..23 = vocabulary size; bits 24..31 = how far the longest word exceeds 24 characters (0 = the
-// benchmark's table: 4..24)
+// benchmark's table: 4..24).  g_empty16: a field is empty when the low 16 bits of its hash are below it (16384 = the
+// benchmark's 25 %; set per launch for tables of other shapes).
+__device__ uint32_t g_empty16 = 16384;
+
 template <bool WRITE>
 __device__ inline uint32_t emit_field(uint8_t *q, uint64_t seed, uint64_t row, uint32_t col, uint32_t gen, uint32_t vocab_and_len)
 {
@@ -49,7 +52,7 @@ __device__ inline uint32_t emit_field(uint8_t *q, uint64_t seed, uint64_t row, u
     uint32_t steps = 0;
     while (row > 0 && steps < 64 && (cell_hash(seed, row, col, 1) & 0xFFFF) < 19661) { --row; ++steps; }   // 0.3 * 65536
     const uint64_t h = cell_hash(seed, row, col, 2);
-    if ((h & 0xFFFF) < 16384) return 0;                                                                       // 25 % empty
+    if ((h & 0xFFFF) < g_empty16) return 0;                                                                  // 25 % empty
     const uint64_t r = h >> 16;
     switch (gen) {
     case 0: {
@@ -117,6 +120,12 @@ __global__ __launch_bounds__(256) void k_synth_fill(const uint8_t *__restrict__ 
 }
 
 }  // namespace
+
+// fraction of empty fields for the launches that follow, in 1/65536 (16384 = the benchmark's table)
+extern "C" int zdw_synth_set_empty(uint32_t empty16)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_empty16), &empty16, sizeof empty16);
+}
 
 extern "C" int zdw_synth_row_lengths(const void *gens, uint32_t ncols, uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t vocab,
                                      void *lens, void *stream)
