@@ -36,7 +36,7 @@ namespace zdw {
 
 constexpr uint32_t WROUND = 1024;                 // bytes per wave round (16 per lane)
 constexpr uint32_t DQ_CHUNK = 256;                // deferred-queue entries a wave takes per atomic
-constexpr uint32_t QCAP = 512;                    // descriptor ring entries per wave (u32 each); a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
+constexpr uint32_t QCAP = 1024;                   // descriptor ring entries per wave (u32 each); a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
 constexpr uint32_t BYTE_RING = 2048;              // two rounds of input bytes per wave
 constexpr uint32_t RING_TAIL = 32;                // copy of the byte ring's first bytes behind its end: 24-byte reads never wrap
 constexpr uint32_t P1_WPB = 4;                    // independent waves per workgroup; they share the column tables
@@ -465,7 +465,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             // block full of such fields: a single address takes about 30 M of them a second).  What is left of a chunk
             // that cannot take this call's fields is filled with blanks (length field all ones), which the second kernel skips.
             const uint32_t k = popc64(sm);
-            const uint32_t qs = L.dqs + (ws.desc >> 8);                      // ws.desc = wave index x 2048
+            const uint32_t qs = L.dqs + ws.desc / (QCAP * 4u) * 8u;          // ws.desc = wave index x ring size
             uint32_t cur = lds_u32(qs), end = lds_u32(qs + 4u);
             if (end - cur < k) {
                 const uint32_t left = end - cur;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
     }
     retire_ids(ws.ids, a.uniq_len, a.id_cap);
     if (DEFER) {
-        const uint32_t qs = L.dqs + (ws.desc >> 8);
+        const uint32_t qs = L.dqs + ws.desc / (QCAP * 4u) * 8u;
         for (uint32_t q = lds_u32(qs) + lane; q < lds_u32(qs + 4u); q += 64)
             if (q < a.dq_cap) a.dq[2ull * q + 1] = ~0ull;
     }
