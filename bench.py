@@ -109,6 +109,7 @@ def main():
                     help="N > 1: every rank writes its rows as its own ZDW block (own dictionary, no exchange; a different, equally valid file: "
                          "SURVEY 8f-3) instead of one block row-sharded over the ranks")
     ap.add_argument("--p-empty", type=float, default=0.25, help="fraction of empty fields (0.25 = BASELINE's table; other values: not a valid bench line)")
+    ap.add_argument("--dead-cols", type=float, default=0.0, help="fraction of columns empty in every row (0 = BASELINE's table)")
     ap.add_argument("--pass1-only", action="store_true", help="profiling: time pass 1 alone (not a valid bench line)")
     args = ap.parse_args()
 
@@ -129,7 +130,7 @@ def main():
             dist.init_process_group(args.backend)
 
     # ---- synthetic table, generated in HBM; rank r holds rows [r*R, (r+1)*R) ----
-    table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local, word_maxlen=args.word_maxlen, p_empty=args.p_empty)
+    table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local, word_maxlen=args.word_maxlen, p_empty=args.p_empty, dead_cols=args.dead_cols)
     rows_per_rank = table.rows_for_bytes(args.gb * 1e9)
     buf, nbytes = table.generate(rank * rows_per_rank, rows_per_rank)
     torch.cuda.synchronize()

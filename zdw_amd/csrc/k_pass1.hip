@@ -424,6 +424,10 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // ---- integers of <= 16 plain digits, char(1) ----
     bool fn = fast && kind != K_TEXT;
     if (fn && kind == K_INT && len > 16u) { slow = true; fn = false; }
+    if (fn && len == 0u) {                 // an empty numeric field is a zero record and touches no range (sparse tables: most of them)
+        if (in_block) *reinterpret_cast<uint64_t *>(recp) = 0ull;
+        fn = false;
+    }
     if (__ballot(fn)) {
         if (fn) {
             uint64_t v_rec = 0, v_range = 0;

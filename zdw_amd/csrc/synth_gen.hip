@@ -43,6 +43,7 @@ __device__ inline uint32_t put_fixed(uint8_t *q, uint64_t v, uint32_t digits)
 // benchmark's table: 4..24).  g_empty16: a field is empty when the low 16 bits of its hash are below it (16384 = the
 // benchmark's 25 %; set per launch for tables of other shapes).
 __device__ uint32_t g_empty16 = 16384;
+__device__ uint32_t g_dead16 = 0;          // a column is empty in every row when the low 16 bits of a hash of its index are below this
 
 template <bool WRITE>
 __device__ inline uint32_t emit_field(uint8_t *q, uint64_t seed, uint64_t row, uint32_t col, uint32_t gen, uint32_t vocab_and_len)
@@ -52,6 +53,7 @@ __device__ inline uint32_t emit_field(uint8_t *q, uint64_t seed, uint64_t row, u
     uint32_t steps = 0;
     while (row > 0 && steps < 64 && (cell_hash(seed, row, col, 1) & 0xFFFF) < 19661) { --row; ++steps; }   // 0.3 * 65536
     const uint64_t h = cell_hash(seed, row, col, 2);
+    if (g_dead16 && (mix(seed ^ (0xD1B54A32D192ED03ull * (col + 1))) & 0xFFFF) < g_dead16) return 0;          // a column nobody fills
     if ((h & 0xFFFF) < g_empty16) return 0;                                                                  // 25 % empty
     const uint64_t r = h >> 16;
     switch (gen) {
@@ -122,9 +124,11 @@ __global__ __launch_bounds__(256) void k_synth_fill(const uint8_t *__restrict__ 
 }  // namespace
 
 // fraction of empty fields for the launches that follow, in 1/65536 (16384 = the benchmark's table)
-extern "C" int zdw_synth_set_empty(uint32_t empty16)
+extern "C" int zdw_synth_set_empty(uint32_t empty16, uint32_t dead16)
 {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_empty16), &empty16, sizeof empty16);
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_empty16), &empty16, sizeof empty16);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_dead16), &dead16, sizeof dead16);
+    return (int)e;
 }
 
 extern "C" int zdw_synth_row_lengths(const void *gens, uint32_t ncols, uint64_t seed, uint64_t row0, uint64_t nrows, uint32_t vocab,

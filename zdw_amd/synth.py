@@ -138,7 +138,7 @@ def _synth_lib():
         L.zdw_synth_row_lengths.restype = C.c_int
         L.zdw_synth_fill.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.zdw_synth_fill.restype = C.c_int
-        L.zdw_synth_set_empty.argtypes = [C.c_uint32]
+        L.zdw_synth_set_empty.argtypes = [C.c_uint32, C.c_uint32]
         L.zdw_synth_set_empty.restype = C.c_int
         _lib = L
     return _lib
@@ -147,11 +147,13 @@ def _synth_lib():
 class DeviceTable:
     """Generates rows [row0, row0 + nrows) of the synthetic table into a torch uint8 CUDA tensor."""
 
-    def __init__(self, ncols=200, seed=SEED, vocab=VOCAB, device="cuda", word_maxlen=24, p_empty=0.25):
+    def __init__(self, ncols=200, seed=SEED, vocab=VOCAB, device="cuda", word_maxlen=24, p_empty=0.25, dead_cols=0.0):
         """word_maxlen: longest vocabulary word (24 = the benchmark's table; up to 279 for tables with long strings);
-        p_empty: fraction of empty fields (0.25 = the benchmark's table)"""
+        p_empty: fraction of empty fields (0.25 = the benchmark's table); dead_cols: fraction of columns that are empty in
+        every row (0 = the benchmark's table; the reference's analytics-hits: 0.88)"""
         import torch
         self.empty16 = int(round(p_empty * 65536))
+        self.dead16 = int(round(dead_cols * 65536))
         self.torch = torch
         assert vocab < (1 << 24) + 1 and 24 <= word_maxlen <= 279
         vocab = min(vocab, (1 << 24) - 1) | ((word_maxlen - 24) << 24)
@@ -162,7 +164,7 @@ class DeviceTable:
     def generate(self, row0, nrows):
         torch = self.torch
         L = _synth_lib()
-        if L.zdw_synth_set_empty(self.empty16):
+        if L.zdw_synth_set_empty(self.empty16, self.dead16):
             raise RuntimeError("zdw_synth_set_empty failed")
         stream = torch.cuda.current_stream().cuda_stream
         lens = torch.empty(nrows + 1, dtype=torch.int64, device=self.device)
