@@ -9,7 +9,8 @@ bytes, CLI flags, optional .metadata sidecar) and what the reference produced (e
 The cases are the list in SURVEY.md §8(c): behaviours that the reference's own committed
 fixtures (test-files/) do not pin.
 
-    python oracle/gen_golden.py            # rewrites tests/golden/edge_cases.json, fuzz_cases.json
+    python oracle/gen_golden.py               # rewrites tests/golden/edge_cases.json, fuzz_cases.json
+    python oracle/gen_golden.py --multiblock  # rewrites tests/golden/multiblock.json (two-block files, Q9)
 """
 import base64
 import json
@@ -223,7 +224,64 @@ def run(c):
                 err_code=int(code.group(1)) if code else None)
 
 
+# (15) forced multi-block files (probe P19) -----------------------------------------------
+# The inputs are too large to commit (>= 64 MiB of unique strings are needed before the reference's
+# StringHeap allocates its second arena, stringheap.cpp:74-86): they are regenerated from the recipe
+# below, and the fixture keeps what the reference produced for them: sha256 of the raw stream and the
+# block summary read from the reference's OWN output (rows, dictionary entries, `done`, m_LongestLine).
+# partial_fields = leading fields of the row after the block that pass 1 had visited when the limit
+# tripped (they stay in the block's dictionary and ranges, ConvertToZDW.cpp:338,404): read off the
+# entry count, since every string of these tables is unique.
+MULTIBLOCK = [
+    dict(name="p19_two_text_columns", mem_limit=100, nrows=1500000,
+         desc=[("a", "varchar(64)"), ("b", "varchar(64)")], row=["A%042d", "B%042d"], text_cols=2),
+    # an int column in front of the strings: the partial row's number pollutes the block's minimum
+    # (values fall with the row number), so the column base of block 1 shows the pollution
+    dict(name="partial_row_pollutes_min", mem_limit=215, nrows=1000000,
+         desc=[("n", "int(11)"), ("s", "varchar(40)"), ("t", "varchar(60)")], row=["%(neg)d", "S%023d", "T%051d"], text_cols=2),
+]
+
+
+def multiblock_tsv(spec):
+    out = []
+    for i in range(spec["nrows"]):
+        out.append("\t".join(f % {"neg": 2000000 - i} if "%(neg)" in f else f % i for f in spec["row"]))
+    return ("\n".join(out) + "\n").encode()
+
+
+def run_multiblock(spec):
+    import hashlib
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    import zdw_walk
+    tsv = multiblock_tsv(spec)
+    rc, zdw, so, se = oracle.run_ref(desc_of(spec["desc"]), tsv, args=["-q", "--mem-limit=%d" % spec["mem_limit"]])
+    assert rc == 0 and zdw is not None, (rc, se[-300:])
+    z = zdw_walk.walk(zdw)
+    blocks = []
+    for b in z.blocks:
+        blocks.append(dict(rows=b.num_rows, entries=b.dict_blob.count(b"\0") - 1 if b.index_size else 0, done=b.done,
+                           longest_line=b.longest_line, col_size=list(b.col_size), col_base=b.col_base))
+    assert len(blocks) >= 2, "the reference did not split: lower mem_limit"
+    # text fields of the partial row that were inserted = entries beyond the block's own rows
+    extra = blocks[0]["entries"] - spec["text_cols"] * blocks[0]["rows"]
+    ntext_before = [sum(1 for (_, t) in spec["desc"][:k] if "char" in t) for k in range(len(spec["desc"]) + 1)]
+    partial = max(k for k in range(len(spec["desc"]) + 1) if ntext_before[k] == extra and (k == 0 or "char" in spec["desc"][k - 1][1]))
+    return dict(name=spec["name"], mem_limit=spec["mem_limit"], nrows=spec["nrows"], desc=b64(desc_of(spec["desc"])), row=spec["row"],
+                tsv_bytes=len(tsv), tsv_sha256=hashlib.sha256(tsv).hexdigest(), zdw_bytes=len(zdw), zdw_sha256=hashlib.sha256(zdw).hexdigest(),
+                blocks=blocks, split_rows=[b["rows"] for b in blocks[:-1]], partial_fields=[partial] + [0] * (len(blocks) - 2))
+
+
 def main():
+    if "--multiblock" in sys.argv:
+        if not oracle.have_ref():
+            sys.exit("oracle/_ref/convertDWfile missing: run `make -C oracle` where /root/reference exists")
+        res = [run_multiblock(s) for s in MULTIBLOCK]
+        with open(os.path.join(OUT_DIR, "multiblock.json"), "w") as f:
+            json.dump(dict(generator="oracle/gen_golden.py --multiblock", reference="adobe/zdw convertDWfile v11b (oracle/_ref), --mem-limit as listed",
+                           cases=res), f, indent=1)
+        for r in res:
+            print(r["name"], r["zdw_sha256"][:16], [(b["rows"], b["entries"], b["done"]) for b in r["blocks"]], "partial", r["partial_fields"])
+        return
     if not oracle.have_ref():
         sys.exit("oracle/_ref/convertDWfile missing: run `make -C oracle` where /root/reference exists")
     os.makedirs(OUT_DIR, exist_ok=True)

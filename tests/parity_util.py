@@ -27,6 +27,26 @@ def cases(fname):
     return out
 
 
+def multiblock_cases():
+    """tests/golden/multiblock.json: two-block files the compiled reference wrote under --mem-limit
+    (oracle/gen_golden.py --multiblock).  The inputs are regenerated from their recipe (multiblock_tsv)."""
+    with open(os.path.join(G, "multiblock.json")) as f:
+        out = json.load(f)["cases"]
+    for c in out:
+        c["desc"] = base64.b64decode(c["desc"])
+    return out
+
+
+def multiblock_tsv(c):
+    import hashlib
+    rows = []
+    for i in range(c["nrows"]):
+        rows.append("\t".join(f % {"neg": 2000000 - i} if "%(neg)" in f else f % i for f in c["row"]))
+    tsv = ("\n".join(rows) + "\n").encode()
+    assert len(tsv) == c["tsv_bytes"] and hashlib.sha256(tsv).hexdigest() == c["tsv_sha256"], "recipe drifted from the fixture"
+    return tsv
+
+
 class CliSandbox:
     """A scratch directory plus a PATH whose `gzip` is `cat`, so <x>.zdw.gz is the raw ZDW stream
     (the same trick oracle/_ref uses for the reference binary)."""

@@ -111,3 +111,23 @@ def test_reference_generated_vectors(fname):
                 assert info.bad_row == c["bad_row"], c["name"]
             n_err += 1
     assert n_ok > 40 and n_err >= 1
+
+
+@pytest.mark.parametrize("case", __import__("tests.parity_util", fromlist=["x"]).multiblock_cases(), ids=lambda c: c["name"])
+def test_reference_multiblock_files(case):
+    """Q9, pinned: two-block files the REAL reference wrote under --mem-limit (sha256 + block summary in
+    tests/golden/multiblock.json).  Given the split the reference took (rows of block 1, fields of the partial
+    row it had visited), the oracle's emulation must reproduce the reference's bytes."""
+    from tests import parity_util as pu
+    tsv = pu.multiblock_tsv(case)
+    rc, out, info = oracle.encode(case["desc"], tsv, split_rows=case["split_rows"], split_cols=case["partial_fields"])
+    assert rc == 0 and info.nblocks == len(case["blocks"])
+    assert len(out) == case["zdw_bytes"]
+    assert hashlib.sha256(out).hexdigest() == case["zdw_sha256"]
+    z = zdw_walk.walk(out)
+    for b, want in zip(z.blocks, case["blocks"]):
+        assert (b.num_rows, b.done, b.longest_line) == (want["rows"], want["done"], want["longest_line"])
+        assert list(b.col_size) == want["col_size"] and b.col_base == want["col_base"]
+    # without the partial-row pollution the bytes differ: the fixture really pins it
+    rc2, out2, _ = oracle.encode(case["desc"], tsv, split_rows=case["split_rows"], split_cols=[0] * len(case["split_rows"]))
+    assert rc2 == 0 and hashlib.sha256(out2).hexdigest() != case["zdw_sha256"]

@@ -286,7 +286,22 @@ __host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool c
 size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds) { return p1_layout(ncols, nnum, use_lds).total; }
 
 __device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *reinterpret_cast<const uint32_t *>(zdw_lds + off); }
-__device__ __forceinline__ uint64_t lds_u64(uint32_t off) { return reinterpret_cast<const PackedU64 *>(zdw_lds + off)->v; }     // any alignment
+__device__ __forceinline__ uint64_t lds_u64(uint32_t off) { return *reinterpret_cast<const uint64_t *>(zdw_lds + off); }     // 8-byte aligned offsets only
+// Field bytes sit at any byte offset of the ring.  A ds_read_b64 / _b128 off its natural alignment is replayed at ~64
+// cycles per wave-instruction (SQ_LDS_UNALIGNED_STALL: 59 % of this kernel's LDS cycles before), so bytes are read
+// as aligned dwords (ds_read2_b32 needs 4-byte alignment only) and moved into place with v_alignbyte.
+template <uint32_t NW>      // NW dwords starting at byte offset `off` (any alignment): reads NW + 1 aligned dwords
+__device__ __forceinline__ void lds_bytes(uint32_t off, uint32_t (&w)[NW])
+{
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(zdw_lds + (off & ~3u));
+    const uint32_t sh = off & 3u;
+    uint32_t d[NW + 1];
+#pragma unroll
+    for (uint32_t k = 0; k <= NW; ++k) d[k] = q[k];
+#pragma unroll
+    for (uint32_t k = 0; k < NW; ++k) w[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+}
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // bit 7 of each byte: set iff the byte of x is non-zero (exact, no carries between bytes)
 __device__ __forceinline__ uint32_t nz7(uint32_t x) { return ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x; }
@@ -360,7 +375,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (len > 32u) slow = true;                   // beyond what the byte ring's tail copy lets this path read in one piece
             else {
                 // blanks at the end of the field: its last 8 bytes (or what precedes it, never counted: k <= len)
-                const uint64_t x = lds_u64(ra + len - 8u) ^ 0x2020202020202020ull;
+                uint32_t tw[2];
+                lds_bytes<2>(ra + len - 8u, tw);
+                const uint64_t x = u64_of(tw[0], tw[1]) ^ 0x2020202020202020ull;
                 const uint64_t f = (((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & 0x8080808080808080ull;      // bit 7 of a byte: it is no blank
                 uint32_t k = f ? (uint32_t)__builtin_clzll(f) >> 3 : 8u;
                 if (k > len) k = len;
@@ -385,7 +402,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (len) {                                                            // empty fields are skipped (:340-341)
                 if (!zdw_lds[t.seen + col]) zdw_lds[t.seen + col] = 1;
                 const uint32_t lo = L.lut + 32u * len;
-                c0 = lds_u64(ra) & lds_u64(lo); c1 = lds_u64(ra + 8) & lds_u64(lo + 8); c2 = lds_u64(ra + 16) & lds_u64(lo + 16);
+                uint32_t fw[6];
+                lds_bytes<6>(ra, fw);
+                c0 = u64_of(fw[0], fw[1]) & lds_u64(lo); c1 = u64_of(fw[2], fw[3]) & lds_u64(lo + 8); c2 = u64_of(fw[4], fw[5]) & lds_u64(lo + 16);
                 acc = nh24(c0, c1, c2);
                 i = hash_place(acc) & a.slot_mask;
                 pending = !(a.debug_skip & 2u);
@@ -437,8 +456,11 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 const uint32_t k = len > 8u ? len - 8u : 0u;
                 const uint64_t m2 = lds_u64(L.lut + 32u * (8u + k - len)), m1 = lds_u64(L.lut + 32u * (8u - k));
                 const uint64_t Z = 0x3030303030303030ull;
-                const uint64_t w2 = (lds_u64(ra + len - 8u) & ~m2) | (Z & m2);
-                const uint64_t w1 = (lds_u64(ra + k - 8u) & ~m1) | (Z & m1);
+                // (with fewer than 8 characters the first word lies before the field and is masked whole)
+                uint32_t nw[4];
+                lds_bytes<4>(ra + len - 16u, nw);
+                const uint64_t w2 = (u64_of(nw[2], nw[3]) & ~m2) | (Z & m2);
+                const uint64_t w1 = (u64_of(nw[0], nw[1]) & ~m1) | (Z & m1);
                 const uint32_t r0 = (uint32_t)w1, r1 = (uint32_t)(w1 >> 32), r2 = (uint32_t)w2, r3 = (uint32_t)(w2 >> 32);
                 const uint32_t t0 = r0 - 0x30303030u, t1 = r1 - 0x30303030u, t2 = r2 - 0x30303030u, t3 = r3 - 0x30303030u;
                 ok = (nondigit_bits(r0, t0) | nondigit_bits(r1, t1) | nondigit_bits(r2, t2) | nondigit_bits(r3, t3)) == 0u;
@@ -446,7 +468,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 const uint32_t hi8 = __umul24(four_digits(t0), 10000u) + four_digits(t1);
                 v_rec = v_range = (uint64_t)hi8 * 100000000ull + lo8;
             } else {   // char(1): pass 1 adds byte 1 only after a backslash (:358-361), pass 2 always (:543-547)
-                const uint32_t w = (uint32_t)lds_u64(ra);
+                uint32_t cw[1];
+                lds_bytes<1>(ra, cw);
+                const uint32_t w = cw[0];
                 const uint32_t b0 = len ? (w & 0xffu) : 0u, b1 = len >= 2u ? ((w >> 8) & 0xffu) : 0u;
                 const int64_t c0 = (int8_t)b0;
                 const int64_t hi8 = (int64_t)((int)(int8_t)b1 * 256);
