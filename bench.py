@@ -9,7 +9,14 @@ weak scaling, every rank holds its own 10 GB row range of ONE ZDW block; RCCL ca
 range all-reduce, the dictionary merge (range-partitioned: two all-to-all-v of unique strings / offsets,
 small all-gathers of samples and range sizes) and the previous-row halo.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--gb G] [--cols C] [--no-cpu]
+After the timed region (never inside it) rank 0 also: verifies the last step's outputs ("verified": row count,
+dictionary header + strict strcmp order of every entry, a walk of the first rows, and byte equality of the
+dictionary / column stats / row section with the same table encoded as THREE row shards, whose positions all stay
+below 2^32); times the reference encoder on the host ("cpu_baseline"); and times the shipped convertDWfile
+binary as a child process on a page-cache-warm 2 GB file ("e2e_cli": compressor child replaced by cat, and the
+default gzip) -- SURVEY.md 8d protocol (b); neither rate is ever `value`.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--gb G] [--cols C] [--no-cpu] [--no-verify] [--no-e2e] [--scaling weak|strong]
 """
 import argparse
 import json
@@ -76,6 +83,118 @@ def pmc_traffic(kernel, nbytes):
     return best if best else (None, None)
 
 
+def verify_outputs(torch, capi, sharded, table, buf, nbytes, enc, nrows, p1, dict_ptr_len, rows_ptr_len, col_stats):
+    """Size-independent properties of the block the timed loop produced last (outputs still in HBM), checked after
+    the timed region.  Raises AssertionError with what is wrong; returns a dict of what was checked."""
+    import hashlib
+    import numpy as np
+    dev = buf.device
+    dptr, dlen = dict_ptr_len
+    rptr, rlen = rows_ptr_len
+    col_size, col_base = col_stats
+    assert p1.num_rows == nrows and p1.is_last_block == 1, "row count %d != %d" % (p1.num_rows, nrows)
+    sec = sharded._wrap(dptr, dlen, "|u1", str(dev)).cpu().numpy()
+    w = int(sec[0])
+    size = int.from_bytes(sec[1:1 + w].tobytes(), "little")
+    blob = sec[1 + w:]
+    assert blob.size == size and blob[0] == 0 and blob[-1] == 0, "dictionary header says %d bytes, section holds %d" % (size, blob.size)
+    entries = blob[1:].tobytes().split(b"\0")[:-1]
+    assert len(entries) == p1.dict_entries, "dictionary holds %d strings, pass 1 counted %d" % (len(entries), p1.dict_entries)
+    assert all(a < b for a, b in zip(entries, entries[1:])), "dictionary is not in strict strcmp order"
+    del entries
+    used = [c for c in range(len(col_size)) if col_size[c]]
+    assert len(col_base) == len(used)
+    nflag = (len(used) + 7) // 8
+    sizes = np.array([col_size[c] for c in used], dtype=np.int64)
+    rows = sharded._wrap(rptr, rlen, "|u1", str(dev))
+    head = rows[:min(rlen, 64 << 20)].cpu().numpy()
+    pos = 0
+    walked = 0
+    while walked < min(nrows, 20000) and pos + nflag <= head.size:
+        flags = np.unpackbits(head[pos:pos + nflag], bitorder="little")[:len(used)].astype(bool)
+        pos += nflag + int(sizes[flags].sum())
+        walked += 1
+    assert pos <= rlen and (walked < nrows or pos == rlen), "row walk left the section"
+    h_dict = hashlib.sha256(sec.tobytes()).hexdigest()
+    h_rows = hashlib.sha256()
+    for o in range(0, rlen, 256 << 20):
+        h_rows.update(rows[o:o + (256 << 20)].cpu().numpy().tobytes())
+    h_rows = h_rows.hexdigest()
+    # the same rows as three shards of one block (every shard's positions and offsets stay below 2^32)
+    cuts = [0]
+    for i in (1, 2):
+        t = nbytes * i // 3
+        win = buf[t:t + (1 << 20)]
+        cuts.append(t + int((win == 10).nonzero()[0][0].item()) + 1)
+    cuts.append(nbytes)
+    encs = []
+    for i in range(3):
+        part = buf[cuts[i]:cuts[i + 1]]
+        if part.data_ptr() % 16:
+            part = part.clone()
+        e = capi.Encoder(table.types, device=dev.index or 0)
+        e.set_input_device(part.data_ptr(), part.numel(), keepalive=part)
+        encs.append(e)
+    torch.cuda.synchronize()
+    blocks = sharded.encode_shards_partitioned_local(encs, device=str(dev))
+    got_dict = hashlib.sha256(b"".join(b.dict_section for b in blocks)).hexdigest()
+    hr = hashlib.sha256()
+    for b in blocks:
+        hr.update(b.rows)
+        assert b.col_size == col_size and b.col_base == col_base, "column stats differ between the sharded and the single block"
+    assert sum(b.num_rows for b in blocks) == nrows
+    assert got_dict == h_dict, "dictionary section differs between 3 shards and 1"
+    assert hr.hexdigest() == h_rows, "row section differs between 3 shards and 1"
+    for e in encs:
+        e.close()
+    return {"rows": int(nrows), "dict_entries": int(p1.dict_entries), "rows_walked": walked, "dict_sha256": h_dict[:16], "rows_sha256": h_rows[:16],
+            "checks": "row count; dictionary size header, entry count and strict strcmp order of every entry; walk of the first rows; "
+                      "dictionary, column stats and row bytes equal to the same table encoded as 3 row shards"}
+
+
+def e2e_cli(torch, table, gb=2.0):
+    """SURVEY.md 8d protocol (b): the shipped convertDWfile binary as a child process on a page-cache-warm file,
+    wall clock from exec to exit (process start, HIP start-up, file read, H2D, encode, D2H, pipe to the compressor
+    child, rename): compressor child replaced by `cat`, and the default gzip."""
+    import stat
+    from zdw_amd import build
+    rows = table.rows_for_bytes(gb * 1e9)
+    buf, nbytes = table.generate(0, rows)
+    d = tempfile.mkdtemp(prefix="zdwcli_")
+    res = {"bytes": int(nbytes), "file": "synthetic table of the same shape, page-cache warm"}
+    try:
+        with open(os.path.join(d, "t.sql"), "wb") as f:
+            f.write(buf[:nbytes].cpu().numpy().tobytes())
+        with open(os.path.join(d, "t.desc.sql"), "wb") as f:
+            f.write(table.desc)
+        del buf
+        shim = os.path.join(d, "shim")
+        os.makedirs(shim)
+        sp = os.path.join(shim, "gzip")
+        with open(sp, "w") as f:
+            f.write("#!/bin/sh\nexec cat\n")
+        os.chmod(sp, os.stat(sp).st_mode | stat.S_IXUSR)
+        with open(os.path.join(d, "t.sql"), "rb") as f:          # warm the page cache
+            while f.read(64 << 20):
+                pass
+        for label, path in (("cat_shim", shim + os.pathsep + os.environ.get("PATH", "")), ("gzip", os.environ.get("PATH", ""))):
+            env = dict(os.environ, PATH=path)
+            t0 = time.perf_counter()
+            r = subprocess.run([build.CLI_EXE, "-q", os.path.join(d, "t.sql")], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            outp = os.path.join(d, "t.zdw.gz")
+            if r.returncode != 0 or not os.path.exists(outp):
+                res[label + "_MBps"] = None
+                res[label + "_error"] = r.stderr[-200:].decode(errors="replace")
+                continue
+            res[label + "_MBps"] = round(nbytes / 1e6 / dt, 1)
+            res[label + "_s"] = round(dt, 2)
+            os.unlink(outp)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
 def stream_copy_gbps(torch, src):
     """Device-to-device copy of (up to) 4 GB of the input image: bytes read + bytes written per second."""
     n = min(int(src.numel()), 4 << 30)
@@ -111,6 +230,12 @@ def main():
     ap.add_argument("--p-empty", type=float, default=0.25, help="fraction of empty fields (0.25 = BASELINE's table; other values: not a valid bench line)")
     ap.add_argument("--dead-cols", type=float, default=0.0, help="fraction of columns empty in every row (0 = BASELINE's table)")
     ap.add_argument("--pass1-only", action="store_true", help="profiling: time pass 1 alone (not a valid bench line)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the property checks of the outputs after the timed region")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end timing of the convertDWfile binary after the timed region")
+    ap.add_argument("--e2e-gb", type=float, default=2.0, help="size of the file the convertDWfile binary is timed on")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank holds its own --gb of rows (default); strong = ONE table of --gb split over the ranks "
+                         "(BASELINE configs[3] as written).  With N > 1 the line of a weak run also carries a strong measurement.")
     args = ap.parse_args()
 
     import torch
@@ -131,8 +256,17 @@ def main():
 
     # ---- synthetic table, generated in HBM; rank r holds rows [r*R, (r+1)*R) ----
     table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local, word_maxlen=args.word_maxlen, p_empty=args.p_empty, dead_cols=args.dead_cols)
-    rows_per_rank = table.rows_for_bytes(args.gb * 1e9)
-    buf, nbytes = table.generate(rank * rows_per_rank, rows_per_rank)
+    rows_total = table.rows_for_bytes(args.gb * 1e9)
+
+    def rank_rows(mode):
+        """(first row, rows) of this rank: weak = its own --gb; strong = its share of ONE table of --gb"""
+        if mode == "weak" or world == 1:
+            return rank * rows_total, rows_total
+        lo_r, hi_r = rows_total * rank // world, rows_total * (rank + 1) // world
+        return lo_r, hi_r - lo_r
+
+    row0, rows_per_rank = rank_rows(args.scaling)
+    buf, nbytes = table.generate(row0, rows_per_rank)
     torch.cuda.synchronize()
 
     # N > 1: every rank's table must hold the union of all ranks' strings (it is not regrown after pass 1):
@@ -145,6 +279,8 @@ def main():
     enc.set_input_device(buf.data_ptr(), nbytes, keepalive=buf)
     enc.enable_timing(True)
 
+    last = {}
+
     def step():
         if world > 1 and args.independent_blocks:
             blocks = sharded.encode_independent_blocks_dist(enc, rank, world, fetch=False)
@@ -156,9 +292,10 @@ def main():
             raise capi.ZdwError(rc, "pass1")
         if args.pass1_only:
             return p1.num_rows, 0, 0
-        _, dlen, _ = enc.dict_section_device()
-        enc.stats()
-        _, rlen = enc.pass2_device()
+        dptr, dlen, _ = enc.dict_section_device()
+        stats = enc.stats()
+        rptr, rlen = enc.pass2_device()
+        last.update(p1=p1, dict=(dptr, dlen), rows=(rptr, rlen), stats=stats)
         return p1.num_rows, dlen, rlen
 
     def fence():
@@ -191,6 +328,31 @@ def main():
     ms = dt / args.steps * 1e3
     stages = enc.stage_times()
 
+    # N > 1, weak run: the same ranks on ONE table of --gb (BASELINE configs[3] as written), reported beside the weak number
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.independent_blocks:
+        s_row0, s_rows = rank_rows("strong")
+        del buf
+        enc.close()
+        buf, s_bytes = table.generate(s_row0, s_rows)
+        torch.cuda.synchronize()
+        enc = capi.Encoder(table.types, device=local, dict_slots=slots)
+        enc.set_input_device(buf.data_ptr(), s_bytes, keepalive=buf)
+        for _ in range(max(1, args.warmup)):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        sdt = time.perf_counter() - t1
+        t = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tb = torch.tensor([s_bytes], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tb)
+        strong = {"value": round(int(tb.item()) / 1e6 / (float(t.item()) / args.steps), 1), "unit": "MB/s", "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3),
+                  "input_bytes_total": int(tb.item()), "workload": "ONE synthetic table of %.1f GB split over %d ranks by rows" % (int(tb.item()) / 1e9, world)}
+
     if rank == 0:
         out_local = dict_len + rows_len + 9 + args.cols * 9
         per = {k: round(v[0] / max(1, args.steps), 3) for k, v in stages.items() if v[1]}
@@ -208,9 +370,10 @@ def main():
             "metric": "TSV->ZDW encode throughput (input bytes / wall time, input resident in HBM, raw .zdw left in HBM)",
             "value": round(total_in / 1e6 / (dt / args.steps), 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
-            "config": {"workload": "synthetic TSV %.1f GB x %d cols per GPU, mixed VARCHAR/LONG, Zipf(1.1) strings over 2^20 words, 25%% empty, 30%% repeat (BASELINE configs[3])"
-                                   % (nbytes / 1e9, args.cols),
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
+            "config": {"workload": "synthetic TSV %.1f GB x %d cols %s, mixed VARCHAR/LONG, Zipf(1.1) strings over 2^20 words, 25%% empty, 30%% repeat (BASELINE configs[3])"
+                                   % ((total_in if args.scaling == "strong" else nbytes) / 1e9, args.cols,
+                                      "split over the GPUs by rows" if (args.scaling == "strong" and world > 1) else "per GPU"),
                        "rows_per_gpu": int(nrows), "input_bytes_per_gpu": int(nbytes), "zdw_bytes_per_gpu": int(out_local),
                        "compression_ratio": round(nbytes / max(1, out_local), 3),
                        "parallelism": ("one ZDW block per GPU, %d GPUs, independent dictionaries (not the single-block file)" % world)
@@ -223,6 +386,18 @@ def main():
             "stage_ms": per,
             "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "min": round(step_ms[0], 3)},
         }
+        if strong is not None:
+            res["strong_scaling"] = strong
+        # ---- after the timed region: are the bytes that were just timed the right ones? ----
+        if world == 1 and not args.pass1_only and not args.no_verify and last:
+            try:
+                res["verify"] = verify_outputs(torch, capi, sharded, table, buf, nbytes, enc, rows_per_rank, last["p1"], last["dict"], last["rows"], last["stats"])
+                res["verified"] = True
+            except AssertionError as e:
+                res["verified"] = False
+                res["verify"] = {"error": str(e)}
+        else:
+            res["verified"] = None
         # what a plain streaming copy reaches on this box (quote the fraction of both peaks)
         copy_gbps = stream_copy_gbps(torch, buf)
         res["roofline"]["stream_copy"] = {"measured": round(copy_gbps, 1), "unit": "GB/s (read + write)",
@@ -236,6 +411,14 @@ def main():
             res["cpu_baseline"]["host_cores"] = os.cpu_count()
         else:
             res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 1, "kind": "port", "sample": "skipped (--no-cpu)"}
+        if not args.no_e2e and not args.pass1_only:
+            enc.close()
+            del buf
+            torch.cuda.empty_cache()
+            try:
+                res["e2e_cli"] = e2e_cli(torch, table, args.e2e_gb)
+            except Exception as e:  # noqa: BLE001
+                res["e2e_cli"] = {"error": repr(e)[:200]}
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -63,7 +63,10 @@ typedef struct zdw_opts {
     uint32_t first_row_capacity;   /* initial m_LongestLine; 0 = 16384 (ConvertToZDW.cpp:965) */
     uint64_t dict_slots;           /* initial hash-table slots for the string dictionary; 0 = automatic */
     uint64_t max_dict_bytes;       /* a block's dictionary may not exceed this; 0 = the format's limit (2^32 - 1) */
-    uint64_t reserved[3];
+    uint64_t max_device_bytes;     /* device memory this context may hold; 0 = no limit of its own.  A block whose buffers do not
+                                      fit (this limit or the device itself) ends earlier, as the reference ends a block when its
+                                      memory limit trips (--mem-limit, stringheap.cpp:74-86) */
+    uint64_t reserved[2];
 } zdw_opts;
 
 /* Where a block must end when it cannot hold the whole remaining input (reference: memory-driven,
@@ -163,6 +166,13 @@ int zdw_shard_import_ranges(zdw_ctx *ctx, const uint64_t *col_min, const uint64_
 int zdw_shard_export_uniques(zdw_ctx *ctx, const void **d_lens, const void **d_bytes, uint64_t *count, uint64_t *nbytes);
 int zdw_shard_import_uniques(zdw_ctx *ctx, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes);
 int zdw_shard_last_row(zdw_ctx *ctx, uint64_t *stored /* ncols */);
+/* m_LongestLine of a row-sharded block (block header field 2).  The reference's line buffer starts at 16384, doubles
+ * while a row does not fit and never shrinks (getnextrow.cpp:57-65), so what it holds after a shard's rows depends on
+ * what it held before them.  caps[k] = the buffer after this shard's rows when it held 16384 << k before them
+ * (k = 0 .. ZDW_LINE_CAPS - 1): composing the shards' tables in row order gives the block's value without a
+ * sequential chain of exchanges.  zdw_pass1_result.longest_line is the k = 0 entry of a context's first block. */
+#define ZDW_LINE_CAPS 18
+int zdw_shard_line_caps(zdw_ctx *ctx, uint32_t *caps /* ZDW_LINE_CAPS */);
 int zdw_shard_set_prev_row(zdw_ctx *ctx, const uint64_t *stored /* ncols, NULL = zeros */);
 
 /* Range-partitioned dictionary (instead of export / import of the union): the node-wide dictionary is sorted

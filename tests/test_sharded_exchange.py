@@ -39,6 +39,20 @@ def _worker(rank, world, port, q):
     assert two[0] == recv_counts and two[1] == [3 * (peer + 1 + rank) + peer for peer in range(world)]
     got = sharded.alltoallv(payload, send_counts, recv_counts)
     gathered = sharded.allgather_i64([rank * 7, -rank], "cpu")
+    # the status of a rank-local step travels with the range all-reduce; the line-buffer tables with the halo
+    rs = sharded.allreduce_ranges(mn, mx, seen, device="cpu", status=15 if rank == 1 else 0)
+    assert rs[:3] == r and rs[3] == 15
+    caps = [max(16384 << k, 65536 if rank == 0 else 16384) for k in range(18)]       # rank 0 holds a 40 KB row
+    prev2, longest = sharded.exchange_prev_row(last, nrows, rank, world, device="cpu", line_caps=caps)
+    assert prev2 == prev and longest == 65536
+    from zdw_amd import capi
+    sharded.agree(0, "cpu", what="nothing")
+    try:
+        sharded._guarded(lambda: (_ for _ in ()).throw(capi.ZdwError(7, "rank-local")) if rank == 0 else 1, "cpu", None, "a step")
+        raised = None
+    except capi.ZdwError as e:
+        raised = e.code
+    assert raised == 7, raised          # both ranks: the one that failed and the one that did not
     q.put((rank, r, ol.tolist(), ob.tolist(), prev, recv_counts, got.tolist(), gathered))
     dist.barrier()
     dist.destroy_process_group()
@@ -99,3 +113,17 @@ def test_chain_longest_lines():
     """the reference's line buffer only grows: block i's header carries the largest of shards 0..i"""
     assert sharded.chain_longest_lines([16384, 65536, 16384, 32768, 131072, 16384]) == [16384, 65536, 65536, 65536, 131072, 131072]
     assert sharded.chain_longest_lines([]) == []
+
+
+def test_compose_line_caps():
+    """m_LongestLine of a row-sharded block: the shards' tables composed in row order (the buffer a shard starts with is
+    what the shards before it left)."""
+    same = [16384 << k for k in range(18)]                       # a shard without long rows leaves the buffer as it was
+    grows = [max(16384 << k, 65536) for k in range(18)]          # a 40 KB row: at least 65536 afterwards
+    assert sharded.compose_line_caps([same, same]) == [16384, 16384]
+    assert sharded.compose_line_caps([same, grows, same]) == [16384, 65536, 65536]
+    assert sharded.compose_line_caps([grows, [32768] + [16384 << k for k in range(1, 18)]]) == [65536, 65536]
+    # the start matters: this shard doubles once more only when it starts from 16384 (a chunk boundary on an escaped newline)
+    odd = [65536] + [16384 << k for k in range(1, 18)]
+    assert sharded.compose_line_caps([odd]) == [65536] and sharded.compose_line_caps([[32768] + same[1:], odd]) == [32768, 32768]
+    assert sharded.compose_line_caps([]) == []

@@ -12,7 +12,7 @@ STAGE_NAMES = ["scan_rows", "pass1", "dict_compact", "dict_sort", "dict_emit", "
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("trim_trailing_spaces", C.c_uint32),
-                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("max_dict_bytes", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("max_dict_bytes", C.c_uint64), ("max_device_bytes", C.c_uint64), ("reserved", C.c_uint64 * 2)]
 
 
 class SplitHint(C.Structure):
@@ -75,6 +75,7 @@ def lib():
         L.zdw_shard_set_offsets.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int]
         L.zdw_shard_last_row.argtypes = [vp, u64p]
         L.zdw_shard_set_prev_row.argtypes = [vp, u64p]
+        L.zdw_shard_line_caps.argtypes = [vp, u32p]
         _lib = L
     return _lib
 
@@ -95,7 +96,7 @@ class Block:
 class Encoder:
     """One zdw_ctx: the per-block seam of ConvertToZDW::processFile (cplusplus/ConvertToZDW.cpp:805-872)."""
 
-    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0, max_dict_bytes=0):
+    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0, max_dict_bytes=0, max_device_bytes=0):
         self.L = lib()
         self.ncols = len(col_types)
         types = (C.c_uint8 * max(1, self.ncols))(*col_types)
@@ -106,6 +107,7 @@ class Encoder:
         o.first_row_capacity = first_row_capacity
         o.dict_slots = dict_slots
         o.max_dict_bytes = max_dict_bytes
+        o.max_device_bytes = max_device_bytes
         h = C.c_void_p()
         rc = self.L.zdw_ctx_create(types, self.ncols, C.byref(o), C.byref(h))
         if rc:
@@ -251,6 +253,12 @@ class Encoder:
         out = (C.c_uint64 * max(1, self.ncols))()
         self._chk(self.L.zdw_shard_last_row(self.h, out))
         return list(out)[:self.ncols]
+
+    def line_caps(self):
+        """[cap after this shard's rows when the line buffer held 16384 << k before them, k = 0..17]"""
+        out = (C.c_uint32 * 18)()
+        self._chk(self.L.zdw_shard_line_caps(self.h, out))
+        return list(out)
 
     def set_prev_row(self, stored):
         if stored is None:

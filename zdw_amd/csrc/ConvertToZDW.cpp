@@ -293,6 +293,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         opts.trim_trailing_spaces = bTrimTrailingSpaces ? 1u : 0u;
         if (const char *e = getenv("ZDW_DICT_SLOTS")) opts.dict_slots = strtoull(e, NULL, 10);
         if (const char *e = getenv("ZDW_MAX_DICT_BYTES")) opts.max_dict_bytes = strtoull(e, NULL, 10);
+        if (const char *e = getenv("ZDW_MAX_DEVICE_BYTES")) opts.max_device_bytes = strtoull(e, NULL, 10);
         const int rc = zdw_ctx_create(schema.types.data(), static_cast<uint32_t>(numColumns), &opts, &guard.ctx);
         if (rc != ZDW_OK) {
             libError = zdw_last_error(NULL);
@@ -358,19 +359,23 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         zdw_pass1_result p1;
         uint64_t sectionLen = 0; uint8_t indexSize = 0;
         int rc;
-        // A block whose dictionary outgrows its limit is redone with half the rows (the reference ends a
-        // block for the same reason -- memory -- at a point that depends on the machine).
+        // A block whose dictionary outgrows its limit, or whose outputs do not fit the device, is redone with half the
+        // rows (the reference ends a block for the same reason -- memory -- at a point that depends on the machine).
+        // Everything of the block is built on the device before a byte of it is written, so a retry costs no output.
+        uint32_t used = 0;
         for (;;) {
             rc = zdw_block_pass1(ctx, forced ? &hint : NULL, &p1);
             if (rc != ZDW_OK || p1.num_rows == 0) break;
-            rc = zdw_block_dict_device(ctx, NULL, &sectionLen, &indexSize);     // built and measured on the device; written below
+            rc = zdw_block_dict_device(ctx, NULL, &sectionLen, &indexSize);
+            if (rc == ZDW_OK) rc = zdw_block_stats(ctx, colSize.data(), colBase.data(), &used);
+            if (rc == ZDW_OK) rc = zdw_block_pass2_device(ctx, NULL, NULL);
             if (rc != ZDW_OUT_OF_MEMORY || p1.num_rows < 2) break;
             forced = true;
             hint.max_rows = p1.num_rows / 2;
             hint.partial_fields = 0;
-            if (!bQuiet) statusOutput(INFO, "\nDictionary too large for one block: retrying with %u rows\n", hint.max_rows);
+            if (!bQuiet) statusOutput(INFO, "\nBlock too large for the device or its dictionary limit: retrying with %u rows\n", hint.max_rows);
         }
-        clock.mark("pass1+dict");
+        clock.mark("pass1+dict+pass2");
         if (rc == ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW) {
             statusOutput(ERROR, "\nRow %u had the problem\n", p1.bad_row);
             res = WRONG_NUM_OF_COLUMNS_ON_A_ROW;
@@ -400,15 +405,11 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
             rc = zdw_block_dict_write(ctx, writeToPipe, &out, NULL, NULL);
             if (rc != ZDW_OK) ok = false;
             clock.mark("write_dict");
-            uint32_t used = 0;
-            rc = zdw_block_stats(ctx, colSize.data(), colBase.data(), &used);
             if (rc == ZDW_OK) {
                 ok = ok && out.put(colSize.data(), numColumns);
                 for (uint32_t u = 0; u < used; ++u) ok = ok && out.le(colBase[u], 8);
                 if (!bQuiet) statusOutput(INFO, "\nWriting rows\n");
-                rc = zdw_block_pass2_device(ctx, NULL, NULL);
-                clock.mark("stats+pass2");
-                if (rc == ZDW_OK && zdw_block_pass2_write(ctx, writeToPipe, &out, NULL) != ZDW_OK) ok = false;
+                if (zdw_block_pass2_write(ctx, writeToPipe, &out, NULL) != ZDW_OK) ok = false;
                 clock.mark("write_rows");
             }
         }

@@ -20,9 +20,14 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Device memory a context may hold (zdw_opts.max_device_bytes; 0 = whatever the device gives): lets tests and
+// callers that share a GPU make the encoder end its blocks early instead of failing.
+struct Budget { size_t used = 0, cap = 0; };
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    Budget *bud = nullptr;
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap && p) return hipSuccess;
@@ -31,12 +36,18 @@ struct DevBuf {
         // race), and every regrowth is a hipFree (a device synchronisation) plus a hipMalloc in the middle of a block:
         // a large buffer gets 3 % more than asked, one that has to grow an eighth more.
         if (want >= (1u << 20)) want += want / 32;
-        if (p) { want += want / 8; (void)hipFree(p); p = nullptr; cap = 0; }
+        if (p) { want += want / 8; release(); }
+        if (bud && bud->cap && bud->used + want > bud->cap) return hipErrorOutOfMemory;
         hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want; else p = nullptr;
+        if (e == hipSuccess) { cap = want; if (bud) bud->used += want; }
+        else { p = nullptr; (void)hipGetLastError(); }      // handled here: do not leave the error behind for a later hipGetLastError()
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p) { (void)hipFree(p); if (bud) bud->used -= cap; }
+        p = nullptr; cap = 0;
+    }
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
@@ -77,8 +88,17 @@ struct zdw_ctx {
     std::vector<int32_t> numidx;
     DevBuf d_kind, d_recoff, d_numidx;
     bool trim = false;
-    uint32_t row_cap = FIRST_ROW_CAP;      // emulated m_LongestLine, persists across blocks
+    uint32_t row_cap = FIRST_ROW_CAP;      // emulated m_LongestLine, persists across the blocks of one input
+    uint32_t first_row_cap = FIRST_ROW_CAP; // what it starts from for every input (ConvertToZDW.cpp:965)
+    uint32_t row_cap_block = FIRST_ROW_CAP; // its value when the current block began (a re-run of the block starts from it again)
+    uint64_t row_cap_block_lo = ~0ull;
+    Budget budget;
+    bool oom_seen = false;                 // a call ended in OUT_OF_MEMORY: the next pass 1 starts from released block buffers
+    std::vector<LongRow> long_list;        // this block's rows of 16383 bytes or more, by position (zdw_shard_line_caps replays them)
+    uint64_t long_read_end = 0;
+    bool long_tail = false;
     uint64_t slots_opt = 0, slots_learned = 0, max_dict_bytes = 0;
+    uint32_t rows_learned = 0;             // rows of the block slots_learned was enough for
     // input image
     const uint8_t *d_in = nullptr;
     uint64_t n = 0;
@@ -141,7 +161,7 @@ int fail(zdw_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
+    if (c) { c->err = buf; if (code == ZDW_OUT_OF_MEMORY) c->oom_seen = true; } else g_create_error = buf;
     return code;
 }
 
@@ -217,6 +237,27 @@ void replay_row_reads(const uint8_t *row, uint64_t len, bool terminated, uint32_
     (void)terminated;
 }
 
+// The line buffer after this block's rows, starting from *cap (rows that fit the running buffer cannot grow it and
+// are not fetched; every fetched row grows it, so a call copies a handful of rows at most).
+int replay_long_rows(zdw_ctx *c, uint32_t *cap)
+{
+    std::vector<uint8_t> rowbuf;
+    for (const LongRow &r : c->long_list) {
+        if (r.start > c->long_read_end) continue;              // belongs to a later block
+        if (r.len <= (uint64_t)*cap - 1) continue;             // fits the current buffer: no growth possible
+        rowbuf.resize(r.len);
+        HIP_TRY(c, hipMemcpy(rowbuf.data(), c->d_in + r.start, r.len, hipMemcpyDeviceToHost));
+        replay_row_reads(rowbuf.data(), r.len, true, cap);
+    }
+    if (c->long_tail && c->n - c->hi >= (uint64_t)*cap - 1) {
+        const uint64_t tl = c->n - c->hi;
+        rowbuf.resize(tl);
+        HIP_TRY(c, hipMemcpy(rowbuf.data(), c->d_in + c->hi, tl, hipMemcpyDeviceToHost));
+        replay_row_reads(rowbuf.data(), tl, false, cap);
+    }
+    return ZDW_OK;
+}
+
 int upload_schema(zdw_ctx *c)
 {
     HIP_TRY(c, c->d_kind.ensure(c->ncols));
@@ -234,7 +275,8 @@ int after_input(zdw_ctx *c)
 {
     reset_block(c);
     c->lo = c->next_lo = 0;
-    c->row_cap = c->row_cap ? c->row_cap : FIRST_ROW_CAP;
+    c->row_cap = c->first_row_cap;          // a new input starts with a fresh line buffer (ConvertToZDW.cpp:965)
+    c->row_cap_block_lo = ~0ull;
     c->hi = 0;
     c->avg_row = 0;
     if (c->n) {
@@ -443,6 +485,18 @@ int run_pass2(zdw_ctx *c)
     return ZDW_OK;
 }
 
+std::vector<DevBuf *> all_device_buffers(zdw_ctx *c)
+{
+    return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->scan_tmp, &c->rec,
+                      &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
+                      &c->own_upos, &c->own_ulen, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
+                      &c->own_out, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
+                      &c->uniq_pos, &c->uniq_len, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
+                      &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
+                      &c->extra_lens, &c->extra_offs, &c->exp_bytes, &c->d_used_recoff, &c->d_used_kind, &c->d_used_size,
+                      &c->d_used_base, &c->d_prev0, &c->d_last, &c->row_len, &c->row_off, &c->rows_out, &c->batch_pre};
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -491,10 +545,12 @@ int zdw_ctx_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opt
     c->nnum = nnum;
     if (opts) {
         c->trim = opts->trim_trailing_spaces != 0;
-        c->row_cap = opts->first_row_capacity ? opts->first_row_capacity : FIRST_ROW_CAP;
+        c->first_row_cap = c->row_cap = opts->first_row_capacity ? opts->first_row_capacity : FIRST_ROW_CAP;
         c->slots_opt = opts->dict_slots;
         c->max_dict_bytes = opts->max_dict_bytes;
+        if (opts->struct_size >= offsetof(zdw_opts, max_device_bytes) + sizeof(uint64_t)) c->budget.cap = opts->max_device_bytes;
     }
+    for (DevBuf *b : all_device_buffers(c)) b->bud = &c->budget;
     int rc = upload_schema(c);
     if (rc) { g_create_error = c->err; zdw_ctx_destroy(c); return rc; }
     *out = c;
@@ -507,15 +563,7 @@ void zdw_ctx_destroy(zdw_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_times(c);
-    DevBuf *bufs[] = {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->scan_tmp, &c->rec,
-                      &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
-                      &c->own_upos, &c->own_ulen, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
-                      &c->own_out, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
-                      &c->uniq_pos, &c->uniq_len, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
-                      &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
-                      &c->extra_lens, &c->extra_offs, &c->exp_bytes, &c->d_used_recoff, &c->d_used_kind, &c->d_used_size,
-                      &c->d_used_base, &c->d_prev0, &c->d_last, &c->row_len, &c->row_off, &c->rows_out, &c->batch_pre};
-    for (DevBuf *b : bufs) b->release();
+    for (DevBuf *b : all_device_buffers(c)) b->release();
     c->h_dict.release(); c->h_rows.release();
     for (int i = 0; i < 2; ++i) { c->h_piece[i].release(); if (c->piece_ev[i]) (void)hipEventDestroy(c->piece_ev[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -576,7 +624,19 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     (void)hipSetDevice(c->device);
     hipStream_t s = c->stream;
     reset_block(c);
+    if (c->oom_seen) {
+        // The caller comes back with fewer rows after an allocation failed: buffers sized for the larger attempt would
+        // keep the memory the smaller one needs.  Everything but the input image and the schema is rebuilt on demand.
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (DevBuf *b : all_device_buffers(c))
+            if (b != &c->in_owned && b != &c->d_kind && b != &c->d_recoff && b != &c->d_numidx) b->release();
+        c->oom_seen = false;
+    }
     const uint64_t lo = c->lo, hi = c->hi;
+    // a block that is run again (smaller split hint after an oversized dictionary) starts from the line buffer the block
+    // began with: rows that move to the next block must not have grown it
+    if (c->row_cap_block_lo == lo) c->row_cap = c->row_cap_block;
+    else { c->row_cap_block = c->row_cap; c->row_cap_block_lo = lo; }
     res->longest_line = c->row_cap;
     res->is_last_block = 1;
     res->bytes_consumed = lo;
@@ -627,9 +687,15 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     if (hint && hint->max_rows != 0xFFFFFFFFu && hint->max_rows < total_rows) {
         tripped = true; row_limit = hint->max_rows; partial = hint->partial_fields;
     }
-    const uint32_t nrows = tripped ? row_limit : (uint32_t)total_rows;
-    c->nrows = nrows;
-    c->is_last = !tripped;
+    uint32_t nrows = tripped ? row_limit : (uint32_t)total_rows;
+    // Buffers that grow with the block's rows (records, dictionary table): when the device (or zdw_opts.max_device_bytes)
+    // cannot hold them the block ends earlier -- half the rows, again if need be -- instead of failing; the reference ends
+    // a block for the same reason, memory, at a point that depends on the machine (Q9).
+    auto fewer_rows = [&]() {
+        if (nrows < 2) return false;
+        nrows /= 2; tripped = true; row_limit = nrows; partial = 0;
+        return true;
+    };
 
     // ---- pass 1 proper (also runs for zero rows when a partial row pollutes the block) ----
     // column facts and ranges live in per-wave LDS when they fit there (and in the packed 14 + 16 bit form)
@@ -637,28 +703,51 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
                             c->nnum < 16384 && c->rec_stride < 65536;
     // dictionary table (32-byte slots): one slot per 32 input bytes, within [2^14, 2^25] (1 GiB); load factor
     // limit 5/8; a context remembers what its last block needed
-    uint64_t nslots = c->slots_opt;
-    if (const char *e = getenv("ZDW_DICT_SLOTS")) nslots = strtoull(e, nullptr, 10);   // experiments
-    if (!nslots) {
-        nslots = 1ull << 14;
-        const uint64_t want = (hi > lo ? hi - lo : 0) / 32;
-        while (nslots < want && nslots < (1ull << 25)) nslots <<= 1;
-        if (c->slots_learned > nslots) nslots = c->slots_learned;
-    }
-    { uint64_t p2 = 1; while (p2 < nslots) p2 <<= 1; nslots = p2; }
+    auto first_table = [&](uint32_t rows_in_block) {
+        uint64_t ns = c->slots_opt;
+        if (const char *e = getenv("ZDW_DICT_SLOTS")) ns = strtoull(e, nullptr, 10);   // experiments
+        if (!ns) {
+            ns = 1ull << 14;
+            // (the block's share of the remaining input, by rows)
+            const uint64_t bytes = total_rows ? (uint64_t)((double)(hi > lo ? hi - lo : 0) * rows_in_block / (double)total_rows) : 0;
+            while (ns < bytes / 32 && ns < (1ull << 25)) ns <<= 1;
+            if (c->slots_learned > ns && rows_in_block >= c->rows_learned) ns = c->slots_learned;
+        }
+        uint64_t p2 = 1;
+        while (p2 < ns) p2 <<= 1;
+        return p2;
+    };
+    uint64_t nslots = first_table(nrows);
     HIP_TRY(c, c->col_min.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_max.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_seen.ensure(c->ncols + 8));
-    HIP_TRY(c, c->rec.ensure((uint64_t)nrows * c->rec_stride + 64));      // slack: 8-byte reads of 4-byte fields, 16-byte staging reads
+    for (;;) {
+        const hipError_t e = c->rec.ensure((uint64_t)nrows * c->rec_stride + 64);      // slack: 8-byte reads of 4-byte fields, 16-byte staging reads
+        if (e == hipSuccess) break;
+        if (e != hipErrorOutOfMemory || !fewer_rows())
+            return fail(c, e == hipErrorOutOfMemory ? ZDW_OUT_OF_MEMORY : ZDW_UNKNOWN_ERROR, "record matrix of %llu bytes: %s",
+                        (unsigned long long)nrows * c->rec_stride, hipGetErrorString(e));
+    }
     const uint64_t blk_bytes = hi > lo ? hi - lo : 0;
     const uint32_t long_cap = (uint32_t)std::min<uint64_t>(blk_bytes / (FIRST_ROW_CAP - 1) + 2, 1u << 26);
     HIP_TRY(c, c->long_rows.ensure((uint64_t)long_cap * sizeof(LongRow)));
     P1Status st{};
     bool dq_grown = false;
     for (int attempt = 0;; ++attempt) {
-        if (nslots > (1ull << 31)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary needs more than 2^31 table slots; split the block");
-        HIP_TRY(c, c->slots.ensure(nslots * 32));
-        {   // unique ids: the table's load limit plus what waves can leave unused in their chunks (holes)
-            const uint64_t cap = std::min<uint64_t>(nslots / 8 * 5 + 64ull * 65536, 0xFFFFFFF0ull);
-            HIP_TRY(c, c->uniq_pos.ensure(cap * 8)); HIP_TRY(c, c->uniq_len.ensure(cap * 4));
+        {   // the table and the unique ids: the table's load limit plus what waves can leave unused in their chunks (holes)
+            const uint64_t cap = std::min<uint64_t>(nslots / 8 * 5 + 64ull * 8192 + nslots / 16, 0xFFFFFFF0ull);
+            hipError_t e = nslots > (1ull << 31) ? hipErrorOutOfMemory : c->slots.ensure(nslots * 32);
+            if (e == hipSuccess) e = c->uniq_pos.ensure(cap * 8);
+            if (e == hipSuccess) e = c->uniq_len.ensure(cap * 4);
+            if (e == hipErrorOutOfMemory) {
+                // no room for a table of this block's uniques: fewer rows, fewer uniques (and a smaller record matrix)
+                if (!fewer_rows()) return fail(c, ZDW_OUT_OF_MEMORY, "no room for a dictionary table of %llu slots; split the block", (unsigned long long)nslots);
+                c->slots.release(); c->uniq_pos.release(); c->uniq_len.release(); c->rec.release();
+                while (c->rec.ensure((uint64_t)nrows * c->rec_stride + 64) != hipSuccess)
+                    if (!fewer_rows()) return fail(c, ZDW_OUT_OF_MEMORY, "no room for the record matrix of a single row; split the block");
+                nslots = std::min(nslots, first_table(nrows));
+                attempt = -1;
+                continue;
+            }
+            if (e != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary table: %s", hipGetErrorString(e));
             c->id_cap = (uint32_t)cap;
         }
         HIP_TRY(c, hipMemsetAsync(c->slots.p, 0, nslots * 32, s));
@@ -721,15 +810,17 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         }
         HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
-        hipError_t le = hipGetLastError();
+        hipError_t le = hipGetLastError();      // (allocation failures handled above have cleared theirs: DevBuf::ensure)
         if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));
         if (st.nul_seen == 2) return fail(c, ZDW_UNKNOWN_ERROR, "a single field of 1 GiB or more is not supported");
         if (!st.overflow) break;
-        nslots <<= 4;                       // table too small for this block's uniques: grow and redo the pass
-        if (attempt > 6) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
+        nslots <<= 2;                       // table too small for this block's uniques: grow and redo the pass
+        if (attempt > 12) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
     }
+    c->nrows = nrows;
+    c->is_last = !tripped;
     res->table_slots = nslots;
-    c->slots_learned = nslots;
+    c->slots_learned = nslots; c->rows_learned = nrows;
     res->dict_entries = st.entries;
 
     if (st.bad_row != 0xFFFFFFFFu && st.bad_row <= row_limit) {          // ConvertToZDW.cpp:810-812
@@ -739,29 +830,18 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
 
     // ---- m_LongestLine: replay the reference's buffer growth on rows that could have triggered it ----
     {
-        std::vector<LongRow> lr;
+        c->long_list.clear();
         uint32_t cnt = st.long_count;
         if (cnt > long_cap) cnt = long_cap;
         if (cnt) {
-            lr.resize(cnt);
-            HIP_TRY(c, hipMemcpy(lr.data(), c->long_rows.p, cnt * sizeof(LongRow), hipMemcpyDeviceToHost));
-            std::sort(lr.begin(), lr.end(), [](const LongRow &x, const LongRow &y) { return x.start < y.start; });
+            c->long_list.resize(cnt);
+            HIP_TRY(c, hipMemcpy(c->long_list.data(), c->long_rows.p, cnt * sizeof(LongRow), hipMemcpyDeviceToHost));
+            std::sort(c->long_list.begin(), c->long_list.end(), [](const LongRow &x, const LongRow &y) { return x.start < y.start; });
         }
-        std::vector<uint8_t> rowbuf;
-        const uint64_t read_end = tripped ? st.split_pos : c->n;   // pass 1 reads rows up to and including the one at the split
-        for (const LongRow &r : lr) {
-            if (r.start > read_end) continue;                      // belongs to a later block
-            if (r.len <= (uint64_t)c->row_cap - 1) continue;      // fits the current buffer: no growth possible
-            rowbuf.resize(r.len);
-            HIP_TRY(c, hipMemcpy(rowbuf.data(), c->d_in + r.start, r.len, hipMemcpyDeviceToHost));
-            replay_row_reads(rowbuf.data(), r.len, true, &c->row_cap);
-        }
-        if (!tripped && c->n > hi && c->n - hi >= (uint64_t)c->row_cap - 1) {   // unterminated tail read (and dropped) by pass 1
-            const uint64_t tl = c->n - hi;
-            rowbuf.resize(tl);
-            HIP_TRY(c, hipMemcpy(rowbuf.data(), c->d_in + hi, tl, hipMemcpyDeviceToHost));
-            replay_row_reads(rowbuf.data(), tl, false, &c->row_cap);
-        }
+        c->long_read_end = tripped ? st.split_pos : c->n;   // pass 1 reads rows up to and including the one at the split
+        c->long_tail = !tripped && c->n > hi;               // an unterminated tail is read (and dropped) by pass 1 as well
+        int rc_lr = replay_long_rows(c, &c->row_cap);
+        if (rc_lr) return rc_lr;
     }
     res->longest_line = c->row_cap;
     res->num_rows = nrows;
@@ -1004,6 +1084,20 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
                     (unsigned long long)c->nslots);
     c->extra_bytes = nbytes;
     c->dict_done = c->stats_done = c->p2_done = false;
+    return ZDW_OK;
+}
+
+int zdw_shard_line_caps(zdw_ctx *c, uint32_t *caps)
+{
+    if (!c || !caps || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    for (uint32_t k = 0; k < ZDW_LINE_CAPS; ++k) {
+        const uint64_t start = (uint64_t)FIRST_ROW_CAP << k;
+        uint32_t cap = start > 0x80000000ull ? 0x80000000u : (uint32_t)start;
+        int rc = replay_long_rows(c, &cap);
+        if (rc) return rc;
+        caps[k] = cap;
+    }
     return ZDW_OK;
 }
 

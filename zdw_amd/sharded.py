@@ -93,6 +93,21 @@ def chain_prev_rows(last_rows, nrows):
     return prev
 
 
+FIRST_ROW_CAP = 16384
+
+
+def compose_line_caps(tables):
+    """tables[i][k] = the reference's line buffer after shard i's rows when it held 16384 << k before them
+    (capi.Encoder.line_caps).  Returns the buffer after shards 0..i for every i: m_LongestLine of the block is the
+    last entry (the buffer starts at 16384 and only ever doubles, getnextrow.cpp:57-65)."""
+    out, cap = [], FIRST_ROW_CAP
+    for t in tables:
+        k = max(0, (int(cap) // FIRST_ROW_CAP).bit_length() - 1)
+        cap = int(t[min(k, len(t) - 1)])
+        out.append(cap)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # device-pointer <-> torch plumbing
 # ------------------------------------------------------------------------------------------------
@@ -145,13 +160,14 @@ def encode_shards_local(encoders, device="cuda"):
         if lens.numel():
             e.import_uniques(lens.data_ptr(), byts.data_ptr(), lens.numel(), byts.numel())
     prev = chain_prev_rows([e.last_row() for e in encoders], [p.num_rows for p in p1s])
+    longest = (compose_line_caps([e.line_caps() for e in encoders]) or [FIRST_ROW_CAP])[-1]      # one block: one header value
     blocks = []
     for i, e in enumerate(encoders):
         e.set_prev_row(prev[i])
         sec, _ = e.dict_section()
         cs, cb = e.stats()
         rows = e.pass2()
-        blocks.append(capi.Block(p1s[i].num_rows, p1s[i].longest_line, True, sec, cs, cb, rows, p1s[i]))
+        blocks.append(capi.Block(p1s[i].num_rows, longest, True, sec, cs, cb, rows, p1s[i]))
     return blocks
 
 
@@ -286,13 +302,14 @@ def encode_shards_partitioned_local(encoders, device="cuda"):
         _torch_done()
         e.set_offsets(mine.data_ptr() if mine.numel() else 0, mine.numel(), total, q == 0)
     prev = chain_prev_rows([e.last_row() for e in encoders], [p.num_rows for p in p1s])
+    longest = (compose_line_caps([e.line_caps() for e in encoders]) or [FIRST_ROW_CAP])[-1]      # one block: one header value
     blocks = []
     for i, e in enumerate(encoders):
         e.set_prev_row(prev[i])
         sec, _ = e.dict_section()
         cs, cb = e.stats()
         rows = e.pass2()
-        blocks.append(capi.Block(p1s[i].num_rows, p1s[i].longest_line, True, sec, cs, cb, rows, p1s[i]))
+        blocks.append(capi.Block(p1s[i].num_rows, longest, True, sec, cs, cb, rows, p1s[i]))
     return blocks
 
 
@@ -348,13 +365,15 @@ def _i64_to_u64(v):
 
 def partitioned_dictionary(enc, rank, world, device, group=None):
     """The dictionary steps of one rank with the range-partitioned dictionary (after the range exchange)."""
-    enc.sort_uniques()
-    mine = enc.sample_keys(SAMPLES_PER_SHARD)
+    def _sample():
+        enc.sort_uniques()
+        return enc.sample_keys(SAMPLES_PER_SHARD)
+    mine = _guarded(_sample, device, group, "sampling the dictionary")
     flat = [_u64_to_i64(w) for k in mine for w in k]
     allk = allgather_i64(flat, device, group=group)
     samples = [(_i64_to_u64(a[2 * i]), _i64_to_u64(a[2 * i + 1])) for a in allk for i in range(len(a) // 2)]
     splitters = pick_splitters(samples, world)
-    counts, nb, d_lens, d_bytes = enc.partition(splitters)
+    counts, nb, d_lens, d_bytes = _guarded(lambda: enc.partition(splitters), device, group, "partitioning the dictionary")
     lens = _wrap(d_lens, sum(counts) * 4, "<i4", device).clone()      # torch-owned copies: the collectives work on memory torch allocated
     byts = _wrap(d_bytes, sum(nb), "|u1", device).clone()
     _torch_done()
@@ -362,28 +381,70 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
     got_lens = alltoallv(lens, counts, rcounts, group=group)
     got_byts = alltoallv(byts, nb, rbytes, group=group)
     _torch_done()
-    slice_bytes = enc.owner_build(got_lens.data_ptr() if got_lens.numel() else 0, got_byts.data_ptr() if got_byts.numel() else 0,
-                                  got_lens.numel(), got_byts.numel())
-    slices = [a[0] for a in allgather_i64([slice_bytes], device, group=group)]
+    # (an owner whose build fails still reports: the size all-gather carries its code, so nobody waits for it in vain)
+    from . import capi
+    rc_own, slice_bytes = 0, 0
+    try:
+        slice_bytes = enc.owner_build(got_lens.data_ptr() if got_lens.numel() else 0, got_byts.data_ptr() if got_byts.numel() else 0,
+                                      got_lens.numel(), got_byts.numel())
+    except capi.ZdwError as e:
+        rc_own = e.code or 20
+    gathered = allgather_i64([slice_bytes, rc_own], device, group=group)
+    if any(a[1] for a in gathered):
+        raise capi.ZdwError(rc_own or max(a[1] for a in gathered), "building a dictionary range failed on a rank")
+    slices = [a[0] for a in gathered]
     bases, total = range_bases(slices)
-    offs = _wrap(enc.owner_offsets(bases[rank]), sum(rcounts) * 4, "<i4", device).clone()
+    d_offs = _guarded(lambda: enc.owner_offsets(bases[rank]), device, group, "dictionary offsets")
+    offs = _wrap(d_offs, sum(rcounts) * 4, "<i4", device).clone()
     _torch_done()
     back = alltoallv(offs, rcounts, counts, group=group)
     _torch_done()
-    enc.set_offsets(back.data_ptr() if back.numel() else 0, back.numel(), total, rank == 0)
+    _guarded(lambda: enc.set_offsets(back.data_ptr() if back.numel() else 0, back.numel(), total, rank == 0), device, group, "dictionary offsets")
 
 
-def allreduce_ranges(mn, mx, seen, device, group=None):
+def allreduce_ranges(mn, mx, seen, device, group=None, status=None):
     """RCCL/gloo form of merge_ranges: ONE all-reduce (max) over [~min, max, seen] -- ~x reverses the order of
-    int64, so the maximum of the complements is the complement of the minimum."""
+    int64, so the maximum of the complements is the complement of the minimum.  With `status` (this rank's return
+    code of pass 1) the same all-reduce carries it: returns (mn, mx, seen, worst status of any rank)."""
     import torch.distributed as dist
     tmn = u64_to_ordered_i64(mn)
     tmx = u64_to_ordered_i64(mx)
     n = tmn.numel()
-    t = torch.cat([torch.bitwise_not(tmn), tmx, torch.tensor(seen, dtype=torch.int64)]).to(device)
+    extra = [] if status is None else [int(status)]
+    t = torch.cat([torch.bitwise_not(tmn), tmx, torch.tensor(list(seen) + extra, dtype=torch.int64)]).to(device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     t = t.cpu()
-    return ordered_i64_to_u64(torch.bitwise_not(t[:n])), ordered_i64_to_u64(t[n:2 * n]), [int(x) for x in t[2 * n:].tolist()]
+    res = (ordered_i64_to_u64(torch.bitwise_not(t[:n])), ordered_i64_to_u64(t[n:2 * n]), [int(x) for x in t[2 * n:3 * n].tolist()])
+    return res if status is None else res + (int(t[3 * n].item()),)
+
+
+def agree(rc, device, group=None, what="a shard step"):
+    """Every rank learns the worst return code of a rank-local step and raises together: a rank that failed alone
+    would leave the others waiting in the next collective until the RCCL timeout."""
+    import torch.distributed as dist
+    from . import capi
+    t = torch.tensor([int(rc)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    worst = int(t.item())
+    if worst:
+        raise capi.ZdwError(worst, "%s failed on a rank (this rank: %d)" % (what, rc))
+
+
+def _guarded(fn, device, group, what):
+    """Run a rank-local step, then agree on its outcome (see agree)."""
+    from . import capi
+    rc, out, err = 0, None, None
+    try:
+        out = fn()
+    except capi.ZdwError as e:
+        rc, err = (e.code or 20), e
+    try:
+        agree(rc, device, group, what)
+    except capi.ZdwError:
+        if err is not None:
+            raise err
+        raise
+    return out
 
 
 def allgather_uniques(lens, byts, rank, world, group=None):
@@ -409,19 +470,28 @@ def allgather_uniques(lens, byts, rank, world, group=None):
     return concat_uniques(parts, skip=rank)
 
 
-def exchange_prev_row(last_row, nrows, rank, world, device, group=None):
-    """Row halo: every rank learns the stored values that precede its first row."""
+def exchange_prev_row(last_row, nrows, rank, world, device, group=None, line_caps=None):
+    """Row halo: every rank learns the stored values that precede its first row.  With `line_caps` (this rank's
+    capi.Encoder.line_caps()) the same all-gather carries the tables and the block's m_LongestLine is returned too."""
     import torch.distributed as dist
     ncols = len(last_row)
-    mine = torch.empty(ncols + 1, dtype=torch.int64, device=device)
+    caps = list(line_caps) if line_caps is not None else []
+    mine = torch.empty(ncols + 1 + len(caps), dtype=torch.int64)
     mine[0] = nrows
     if ncols:
-        mine[1:] = u64_to_ordered_i64(last_row).to(device)
-    allr = [torch.empty(ncols + 1, dtype=torch.int64, device=device) for _ in range(world)]
+        mine[1:ncols + 1] = u64_to_ordered_i64(last_row)
+    if caps:
+        mine[ncols + 1:] = torch.tensor(caps, dtype=torch.int64)
+    mine = mine.to(device)
+    allr = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine, group=group)
-    rows = [ordered_i64_to_u64(t[1:].cpu()) for t in allr]
+    allr = [t.cpu() for t in allr]
+    rows = [ordered_i64_to_u64(t[1:ncols + 1]) for t in allr]
     counts = [int(t[0].item()) for t in allr]
-    return chain_prev_rows(rows, counts)[rank]
+    prev = chain_prev_rows(rows, counts)[rank]
+    if line_caps is None:
+        return prev
+    return prev, compose_line_caps([[int(x) for x in t[ncols + 1:].tolist()] for t in allr])[-1]
 
 
 def encode_shard_dist(enc, rank, world, group=None, fetch=False, merge=None):
@@ -435,9 +505,13 @@ def encode_shard_dist(enc, rank, world, group=None, fetch=False, merge=None):
     from . import capi
     device = "cuda:%d" % torch.cuda.current_device()
     rc, p1 = enc.pass1()
-    if rc:
-        raise capi.ZdwError(rc, "pass 1 failed on rank %d" % rank)
-    mn, mx, seen = allreduce_ranges(*enc.export_ranges(), device=device, group=group)
+    # A rank-local failure (a row with a wrong field count, a NUL byte, memory) must fail the job on EVERY rank before
+    # the first data collective, or the others wait in it until the RCCL timeout: the range all-reduce carries the code.
+    ncols = enc.ncols
+    mine = enc.export_ranges() if rc == 0 else ([NO_MIN] * ncols, [0] * ncols, [0] * ncols)
+    mn, mx, seen, worst = allreduce_ranges(*mine, device=device, group=group, status=rc)
+    if worst:
+        raise capi.ZdwError(rc or worst, "pass 1 failed on rank %d" % rank if rc else "pass 1 failed on another rank")
     enc.import_ranges(mn, mx, seen)
     if merge == "partition":
         partitioned_dictionary(enc, rank, world, device, group=group)
@@ -445,15 +519,16 @@ def encode_shard_dist(enc, rank, world, group=None, fetch=False, merge=None):
         lens, byts = export_uniques_tensors(enc, device)
         olens, obyts = allgather_uniques(lens, byts, rank, world, group=group)
         _torch_done()
-        if olens.numel():
-            enc.import_uniques(olens.data_ptr(), obyts.data_ptr(), olens.numel(), obyts.numel())
-    prev = exchange_prev_row(enc.last_row(), p1.num_rows, rank, world, device, group=group)
+        _guarded(lambda: enc.import_uniques(olens.data_ptr(), obyts.data_ptr(), olens.numel(), obyts.numel()) if olens.numel() else None,
+                 device, group, "the dictionary import")
+    last, caps = _guarded(lambda: (enc.last_row(), enc.line_caps()), device, group, "the dictionary")
+    prev, longest = exchange_prev_row(last, p1.num_rows, rank, world, device, group=group, line_caps=caps)
     enc.set_prev_row(prev)
     if fetch:
         sec, _ = enc.dict_section()
         cs, cb = enc.stats()
         rows = enc.pass2()
-        return capi.Block(p1.num_rows, p1.longest_line, True, sec, cs, cb, rows, p1)
+        return capi.Block(p1.num_rows, longest, True, sec, cs, cb, rows, p1)
     _, dlen, _ = enc.dict_section_device()
     enc.stats()
     _, rlen = enc.pass2_device()
