@@ -5,25 +5,28 @@
 // together with GetNextRow (getnextrow.cpp:26-84), GetDataRow/get_next_column
 // (ConvertToZDW.cpp:265-323,1048-1067) and Dictionary::insert (dictionary.cpp:31-51).
 //
-// The kernel is bound by vector-ALU issue (one wave64 instruction per cycle and CU), so the design
-// goal is few instructions per input byte at full lane occupancy:
-//   * the TSV image is cut into 16 KiB spans; a wave visit owns every row that STARTS in its span
+// The kernel is bound by instruction issue and by the latency of one wave, not by HBM, so the design goal is
+// few instructions per input byte at full lane occupancy, and no wait that other work could cover:
+//   * the TSV image is cut into spans (16 KiB .. 1 MiB); a wave visit owns every row that STARTS in its span
 //     and follows the last of them past the span end (no row-length limit);
-//   * the wave streams 1 KiB rounds: one coalesced 16-byte load per lane (next round requested
-//     before the current one is looked at), kept in a two-round LDS byte ring.  Each lane finds the
-//     tabs / newlines among its 16 bytes with exact SWAR compares; backslash escapes (rare) take a
-//     wave-uniform side path;
-//   * one wave prefix sum per round places every boundary in a per-wave LDS ring of 4-byte
-//     descriptors {end position relative to the visit, ends-a-line}.  Column and row numbers are NOT
-//     computed per byte: a field is the gap between two consecutive descriptors, its column is its
-//     distance to the last line end before it and its row the number of line ends before it -- two
-//     ballots per 64 fields;
-//   * whenever 64 descriptors are pending the wave handles them one per lane, so field work runs
-//     at full lane occupancy whatever the field-length distribution is.  Strings of <= 24 bytes and
-//     plain integers of <= 16 digits are served from the LDS byte ring in registers (NH hash with
-//     three multiplies, one 32-byte table slot decides a lookup, 24-bit SWAR digit arithmetic);
+//   * the wave streams 2 KiB rounds as two 1 KiB chunks: one coalesced 16-byte load per lane and chunk, kept
+//     in a two-round LDS byte ring.  The tokeniser only finds the bytes that are a tab or a newline (one exact
+//     SWAR test for both) -- WHICH of the two a boundary is, and whether a backslash escapes it (Q1, Q4), is
+//     decided by the lane that later handles the field, from the byte ring (two byte reads; the exact parity of a
+//     backslash run only where one precedes a boundary).  One wave prefix sum per ROUND (both chunks' counts
+//     packed in one word) places every boundary in a per-wave LDS ring of 4-byte descriptors {position
+//     relative to the visit};
+//   * the loads are software-pipelined against the field work: chunk B of a round is requested before the
+//     pending descriptors of the round before are handled, chunk A of the next round before this round's
+//     boundaries are emitted and handled, so one chunk (4 VGPRs) is in flight at any time and neither is waited for;
+//   * column and row numbers are NOT computed per byte: a field is the gap between two consecutive
+//     descriptors, its column is its distance to the last line end before it and its row the number of line
+//     ends before it -- two ballots per 64 fields.  Whenever 64 descriptors are pending the wave handles them
+//     one per lane, so field work runs at full lane occupancy whatever the field-length distribution is.
+//     Strings of <= 24 bytes and plain integers of <= 16 digits are served from the LDS byte ring in registers
+//     (NH hash with three multiplies, one 32-byte table slot decides a lookup, 24-bit SWAR digit arithmetic);
 //     everything else goes through the general form in zdw_field_dev.h / zdw_dict_dev.h;
-//   * pass 2 never re-reads the text: each field leaves a fixed-width record (u32 table slot id
+//   * pass 2 never re-reads the text: each field leaves a fixed-width record (u32 unique id + 1
 //     or u64 parsed value) in rec[row][column].
 #include "zdw_dev.h"
 #include "zdw_kernels.h"
@@ -34,14 +37,19 @@
 
 namespace zdw {
 
-constexpr uint32_t WROUND = 1024;                 // bytes per wave round (16 per lane)
+constexpr uint32_t WROUND = 1024;                 // bytes per load step (a chunk): one 16-byte load per lane
+constexpr uint32_t ROUND = 2 * WROUND;            // bytes per tokeniser round: chunks A and B
 constexpr uint32_t DQ_CHUNK = 256;                // deferred-queue entries a wave takes per atomic
-constexpr uint32_t QCAP = 1024;                   // descriptor ring entries per wave (u32 each); a round that does not fit is emitted in four 16-lane pieces (<= 256 each)
-constexpr uint32_t BYTE_RING = 2048;              // two rounds of input bytes per wave
+constexpr uint32_t BYTE_RING = 4096;              // two rounds of input bytes per wave
 constexpr uint32_t RING_TAIL = 32;                // copy of the byte ring's first bytes behind its end: 24-byte reads never wrap
-constexpr uint32_t P1_WPB = 4;                    // independent waves per workgroup; they share the column tables
-constexpr uint32_t DESC_NL = 0x80000000u;         // descriptor = end position relative to the visit base | line end << 31
+constexpr uint32_t RING_HEAD = 16;                // copy of its last bytes in front of it: the byte before position 0 of the ring
+constexpr uint32_t RING_STRIDE = RING_HEAD + BYTE_RING + RING_TAIL;
+constexpr uint32_t P1_WPB = 8;                    // independent waves per workgroup; they share the column tables
 constexpr uint32_t LUT_ROWS = 25;                 // byte masks "first L bytes" for L = 0..24, 32 bytes per row
+// Descriptor ring entries per wave (u32 each): 512 for ordinary tables (a 2 KiB round holds ~220 boundaries), 2048 for
+// tables of mostly empty fields (a round of such data holds 1000+); a round that does not fit is emitted in eight
+// 16-lane pieces (<= 256 boundaries each), the ring drained in between.
+constexpr uint32_t QCAP_SMALL = 512, QCAP_LARGE = 2048;
 
 // ------------------------------------------------------------------------------------------
 // per-lane byte classes of 16 bytes
@@ -257,18 +265,18 @@ void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_
 // pass 1
 // ------------------------------------------------------------------------------------------
 // LDS of one workgroup (byte offsets into zdw_lds):
-//   desc   P1_WPB x 2 KiB   descriptor rings (2 KiB aligned: ring addressing is one and-or)
-//   bytes  P1_WPB x (2 KiB + 32)   byte rings, each followed by a copy of its first 32 bytes
+//   desc   P1_WPB x QCAP x 4   descriptor rings (size-aligned: ring addressing is one and-or)
+//   bytes  P1_WPB x (16 + 4 KiB + 32)   byte rings, each between a copy of its last 16 and of its first 32 bytes
 //   lut    25 x 32 B        byte masks "first L bytes are 0xff" for L = 0..24
 //   meta / mn / mx / seen   column tables shared by the waves of the workgroup (cols_in_lds)
 struct P1Lds { uint32_t desc, bytes, lut, dqs, meta, mn, mx, seen, total; };
 
-__host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool cols_in_lds)
+__host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool cols_in_lds, uint32_t qcap)
 {
     P1Lds L;
     L.desc = 0;
-    L.bytes = P1_WPB * QCAP * 4u;
-    L.lut = L.bytes + P1_WPB * (BYTE_RING + RING_TAIL);
+    L.bytes = P1_WPB * qcap * 4u;
+    L.lut = L.bytes + P1_WPB * RING_STRIDE;
     L.dqs = L.lut + LUT_ROWS * 32u;              // P1_WPB x {cur, end}: kept here, not in registers (the main loop has none to spare)
     L.meta = L.dqs + P1_WPB * 8u;
     uint32_t end = L.meta;
@@ -283,7 +291,7 @@ __host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool c
     return L;
 }
 
-size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds) { return p1_layout(ncols, nnum, use_lds).total; }
+size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds) { return p1_layout(ncols, nnum, use_lds, QCAP_SMALL).total; }
 
 __device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *reinterpret_cast<const uint32_t *>(zdw_lds + off); }
 __device__ __forceinline__ uint64_t lds_u64(uint32_t off) { return *reinterpret_cast<const uint64_t *>(zdw_lds + off); }     // 8-byte aligned offsets only
@@ -303,23 +311,35 @@ __device__ __forceinline__ void lds_bytes(uint32_t off, uint32_t (&w)[NW])
 }
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// bit 7 of each byte: set iff the byte of x is non-zero (exact, no carries between bytes)
-__device__ __forceinline__ uint32_t nz7(uint32_t x) { return ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x; }
 // bits 7, 15, 23, 31 -> bits 0..3 (one 24-bit multiply)
 __device__ __forceinline__ uint32_t pack4(uint32_t m7) { return ((__umul24((m7 & 0x00808080u) >> 7, 0x4081u) >> 14) & 7u) | ((m7 >> 28) & 8u); }      // (the mask lets the compiler prove 24 bits: v_mul_u32_u24, not the quarter-rate 32-bit multiply)
 __device__ __forceinline__ uint32_t pack16(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
     return pack4(a) | (pack4(b) << 4) | (pack4(c) << 8) | (pack4(d) << 12);
 }
+// bit 7 of each byte of w: the byte is a tab (0x09) or a newline (0x0a).  y = byte ^ 8 maps them to 1 and 2; of the
+// low seven bits m, m + 0x7f carries into bit 7 iff m >= 1 and m + 0x7d iff m >= 3 (no carry leaves a byte); bytes >= 0x80 are out.
+__device__ __forceinline__ uint32_t tab_or_nl7(uint32_t w)
+{
+    const uint32_t y = w ^ 0x08080808u, m = y & 0x7f7f7f7fu;
+    return (m + 0x7f7f7f7fu) & ~(m + 0x7d7d7d7du) & ~y & 0x80808080u;
+}
+// the 16-bit set, in position order, of the bytes of a lane's chunk that are a tab or a newline
+__device__ __forceinline__ uint32_t boundaries16(const uint4 &v) { return pack16(tab_or_nl7(v.x), tab_or_nl7(v.y), tab_or_nl7(v.z), tab_or_nl7(v.w)); }
 
 // wave-uniform state of one worker wave
 struct WaveState {
-    uint32_t desc, bytes;        // LDS offsets of this wave's rings
+    uint32_t desc, bytes;        // LDS offsets of this wave's rings (bytes: position 0 of the byte ring)
     uint32_t q_head, q_count;    // pending descriptors: ring indices q_head .. q_head + q_count - 1 (mod QCAP)
     uint32_t row_cur, col_cur;   // row / column of the field that ends at the head descriptor
     uint32_t ring_lo;            // smallest relative position the byte ring still holds
+    uint32_t rel_se1;            // relative position of the span's last byte: the visit ends with the first line end at or past it
     bool first_pending;          // the head descriptor is the visit's sentinel: the line end before the first owned row
+    bool ignoring;               // the visit began inside a row of the span before: everything up to that row's end is not ours
+    bool prev_nl;                // the boundary before the head descriptor is a line end
+    bool done;                   // the visit's last row has been handled
     uint64_t vbase;              // visit base: absolute position = vbase + relative position (multiple of BYTE_RING)
+    uint64_t row_start;          // absolute position where the row that is open at the head descriptor began (m_LongestLine candidates)
     IdAlloc ids;                 // this wave's chunk of unique ids
 };
 
@@ -327,22 +347,94 @@ struct WaveState {
 // entries were created.  DEFER: fields that need the general form are queued for k_pass1_deferred instead of
 // being handled here (the general form costs this kernel a fifth of its registers and a wave per SIMD).
 // TRIM: convertDWfile -t -- trailing blanks are cut off every field before anything else looks at it (ConvertToZDW.cpp:295-313).
-template <bool DEFER, bool TRIM>
+template <bool DEFER, bool TRIM, uint32_t QCAP>
 __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const DictTable &d, const P1Lds &L, WaveState &ws, uint32_t cnt,
                                             uint32_t lane)
 {
+    constexpr uint32_t QM = QCAP * 4u - 1u;
     const bool live = lane < cnt;
     const uint32_t di = ws.q_head + lane;
-    const uint32_t e = lds_u32(ws.desc | ((di << 2) & (QCAP * 4u - 1u)));
-    const uint32_t pe = lds_u32(ws.desc | (((di - 1u) << 2) & (QCAP * 4u - 1u)));
-    const bool e_nl = live && (e >> 31) != 0;
-    const uint32_t e_pos = e & ~DESC_NL, fs = (pe & ~DESC_NL) + 1u;      // a field begins one byte after its predecessor's end
+    const uint32_t e_pos = lds_u32(ws.desc | ((di << 2) & QM));
+    uint32_t pe_pos = lds_u32(ws.desc | (((di - 1u) << 2) & QM));
+    // ---- what kind of boundary is mine?  The tokeniser only said "a tab or a newline": the byte itself and the one
+    // ---- before it (a backslash?) come from the byte ring
+    const uint32_t ea = ws.bytes + (e_pos & (BYTE_RING - 1u));
+    const uint32_t be = zdw_lds[ea], bp = zdw_lds[ea - 1u];
+    // (predicates are combined with & and |: no short-circuit branches around loads in this path)
+    const bool at_sentinel = ws.first_pending & (lane == 0);           // (its byte may lie before anything the visit loaded)
+    bool e_nl = live & ((be == '\n') | at_sentinel);
+    bool dead = !live;                   // takes no part: beyond cnt, escaped, foreign, past the end of the visit
+    uint32_t sent_lane = ws.first_pending ? 0u : 64u;                   // the lane whose line end precedes the visit's first row
+    uint64_t vm = 0;                     // escaped separators of this batch
+    // Anything out of the ordinary in this batch?  A backslash in front of a boundary, a boundary whose bytes the ring no
+    // longer holds, a visit that has not found its first row yet, the end of the span: all rare, all in one branch.
+    const bool odd = live & !at_sentinel & ((bp == '\\') | (e_pos <= ws.ring_lo));
+    const uint64_t oddm = __ballot(odd);
+    if ((oddm != 0) | ws.ignoring | (lane_value(e_pos, (int)cnt - 1) >= ws.rel_se1)) {
+        if (oddm) {
+            // exact: the byte and the parity of the backslash run before it, from the image (Q1, Q4: special iff an even
+            // number of backslashes precedes)
+            bool esc = false;
+            if (odd) {
+                const uint64_t p = ws.vbase + e_pos;
+                const bool nl = a.in[p] == '\n';
+                esc = (backslashes_before(a.in, a.lo, p) & 1u) != 0;
+                e_nl = nl && !esc;
+                if (esc) dead = true;
+            }
+            vm = __ballot(esc);           // (the loads have landed before anything below looks at their values)
+        }
+        // a visit that began inside a row of the span before: that row's end is the line end before our first row
+        if (ws.ignoring) {
+            const uint64_t nl0 = __ballot(e_nl);
+            if (!nl0) return 0;                                         // all of it foreign
+            sent_lane = (uint32_t)lowest_bit(nl0);
+            if (lane < sent_lane) { dead = true; e_nl = false; }
+            ws.ignoring = false;
+        }
+        // the visit ends with the first line end at or past the last byte of its span
+        const uint64_t endm = __ballot(e_nl && lane != sent_lane && e_pos >= ws.rel_se1);
+        if (endm) {
+            if (lane > (uint32_t)lowest_bit(endm)) { dead = true; e_nl = false; }
+            ws.done = true;
+        }
+    }
+    const bool sentinel = lane == sent_lane;
+    const uint64_t nlm = __ballot(e_nl);                               // line ends that count
+    uint32_t fs = pe_pos + 1u;                                          // a field begins one byte after the boundary before it
+    uint32_t pnl = wave_shr1(e_nl ? 1u : 0u);                           // ... which is a line end?
+    if (lane == 0) pnl = ws.prev_nl ? 1u : 0u;
+    uint64_t realm = 0;                                                 // (vm != 0 only) boundaries that count
+    if (vm) {
+        // rare: separators of this batch are escaped -- my field begins after the last boundary that counts
+        realm = __ballot(!dead);
+        const uint64_t before = realm & mask_lt((int)lane);
+        if (!dead && before) {
+            const int p = highest_bit(before);
+            if ((uint32_t)p + 1u != lane) {
+                pe_pos = lds_u32(ws.desc | (((ws.q_head + (uint32_t)p) << 2) & QM));
+                fs = pe_pos + 1u;
+                pnl = (uint32_t)(nlm >> p) & 1u;
+            }
+        } else if (!dead && lane > 0) {                                 // none in this batch: the one before the batch
+            pe_pos = lds_u32(ws.desc | (((ws.q_head - 1u) << 2) & QM));
+            fs = pe_pos + 1u;
+            pnl = ws.prev_nl ? 1u : 0u;
+        }
+        // the next batch must find a boundary that counts in front of it
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t mine = realm & mask_lt((int)cnt);
+        if (!((mine >> (cnt - 1u)) & 1ull)) {
+            const uint32_t slot = ws.desc | (((ws.q_head + cnt - 1u) << 2) & QM);
+            if (mine) { if (lane == (uint32_t)highest_bit(mine)) *reinterpret_cast<uint32_t *>(zdw_lds + slot) = e_pos; }
+            else if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + slot) = lds_u32(ws.desc | (((ws.q_head - 1u) << 2) & QM));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     const uint32_t raw_len = e_pos - fs;
     uint32_t len = raw_len;
-    const bool sentinel = ws.first_pending && lane == 0;
-    const bool blank = e_nl && (pe >> 31) != 0 && len == 0;              // line end right after a line end: no row (getnextrow.cpp:38-43)
-    const bool ends_row = e_nl && !blank && !sentinel;
-    const uint64_t nlm = __ballot(e_nl);
+    const bool blank = e_nl & (pnl != 0) & (len == 0) & !sentinel;    // line end right after a line end: no row (getnextrow.cpp:38-43)
+    const bool ends_row = e_nl & !blank & !sentinel;
     uint32_t row = ws.row_cur, col = ws.col_cur + lane;
     uint64_t rm = 0;
     if (nlm) {
@@ -350,6 +442,25 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         row += mbcnt64(rm);
         const uint64_t prev = nlm & mask_lt((int)lane);
         if (prev) col = lane - 1u - (uint32_t)highest_bit(prev);
+        // rows of 16383 bytes or more can grow the reference's line buffer (m_LongestLine): the host replays exactly those.
+        // Only a batch whose last line end lies that far past the start of the open row can hold one.
+        const int h = highest_bit(nlm);
+        const uint64_t abs_h = ws.vbase + lane_value(e_pos, h);
+        if (abs_h + 1 - ws.row_start >= FIRST_ROW_CAP - 1) {
+            const uint32_t e_prev = (uint32_t)__shfl((int)e_pos, prev ? highest_bit(prev) : 0, 64);      // (every lane takes part in the exchange)
+            const uint64_t start = prev ? ws.vbase + e_prev + 1 : ws.row_start;
+            const uint64_t rl = ws.vbase + e_pos + 1 - start;
+            if (e_nl && !sentinel && rl >= FIRST_ROW_CAP - 1) {
+                const uint32_t li = atomicAdd(&a.st->long_count, 1u);
+                if (li < a.long_cap) { a.long_rows[li].start = start; a.long_rows[li].len = rl; }
+            }
+        }
+        ws.row_start = abs_h + 1;
+    }
+    if (vm) {
+        // columns count the boundaries that count
+        const uint64_t before = realm & mask_lt((int)lane), prev = nlm & mask_lt((int)lane);
+        col = prev ? popc64(before & ~mask_le(highest_bit(prev))) : ws.col_cur + popc64(before);
     }
     if (rm) {
         if (ends_row && row <= a.row_limit) {
@@ -358,11 +469,17 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         }
     }
     const bool in_block = row < a.row_limit;
-    const bool is_field = live && !sentinel && !blank && col < a.ncols && (in_block || (row == a.row_limit && col < a.partial_fields)) &&
+    const bool is_field = !dead & !sentinel & !blank & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) &
                           !(a.debug_skip & 1u);
     // state for the next call
     ws.row_cur += popc64(rm);
-    ws.col_cur = nlm ? cnt - 1u - (uint32_t)highest_bit(nlm) : ws.col_cur + cnt;
+    if (vm) {
+        ws.col_cur = nlm ? popc64(realm & ~mask_le(highest_bit(nlm))) : ws.col_cur + popc64(realm);
+        if (realm) ws.prev_nl = ((nlm >> highest_bit(realm)) & 1ull) != 0;
+    } else {
+        ws.col_cur = nlm ? cnt - 1u - (uint32_t)highest_bit(nlm) : ws.col_cur + cnt;
+        ws.prev_nl = ((nlm >> (cnt - 1u)) & 1ull) != 0;          // (lanes a foreign row or the end of the visit took out: nothing reads it then)
+    }
     ws.first_pending = false;
 
     uint32_t meta = 0;
@@ -435,7 +552,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 }
             }
             if (pending) slow = true;
-            if (!slow && in_block) *reinterpret_cast<uint32_t *>(recp) = id;
+            if (!slow && in_block && !(a.debug_skip & 4u)) *reinterpret_cast<uint32_t *>(recp) = id;
         }
         adopt_ids(ws.ids, ftm);
     }
@@ -444,7 +561,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     bool fn = fast && kind != K_TEXT;
     if (fn && kind == K_INT && len > 16u) { slow = true; fn = false; }
     if (fn && len == 0u) {                 // an empty numeric field is a zero record and touches no range (sparse tables: most of them)
-        if (in_block) *reinterpret_cast<uint64_t *>(recp) = 0ull;
+        if (in_block && !(a.debug_skip & 4u)) *reinterpret_cast<uint64_t *>(recp) = 0ull;
         fn = false;
     }
     if (__ballot(fn)) {
@@ -480,7 +597,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (!ok) slow = true;
             else {
                 if (v_range > 0) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
-                if (in_block) *reinterpret_cast<uint64_t *>(recp) = v_rec;
+                if (in_block && !(a.debug_skip & 4u)) *reinterpret_cast<uint64_t *>(recp) = v_rec;
             }
         }
     }
@@ -521,14 +638,17 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     }
     return popc64(__ballot(is_new));
 }
-
-template <bool DEFER, bool TRIM>
-__global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass1Args a)
+template <bool DEFER, bool TRIM, uint32_t QCAP>
+__global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass1Args a)
 {
-    const uint32_t wv = threadIdx.x >> 6;
+    constexpr uint32_t QM = QCAP * 4u - 1u;
+    // (the compiler cannot prove threadIdx.x >> 6 wave-uniform: without the readfirstlane everything derived from the wave's
+    // number -- spans, positions, the whole visit bookkeeping -- lives in vector registers and every branch on it saves and
+    // restores the exec mask)
+    const uint32_t wv = uniform32(threadIdx.x >> 6);
     const uint32_t wave_id = blockIdx.x * P1_WPB + wv, wave_count = gridDim.x * P1_WPB;
     const uint32_t lane = lane_id();
-    const P1Lds L = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0);
+    const P1Lds L = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, QCAP);
     ColTables t;
     t.meta = L.meta; t.mn = L.mn; t.mx = L.mx; t.seen = L.seen; t.cols_in_lds = a.use_lds_ranges != 0;
 
@@ -552,8 +672,9 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
 
     WaveState ws;
     ws.desc = L.desc + wv * QCAP * 4u;
-    ws.bytes = L.bytes + wv * (BYTE_RING + RING_TAIL);
-    ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.first_pending = false; ws.vbase = 0;
+    ws.bytes = L.bytes + wv * RING_STRIDE + RING_HEAD;
+    ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.rel_se1 = 0; ws.first_pending = false; ws.vbase = 0;
+    ws.ignoring = false; ws.prev_nl = false; ws.done = false; ws.row_start = 0;
     ws.ids.cur = ws.ids.end = 0;
     if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
@@ -561,209 +682,177 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 5 : 1) void k_pass1(const Pass
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
     for (uint32_t si = wave_id; si < a.nspans; si += wave_count) {
-        const uint32_t rowbase = a.span_rowbase[si];
-        if (a.span_rowbase[si + 1] == rowbase) continue;          // no row starts in this span
+        // (values loaded from memory count as divergent for the compiler even when the address is wave-uniform: a branch on
+        // one would put the rest of the loop body under an exec mask and its bookkeeping into vector registers)
+        const uint32_t rowbase = uniform32(a.span_rowbase[si]);
+        if (uniform32(a.span_rowbase[si + 1]) == rowbase) continue;          // no row starts in this span
         if (rowbase > a.row_limit) break;                         // later spans hold rows of later blocks only
-        if (*reinterpret_cast<volatile const uint32_t *>(&a.st->overflow)) break;      // an ordinary (cached) read: a stale 0 only delays the exit
+        if (uniform32(*reinterpret_cast<volatile const uint32_t *>(&a.st->overflow))) break;      // an ordinary (cached) read: a stale 0 only delays the exit
         if (new_entries >= 128) {        // publish this wave's inserts in bulk; stop everybody once the table is half full
             uint32_t seen_total = 0;
             if (lane == 0) seen_total = atomicAdd(&a.st->entries, new_entries) + new_entries;
-            seen_total = bcast32(seen_total, 0);
+            seen_total = lane_value(seen_total, 0);          // (a readlane: wave-uniform for the compiler too, unlike a shuffle)
             new_entries = 0;
-            if (seen_total >= a.max_entries) { if (lane == 0) a.st->overflow = 1; break; }
+            if (seen_total >= a.max_entries) { a.st->overflow = 1; break; }          // (every lane stores: a branch on the lane number next to a break makes the loop's exit divergent for the compiler)
         }
         const uint64_t s0 = (a.span0 + si) << a.span_shift, SPAN_BYTES = 1ull << a.span_shift;
         const uint64_t ss = s0 > a.lo ? s0 : a.lo;
         const uint64_t se = s0 + SPAN_BYTES < a.hi ? s0 + SPAN_BYTES : a.hi;
-        const uint64_t pos0 = ss & ~(uint64_t)(WROUND - 1);
+        const uint64_t pos0 = ss & ~(uint64_t)(ROUND - 1);
 
-        // the visit: all descriptors of the previous one were handled, the ring is empty
-        const bool at_row_start = (ss == a.lo) || is_row_terminator(a.in, a.lo, ss - 1);
-        ws.vbase = (pos0 - WROUND) & ~(uint64_t)(BYTE_RING - 1);           // wraps below zero for the first span: only differences matter
+        // the visit: all descriptors of the previous one were handled or dropped, the ring is empty
+        const bool at_row_start = (ss == a.lo) || uniform32(is_row_terminator(a.in, a.lo, ss - 1) ? 1u : 0u) != 0;
+        ws.vbase = (pos0 - ROUND) & ~(uint64_t)(BYTE_RING - 1);            // wraps below zero for the first span: only differences matter
         ws.q_head = 0; ws.q_count = 0;
         ws.row_cur = rowbase; ws.col_cur = 0;
-        ws.first_pending = true;
-        ws.ring_lo = (uint32_t)(pos0 - ws.vbase);
-        bool ignoring = !at_row_start;       // the row open at ss began in an earlier span and belongs to it; its line end is our sentinel
-        uint64_t st_row_start = ss;          // where the open row began (for m_LongestLine candidates)
+        ws.first_pending = at_row_start;
+        ws.ignoring = !at_row_start;         // the row open at ss began in an earlier span and belongs to it; its line end is our sentinel
+        ws.prev_nl = false; ws.done = false;
+        ws.row_start = ss;
         if (at_row_start) {
-            if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + ws.desc) = (uint32_t)(ss - 1 - ws.vbase) | DESC_NL;
+            // (every lane stores the same word: a branch on the lane number here would make q_count divergent for the compiler)
+            *reinterpret_cast<uint32_t *>(zdw_lds + ws.desc) = (uint32_t)(ss - 1 - ws.vbase);
             ws.q_count = 1;
         }
-        uint32_t bs_carry = (pos0 > a.lo && a.in[pos0 - 1] == '\\') ? 1u : 0u;
-        bool done = false;
 
         // Per-round bookkeeping is 32-bit: positions relative to the visit base, clamped to [0, 2^31) (a visit
         // moves its base long before it gets there); 64-bit positions are rebuilt only on the rare paths.
-        uint32_t rel_ss, rel_se1, rel_hi;
+        uint32_t rel_ss, rel_hi;
         auto rel31 = [&](uint64_t x) {
             const int64_t dlt = (int64_t)(x - ws.vbase);
             return dlt < 0 ? 0u : (dlt > 0x7fffffffll ? 0x7fffffffu : (uint32_t)dlt);
         };
-        auto set_rels = [&]() { rel_ss = rel31(ss); rel_se1 = rel31(se - 1); rel_hi = rel31(a.hi); };
+        auto set_rels = [&]() { rel_ss = rel31(ss); ws.rel_se1 = rel31(se - 1); rel_hi = rel31(a.hi); };
         set_rels();
 
-        const uint8_t *lane_ptr = a.in + pos0 + 16u * lane;               // this lane's 16 bytes of the current round
-        const uint8_t *last_chunk = a.in + ((a.n - 1) & ~15ull);
-        uint4 nxt = load_round16(a.in, pos0, lane, a.n);
-        for (uint32_t relb = (uint32_t)(pos0 - ws.vbase); !done && relb < rel_hi; relb += WROUND, lane_ptr += WROUND) {
-            const uint4 v = nxt;
-            // next round in flight; lanes whose chunk would start at or past the end of the image re-read the last
-            // 16-byte chunk that starts inside it (an aligned chunk whose first byte is inside an allocation never
-            // leaves its page; their bytes lie past `hi` and are masked)
-            {
-                const uint8_t *q = lane_ptr + WROUND;
-                q = q < last_chunk ? q : last_chunk;
-                nxt = *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(q, 16));
+        auto emit = [&](uint32_t bits, uint32_t pos, uint32_t first_slot) {     // this lane's boundaries `bits` (bit i = byte pos + i) from ring slot first_slot on
+            uint32_t qoff = first_slot << 2;
+            while (bits) {
+                const uint32_t i = (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1;
+                *reinterpret_cast<uint32_t *>(zdw_lds + (ws.desc | (qoff & QM))) = pos + i;
+                qoff += 4;
             }
-            uint32_t lrel = relb + 16u * lane;                            // relative position of my first byte
-            {   // keep the round in the LDS byte ring (two rounds deep): field work reads its bytes from there
-                const uint32_t slot = relb & (BYTE_RING - 1);                     // 0 or 1024 (the base is a multiple of the ring)
+        };
+
+        // lanes whose chunk would start at or past the end of the image re-read the last 16-byte chunk that starts
+        // inside it (an aligned chunk whose first byte is inside an allocation never leaves its page; their bytes lie
+        // past `hi` and are masked)
+        const uint8_t *last_chunk = a.in + ((a.n - 1) & ~15ull);
+        auto load_chunk = [&](const uint8_t *q) {
+            q = q < last_chunk ? q : last_chunk;
+            return *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(q, 16));
+        };
+        const uint8_t *lane_ptr = a.in + pos0 + 16u * lane;               // this lane's 16 bytes of chunk A of the current round
+        uint4 P = load_chunk(lane_ptr);                                   // the one chunk in flight
+        uint32_t relb = (uint32_t)(pos0 - ws.vbase);                      // relative position of the current round
+        uint32_t first_rel = relb;                                        // nothing below it was loaded by this visit
+        ws.ring_lo = first_rel;
+        // The visit as a small state machine around ONE place that handles descriptors (the field work is most of
+        // this kernel's code; it is inlined once):
+        //   step A      chunk A into the ring, chunk B requested; then the pending descriptors of the round before (all
+        //               whole batches) while B travels
+        //   step B      chunk B into the ring, chunk A of the next round requested; one prefix sum, the round's
+        //               descriptors; then all but the last one or two batches (those wait for step A of the next round)
+        //   step PIECE  a round denser than the ring: eight 16-lane pieces, the ring drained before each; a visit that
+        //               has outgrown its relative positions moves its base here too
+        //   step END    the image ended: whatever is pending
+        enum : uint32_t { STEP_A = 0, STEP_B = 1, STEP_PIECE = 2, STEP_END = 3 };
+        uint32_t step = relb < rel_hi ? STEP_A : STEP_END, piece = 0;
+        uint32_t mA = 0, mB = 0, ex2 = 0, tot2 = 0;
+        bool rebase = false, near_end = false;
+        for (;;) {
+            uint32_t keep = 0;                    // descriptors that may stay pending after this step
+            if (step == STEP_A) {
+                const uint32_t slot = relb & (BYTE_RING - 1u);                        // 0 or 2048 (the base is a multiple of the ring)
+                const uint4 v = P;
                 *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + slot + 16u * lane) = v;
                 if (slot == 0 && lane < RING_TAIL / 16u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + BYTE_RING + 16u * lane) = v;
-            }
-
-            // ---- classify: exact tab / newline sets of my 16 bytes; escapes resolved (Q1, Q4) ----
-            uint32_t bnd, nl = 0;
-            {
-                const uint32_t tn0 = nz7(v.x ^ 0x0a0a0a0au), tn1 = nz7(v.y ^ 0x0a0a0a0au), tn2 = nz7(v.z ^ 0x0a0a0a0au), tn3 = nz7(v.w ^ 0x0a0a0a0au);
-                const uint32_t H = 0x80808080u, L1 = 0x01010101u;
-                bnd = pack16(~(nz7(v.x ^ 0x09090909u) & tn0) & H, ~(nz7(v.y ^ 0x09090909u) & tn1) & H,
-                             ~(nz7(v.z ^ 0x09090909u) & tn2) & H, ~(nz7(v.w ^ 0x09090909u) & tn3) & H);
-                if (__ballot(((tn0 & tn1 & tn2 & tn3) & H) != H)) nl = pack16(~tn0 & H, ~tn1 & H, ~tn2 & H, ~tn3 & H);
-                const uint32_t b0 = v.x ^ 0x5c5c5c5cu, b1 = v.y ^ 0x5c5c5c5cu, b2 = v.z ^ 0x5c5c5c5cu, b3 = v.w ^ 0x5c5c5c5cu;
-                const uint32_t anybs = (((b0 - L1) & ~b0) | ((b1 - L1) & ~b1) | ((b2 - L1) & ~b2) | ((b3 - L1) & ~b3)) & H;      // exact for "some byte is a backslash"
-                if (__ballot(anybs != 0) | bs_carry) {
-                    // a backslash in (or right before) this round: special iff an even number of backslashes precedes
-                    const uint32_t bs = pack16(~nz7(b0) & H, ~nz7(b1) & H, ~nz7(b2) & H, ~nz7(b3) & H);
-                    uint32_t prev = wave_shr1(bs >> 15);
-                    if (lane == 0) prev = bs_carry;
-                    bs_carry = lane_value(bs >> 15, 63);
-                    const uint32_t cand = bnd & ((bs << 1) | prev) & 0xffffu;
-                    if (__ballot(cand != 0)) {          // count the run exactly (bounded by the block start)
-                        const uint64_t lp = ws.vbase + lrel;
-                        uint32_t c = cand, esc = 0;
-                        while (c) {
-                            const uint32_t i = (uint32_t)__builtin_ctz(c);
-                            c &= c - 1;
-                            // (lanes past the end of the image hold re-read bytes: never follow those into memory)
-                            if (lp + i > a.lo && lp + i < a.n && (backslashes_before(a.in, a.lo, lp + i) & 1u)) esc |= 1u << i;
-                        }
-                        bnd &= ~esc;
-                        nl &= ~esc;
-                    }
+                P = load_chunk(lane_ptr + WROUND);
+                mA = boundaries16(v);
+                ws.ring_lo = relb + WROUND > BYTE_RING + first_rel ? relb + WROUND - BYTE_RING : first_rel;      // the ring holds [relb - 3072, relb + 1024)
+                keep = 63;
+                step = STEP_B;
+            } else if (step == STEP_B) {
+                const uint32_t slot = relb & (BYTE_RING - 1u);
+                {
+                    const uint4 v = P;
+                    *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + slot + WROUND + 16u * lane) = v;
+                    if (slot != 0 && lane == 63u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes - RING_HEAD) = v;      // the ring's last 16 bytes, in front of it
+                    P = load_chunk(lane_ptr + ROUND);
+                    mB = boundaries16(v);
                 }
-            }
-
-            // positions that exist for this visit: [ss, hi), cut after the first line end at or past se - 1
-            if (relb < rel_ss || relb + WROUND > rel_se1) {
-                uint32_t vm = valid16r(lrel, rel_ss, rel_hi);
-                const uint32_t late = nl & vm & valid16r(lrel, rel_se1, 0xffffffffu);
-                const uint64_t lb = __ballot(late != 0);
-                if (lb) {
-                    const int fl = lowest_bit(lb);
-                    const uint32_t fb = lane_value((uint32_t)__builtin_ctz(late | 0x10000u), fl);
-                    done = true;
-                    if (lane > (uint32_t)fl) vm = 0;
-                    else if (lane == (uint32_t)fl) vm &= (2u << fb) - 1u;
+                ws.ring_lo = relb > ROUND + first_rel ? relb - ROUND : first_rel;             // ... now [relb - 2048, relb + 2048)
+                const uint32_t lrel = relb + 16u * lane;                                      // relative position of my first byte of chunk A
+                // positions that exist for this visit: [ss, hi)
+                if (relb < rel_ss || relb + ROUND > rel_hi) {
+                    mA &= valid16r(lrel, rel_ss, rel_hi);
+                    mB &= valid16r(lrel + WROUND, rel_ss, rel_hi);
                 }
-                nl &= vm; bnd &= vm;
-            }
-
-            // line ends of the round (wave-uniform bookkeeping): m_LongestLine candidates, the sentinel of a
-            // visit that starts inside a foreign row
-            const uint64_t tb = __ballot(nl != 0);
-            if (tb) {
-                const int ft_lane = lowest_bit(tb);
-                const uint32_t ft_bit = lane_value((uint32_t)__builtin_ctz(nl | 0x10000u), ft_lane);
-                if (!ignoring) {
-                    // only the row that was open when the round began can be long enough to grow m_LongestLine
-                    const uint64_t rl = ws.vbase + (relb + 16u * (uint32_t)ft_lane + ft_bit) - st_row_start + 1;
-                    if (rl >= FIRST_ROW_CAP - 1 && lane == 0) {
-                        const uint32_t li = atomicAdd(&a.st->long_count, 1u);
-                        if (li < a.long_cap) { a.long_rows[li].start = st_row_start; a.long_rows[li].len = rl; }
-                    }
+                // one prefix sum for both chunks; descriptors of A, then of B.  The ring always keeps the head's
+                // predecessor, so it can take QCAP - 1 - pending new descriptors.
+                static_assert(QCAP >= 256 + 2, "a drained ring must take one 16-lane piece");
+                const uint32_t cnts = (uint32_t)__builtin_popcount(mA) | ((uint32_t)__builtin_popcount(mB) << 16);
+                ex2 = wave_excl_sum(cnts, lane, tot2);
+                const uint32_t totA = tot2 & 0xffffu, nb_total = totA + (tot2 >> 16);
+                near_end = relb + ROUND > ws.rel_se1 || relb + ROUND >= rel_hi;          // the span ends in this round or has ended: find the visit's end promptly
+                if (relb < a.rebase_at && ws.q_count + nb_total <= QCAP - 1) {
+                    // the common round: everything fits
+                    const uint32_t tail = ws.q_head + ws.q_count;
+                    emit(mA, lrel, tail + (ex2 & 0xffffu));
+                    emit(mB, lrel + WROUND, tail + totA + (ex2 >> 16));
+                    ws.q_count += nb_total;
+                    keep = near_end ? 0u : 127u;
+                    relb += ROUND; lane_ptr += ROUND;
+                    step = relb < rel_hi ? STEP_A : STEP_END;
                 } else {
-                    if (lane < (uint32_t)ft_lane) bnd = 0;
-                    else if (lane == (uint32_t)ft_lane) bnd &= ~((1u << ft_bit) - 1u);
-                    ignoring = false;
+                    rebase = relb >= a.rebase_at;                                             // relative positions must stay below 2^31
+                    piece = 0;
+                    step = STEP_PIECE;                                                        // (first: everything that is pending)
                 }
-                const int lt_lane = highest_bit(tb);
-                const uint32_t lt_bit = lane_value(31u - (uint32_t)__builtin_clz(nl | 1u), lt_lane);
-                st_row_start = ws.vbase + (relb + 16u * (uint32_t)lt_lane + lt_bit) + 1;
-            } else if (ignoring) {
-                bnd = 0;
-            }
-
-            // ---- emit this lane's boundaries; handle descriptors 64 at a time ----
-            // The ring always keeps the head's predecessor, so it can take QCAP - 1 - pending new descriptors.
-            static_assert(QCAP >= 256 + 2, "a drained ring must take one 16-lane piece");
-            uint32_t nb_total;
-            const uint32_t nb_before = wave_excl_sum((uint32_t)__builtin_popcount(bnd), lane, nb_total);
-            const bool end_of_visit = done || relb + WROUND >= rel_hi;
-            auto emit = [&](uint32_t bits, uint32_t first_slot) {
-                uint32_t qoff = first_slot << 2;
-                while (bits) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(bits);
-                    bits &= bits - 1;
-                    *reinterpret_cast<uint32_t *>(zdw_lds + (ws.desc | (qoff & (QCAP * 4u - 1u)))) = (lrel + i) | (((nl >> i) & 1u) << 31);
-                    qoff += 4;
-                }
-            };
-            if (relb < a.rebase_at && ws.q_count + nb_total <= QCAP - 1 && !end_of_visit) {
-                // the common round: everything fits; take descriptors 64 at a time
-                emit(bnd, ws.q_head + ws.q_count + nb_before);
-                ws.q_count += nb_total;
-                __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
-                while (ws.q_count >= 64) {
-                    if (!(a.debug_skip & 32u)) new_entries += consume<DEFER, TRIM>(a, t, d, L, ws, 64u, lane);      // 32: profiling only, the producer alone
-                    ws.q_head += 64;
-                    ws.q_count -= 64;
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                // the last round of a visit (drain everything), a round denser than the ring (emitted as four
-                // 16-lane pieces of <= 256 boundaries each, the ring drained in between), or a visit that has
-                // outgrown its relative positions (drain, then move the base)
-                bool rebase = relb >= a.rebase_at;                           // relative positions must stay below 2^31
-                const bool whole = !rebase && ws.q_count + nb_total <= QCAP - 1;
-                const uint32_t b16 = lane_value(nb_before, 16), b32 = lane_value(nb_before, 32), b48 = lane_value(nb_before, 48);
-                const uint32_t npieces = whole ? 1u : 4u;
-                for (uint32_t piece = 0;; ++piece) {
-                    const bool emitting = piece < npieces;
-                    const bool drain = emitting ? !whole : end_of_visit;
-                    __builtin_amdgcn_wave_barrier();
-                    while (drain ? ws.q_count > 0 : ws.q_count >= 64) {
-                        const uint32_t cnt = ws.q_count < 64 ? ws.q_count : 64u;
-                        new_entries += consume<DEFER, TRIM>(a, t, d, L, ws, cnt, lane);
-                        ws.q_head += cnt;
-                        ws.q_count -= cnt;
+            } else if (step == STEP_PIECE) {
+                if (rebase) {
+                    // nothing is pending: move the visit base up; the head's predecessor moves with it
+                    const uint32_t delta = (relb - 2u * BYTE_RING) & ~(BYTE_RING - 1u);
+                    if (!ws.first_pending) {
+                        const uint32_t pa = ws.desc | (((ws.q_head - 1u) << 2) & QM);
+                        uint32_t pp = lds_u32(pa);
+                        if (pp < delta) { pp = delta; if (lane == 0) a.st->nul_seen = 2; }      // a single field of 1 GiB or more
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + pa) = pp - delta;
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    if (!emitting) break;
-                    if (rebase) {
-                        // nothing is pending: move the visit base up; the head's predecessor moves with it
-                        const uint32_t delta = (relb - 2u * BYTE_RING) & ~(BYTE_RING - 1u);
-                        if (!ws.first_pending) {
-                            const uint32_t pa = ws.desc | (((ws.q_head - 1u) << 2) & (QCAP * 4u - 1u));
-                            const uint32_t pd = lds_u32(pa);
-                            uint32_t pp = pd & ~DESC_NL;
-                            if (pp < delta) { pp = delta; if (lane == 0) a.st->nul_seen = 2; }      // a single field of 1 GiB or more
-                            __builtin_amdgcn_wave_barrier();
-                            if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + pa) = (pd & DESC_NL) | (pp - delta);
-                        }
-                        ws.vbase += delta; ws.ring_lo -= delta; relb -= delta; lrel -= delta;
-                        set_rels();
-                        rebase = false;
-                    }
-                    const bool active = whole || (lane >> 4) == piece;
-                    const uint32_t piece_base = whole ? 0u : (piece == 0 ? 0u : (piece == 1 ? b16 : (piece == 2 ? b32 : b48)));
-                    const uint32_t piece_end = whole ? nb_total : (piece == 0 ? b16 : (piece == 1 ? b32 : (piece == 2 ? b48 : nb_total)));
-                    emit(active ? bnd : 0u, ws.q_head + ws.q_count + nb_before - piece_base);
-                    ws.q_count += piece_end - piece_base;
+                    ws.vbase += delta; ws.ring_lo -= delta; relb -= delta;
+                    first_rel = 0;
+                    set_rels();
+                    rebase = false;
+                }
+                const bool inB = piece >= 4u;
+                const uint32_t first_lane = 16u * (piece & 3u);
+                const uint32_t ex = inB ? ex2 >> 16 : ex2 & 0xffffu, tot = inB ? tot2 >> 16 : tot2 & 0xffffu;
+                const uint32_t piece_base = lane_value(ex, (int)first_lane);
+                const uint32_t piece_end = first_lane == 48u ? tot : lane_value(ex, (int)first_lane + 16);
+                const bool active = (lane >> 4) == (piece & 3u);
+                const uint32_t lrel = relb + 16u * lane;
+                emit(active ? (inB ? mB : mA) : 0u, inB ? lrel + WROUND : lrel, ws.q_head + ws.q_count + ex - piece_base);
+                ws.q_count += piece_end - piece_base;
+                if (++piece == 8u) {
+                    keep = near_end ? 0u : 127u;
+                    relb += ROUND; lane_ptr += ROUND;
+                    step = relb < rel_hi ? STEP_A : STEP_END;
                 }
             }
-            ws.ring_lo = relb;              // the next round keeps this one next to it in the byte ring
+            // ---- the one place descriptors are handled: 64 at a time while more than `keep` are pending ----
+            const bool last = step == STEP_END;
+            __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
+            while (!ws.done && ws.q_count > keep) {
+                const uint32_t cnt = ws.q_count < 64u ? ws.q_count : 64u;
+                if (a.debug_skip & 32u) { if (near_end && ws.q_count <= 64u) ws.done = true; }      // profiling only: the tokeniser alone
+                else new_entries += consume<DEFER, TRIM, QCAP>(a, t, d, L, ws, cnt, lane);
+                ws.q_head += cnt;
+                ws.q_count -= cnt;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (ws.done || last) break;
         }
     }
     retire_ids(ws.ids, a.uniq_len, a.id_cap);
@@ -835,21 +924,22 @@ void launch_pass1_deferred(const Pass1Args &a, uint32_t count, hipStream_t s)
     const uint32_t want = (count + 255) / 256;
     hipLaunchKernelGGL(k_pass1_deferred, dim3(want < 2048u ? want : 2048u), dim3(256), 0, s, a, count);
 }
-
 void launch_pass1(const Pass1Args &a, hipStream_t s)
 {
     if (!a.nspans) return;
-    const size_t lds = pass1_lds_bytes(a.ncols, a.nnum, a.use_lds_ranges != 0);
     const bool defer = a.dq != nullptr;
+    const bool trim = a.trim != 0;
+    const bool large = a.dense_boundaries != 0;
+    const size_t lds = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, large ? QCAP_LARGE : QCAP_SMALL).total;
     // Waves walk the spans with a grid stride, so every wave carries the same share of the block: the grid
     // must not exceed what is resident at once, or the surplus waves run alone after the others finish.
     int per_cu = 0, dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const bool trim = a.trim != 0;
     typedef void (*P1Fn)(const Pass1Args);
-    static const P1Fn fns[2][2] = {{k_pass1<false, false>, k_pass1<false, true>}, {k_pass1<true, false>, k_pass1<true, true>}};
-    const P1Fn kfn = fns[defer][trim];
+    static const P1Fn fns[2][2][2] = {{{k_pass1<false, false, QCAP_SMALL>, k_pass1<false, false, QCAP_LARGE>}, {k_pass1<false, true, QCAP_SMALL>, k_pass1<false, true, QCAP_LARGE>}},
+                                      {{k_pass1<true, false, QCAP_SMALL>, k_pass1<true, false, QCAP_LARGE>}, {k_pass1<true, true, QCAP_SMALL>, k_pass1<true, true, QCAP_LARGE>}}};
+    const P1Fn kfn = fns[defer][trim][large];
     const void *fn = (const void *)kfn;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
     const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules

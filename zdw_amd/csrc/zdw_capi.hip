@@ -80,6 +80,7 @@ struct TimedSpan { hipEvent_t a, b; int stage; };
 struct zdw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;         // pass 2's row lengths run here while the dictionary is sorted on `stream`
     std::string err;
     // schema
     uint32_t ncols = 0, nnum = 0, rec_stride = 0;
@@ -108,10 +109,11 @@ struct zdw_ctx {
     uint64_t lo = 0;                       // start of the current block
     uint64_t next_lo = 0;                  // start of the next block (set by pass 1)
     // block state
-    bool p1_done = false, dict_done = false, stats_done = false, p2_done = false, is_last = true;
+    bool p1_done = false, dict_size_done = false, dict_done = false, stats_done = false, p2_size_done = false, p2_done = false, is_last = true;
+    uint32_t dict_max_len = 24;
     uint32_t nrows = 0;
     uint64_t nslots = 0;
-    DevBuf span_starts, span_rowbase, scan_tmp, rec, slots, deferred_q, col_min, col_max, col_seen, status, long_rows, d_scalar;
+    DevBuf span_starts, span_rowbase, scan_tmp, scan_tmp2, rec, slots, deferred_q, col_min, col_max, col_seen, status, long_rows, d_scalar;
     std::vector<uint64_t> h_min, h_max;
     std::vector<uint8_t> h_seen;
     // dictionary
@@ -119,6 +121,7 @@ struct zdw_ctx {
         slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
     uint64_t nuniq = 0, dict_size = 0, extra_bytes = 0;
     uint64_t avg_row = 0;         // bytes per row, sampled at the start of the input
+    bool dense_boundaries = false; // ... and whether fields are so short that pass 1 takes its large descriptor ring
     uint32_t nids = 0;            // unique ids handed out in this block (holes included): entries of id_off
     uint32_t id_cap = 0;                   // capacity of uniq_pos / uniq_len (unique ids, holes included)
     // range-partitioned dictionary (multi-GPU): this shard as a requester ...
@@ -174,17 +177,17 @@ int fail(zdw_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 struct StageScope {
-    zdw_ctx *c; int stage; hipEvent_t a = nullptr;
-    StageScope(zdw_ctx *ctx, int st) : c(ctx), stage(st)
+    zdw_ctx *c; int stage; hipEvent_t a = nullptr; hipStream_t st;
+    StageScope(zdw_ctx *ctx, int stg, hipStream_t on = nullptr) : c(ctx), stage(stg), st(on ? on : ctx->stream)
     {
-        if (c->timing && hipEventCreate(&a) == hipSuccess) (void)hipEventRecord(a, c->stream);
+        if (c->timing && hipEventCreate(&a) == hipSuccess) (void)hipEventRecord(a, st);
     }
     ~StageScope()
     {
         if (!a) return;
         hipEvent_t b = nullptr;
         if (hipEventCreate(&b) == hipSuccess) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st);
             c->spans.push_back({a, b, stage});
         }
     }
@@ -206,7 +209,7 @@ void collect_times(zdw_ctx *c)
 
 void reset_block(zdw_ctx *c)
 {
-    c->p1_done = c->dict_done = c->stats_done = c->p2_done = false;
+    c->p1_done = c->dict_size_done = c->dict_done = c->stats_done = c->p2_size_done = c->p2_done = false;
     c->uniques_sorted = c->own_built = false;
     c->nrows = 0; c->nuniq = 0; c->nids = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
     c->have_prev = false;
@@ -279,6 +282,7 @@ int after_input(zdw_ctx *c)
     c->row_cap_block_lo = ~0ull;
     c->hi = 0;
     c->avg_row = 0;
+    c->dense_boundaries = false;
     if (c->n) {
         HIP_TRY(c, c->d_scalar.ensure(64));
         launch_find_effective_end(c->d_in, c->n, 0, c->d_scalar.as<uint64_t>(), c->stream);
@@ -288,9 +292,11 @@ int after_input(zdw_ctx *c)
         const uint64_t take = std::min<uint64_t>(sizeof sample, c->n);
         HIP_TRY(c, hipMemcpyAsync(sample, c->d_in, take, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        uint64_t lines = 0;
-        for (uint64_t i = 0; i < take; ++i) lines += sample[i] == '\n';
+        uint64_t lines = 0, tabs = 0;
+        for (uint64_t i = 0; i < take; ++i) { lines += sample[i] == '\n'; tabs += sample[i] == '\t'; }
         c->avg_row = take / (lines ? lines : 1);
+        // field boundaries per 2 KiB round of pass 1: tables of mostly empty fields get the large descriptor ring
+        c->dense_boundaries = take && (lines + tabs) * 2048 / take > 330;
     }
     c->have_input = true;
     return ZDW_OK;
@@ -331,47 +337,64 @@ int sort_strings(zdw_ctx *c, const uint8_t *in, uint64_t in_bytes, const uint8_t
 }
 
 // ---- dictionary: table -> sorted blob + slot offsets -----------------------------------------
-int ensure_dict(zdw_ctx *c)
+int start_pass2_size(zdw_ctx *c);
+
+// how many unique ids pass 1 handed out, and Dictionary::getSize(): known without sorting anything
+int ensure_dict_size(zdw_ctx *c)
 {
-    if (c->dict_done) return ZDW_OK;
+    if (c->dict_size_done) return ZDW_OK;
     if (!c->p1_done) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_block_pass1 has not run for this block");
     hipStream_t s = c->stream;
     // pass 1 (and the shard import) left the uniques by id: uniq_pos / uniq_len, length 0 = hole
-    uint32_t count = 0, max_len = 24;
-    {
-        P1Status st{};
-        HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        count = st.id_next;
-        if (st.max_len > max_len) max_len = st.max_len;
-        if (count > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", count, c->id_cap);
-        c->nuniq = st.entries;
-        c->nids = count;
-    }
+    P1Status st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint32_t count = st.id_next;
+    c->dict_max_len = st.max_len > 24 ? st.max_len : 24;
+    if (count > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", count, c->id_cap);
+    c->nuniq = st.entries;
+    c->nids = count;
     const uint64_t u = count;
+    HIP_TRY(c, c->lenp1.ensure((u + 1) * 4));
+    HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(u + 1)));
+    HIP_TRY(c, c->slot_off.ensure((u + 1) * 4));
+    launch_dict_lengths(nullptr, c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);      // by id: the sum does not depend on the order
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->dict_size = total + 1;                       // Dictionary::getSize(): origin byte included
     {
-        int rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, max_len);
+        const uint64_t limit = c->max_dict_bytes && c->max_dict_bytes < (1ull << 32) ? c->max_dict_bytes : (1ull << 32) - 1;
+        if (c->dict_size > limit)                   // (known before the sort: a block that has to be split costs no sort)
+            return fail(c, ZDW_OUT_OF_MEMORY, "dictionary of %llu bytes exceeds the limit of %llu: split the block (smaller zdw_split_hint.max_rows)",
+                        (unsigned long long)c->dict_size, (unsigned long long)limit);
+    }
+    c->index_size = (uint8_t)bytes_for(c->dict_size);
+    c->dict_size_done = true;
+    return ZDW_OK;
+}
+
+int ensure_dict(zdw_ctx *c)
+{
+    if (c->dict_done) return ZDW_OK;
+    int rc = ensure_dict_size(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const uint64_t u = c->nids;
+    // Pass 2's row lengths need the dictionary's SIZE (the width of text columns), not its order: they are computed on
+    // the second stream while the strings are sorted on this one.  (A shard of a row-sharded block waits for its halo row.)
+    if (!c->have_prev && !getenv("ZDW_NO_OVERLAP")) { rc = start_pass2_size(c); if (rc) return rc; }
+    {
+        rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, c->dict_max_len);
         if (rc) return rc;
     }
     {
         StageScope ts(c, ZDW_STAGE_DICT_EMIT);
-        HIP_TRY(c, c->lenp1.ensure((u + 1) * 4));
-        HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
         launch_dict_lengths(c->order.as<uint32_t>(), c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
         launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
-        uint64_t total = 0;
-        HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        c->dict_size = total + 1;                       // Dictionary::getSize(): origin byte included
-        {
-            const uint64_t limit = c->max_dict_bytes && c->max_dict_bytes < (1ull << 32) ? c->max_dict_bytes : (1ull << 32) - 1;
-            if (c->dict_size > limit)
-                return fail(c, ZDW_OUT_OF_MEMORY, "dictionary of %llu bytes exceeds the limit of %llu: split the block (smaller zdw_split_hint.max_rows)",
-                            (unsigned long long)c->dict_size, (unsigned long long)limit);
-        }
-        c->index_size = (uint8_t)bytes_for(c->dict_size);
         HIP_TRY(c, c->dict_sec.ensure(16 + c->dict_size));
-        HIP_TRY(c, c->slot_off.ensure((u + 1) * 4));
         uint8_t *blob = c->dict_sec.as<uint8_t>() + 8;
         launch_dict_emit(c->d_in, c->n, c->extra.as<uint8_t>(), c->order.as<uint32_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(),
                          c->off_excl.as<uint64_t>(), u, blob, c->slot_off.as<uint32_t>(), s);
@@ -384,8 +407,8 @@ int ensure_dict(zdw_ctx *c)
             c->dict_sec_off = 8 - 1 - c->index_size;
             c->dict_sec_len = 1 + c->index_size + c->dict_size;
             HIP_TRY(c, hipMemcpyAsync(c->dict_sec.as<uint8_t>() + c->dict_sec_off, hdr, 1 + c->index_size, hipMemcpyHostToDevice, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
         }
+        HIP_TRY(c, hipStreamSynchronize(s));
     }
     c->dict_done = true;
     return ZDW_OK;
@@ -395,7 +418,7 @@ int ensure_dict(zdw_ctx *c)
 int ensure_stats(zdw_ctx *c)
 {
     if (c->stats_done) return ZDW_OK;
-    int rc = ensure_dict(c);
+    int rc = c->dict_done ? ZDW_OK : ensure_dict_size(c);
     if (rc) return rc;
     c->col_size.assign(c->ncols, 0);
     c->col_base.assign(c->ncols, 0);
@@ -487,7 +510,7 @@ int run_pass2(zdw_ctx *c)
 
 std::vector<DevBuf *> all_device_buffers(zdw_ctx *c)
 {
-    return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->scan_tmp, &c->rec,
+    return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->scan_tmp, &c->scan_tmp2, &c->rec,
                       &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
                       &c->own_upos, &c->own_ulen, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
                       &c->own_out, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
@@ -775,6 +798,8 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             a.rebase_at = 1u << 30;
             if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::max(16384u, (uint32_t)strtoul(e, nullptr, 10));   // tests
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
+            a.dense_boundaries = c->dense_boundaries ? 1u : 0u;
+            if (const char *e = getenv("ZDW_P1_LARGE_RING")) a.dense_boundaries = atoi(e) != 0;      // tests
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
             // Fields that need the general form (long strings, signed / padded numbers, contended slots) are
             // queued by the main kernel (16 bytes each) and handled by a second one.  The queue starts at about 1 %
