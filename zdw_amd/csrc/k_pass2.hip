@@ -45,6 +45,13 @@ __device__ __forceinline__ uint64_t stored_from_raw(const Pass2Args &a, uint64_t
     if (!raw) return 0ull;
     return text ? (uint64_t)a.id_off[(uint32_t)raw - 1] : raw - a.used_base[u];
 }
+// flag of the block's first row: its stored value against the row before the block (the halo row of a shard arrives as
+// stored values; without one it is zero, and a text field then differs iff it is not empty: dictionary offsets are >= 1)
+__device__ __forceinline__ bool first_row_flag(const Pass2Args &a, uint64_t raw, uint32_t u, bool text)
+{
+    if (a.prev_is_zero && text) return raw != 0;
+    return stored_from_raw(a, raw, u, text) != a.prev0[u];
+}
 __device__ __forceinline__ uint64_t stored_value(const Pass2Args &a, uint32_t row, uint32_t u)
 {
     const bool text = a.used_kind[u] == K_TEXT;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
             cur = raw_value(a, row, off, text);
             sz = a.used_size[u];
             if (row) flag = cur != raw_value(a, row - 1, off, text);
-            else flag = stored_from_raw(a, cur, u, text) != a.prev0[u];      // the halo row arrives as stored values
+            else flag = first_row_flag(a, cur, u, text);
         }
         const uint32_t mine = flag ? sz : 0u;
         // inclusive prefix over the G lanes of the group
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256) void k_pass2_size_cols(const Pass2Args a)
 #pragma unroll
             for (uint32_t r = 0; r < P2_R; ++r) {
                 bool flag = v[r + 1] != v[r];
-                if (row0 + r == 0 && f.ok) flag = stored_from_raw(a, v[1], u, f.text) != a.prev0[u];     // the halo row arrives as stored values
+                if (row0 + r == 0 && f.ok) flag = first_row_flag(a, v[1], u, f.text);
                 const uint32_t t = lane_value(wave_incl_sum(flag ? f.sz : 0u), 63);
                 if (lane == 0) tot[(r0 + r) * nbatch + b] = (uint16_t)t;
             }
@@ -259,10 +266,7 @@ __device__ __forceinline__ void emit_batch(const Pass2Args &a, uint8_t *img, uin
     uint32_t flags = 0;
 #pragma unroll
     for (uint32_t r = 0; r < P2_R; ++r) flags |= (v[r + 1] != v[r] ? 1u : 0u) << r;
-    if (row0 == 0 && f.ok) {     // the halo row arrives as stored values
-        const uint64_t s0 = stored_from_raw(a, v[1], u, f.text);
-        flags = (flags & ~1u) | (s0 != a.prev0[u] ? 1u : 0u);
-    }
+    if (row0 == 0 && f.ok) flags = (flags & ~1u) | (first_row_flag(a, v[1], u, f.text) ? 1u : 0u);
     if (!f.ok) flags = 0;
     const uint64_t basev = f.ok && !f.text ? a.used_base[u] : 0ull;
 #pragma unroll
@@ -458,6 +462,9 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
             const void *fn = staged ? (const void *)k_pass2_size_cols<true> : (const void *)k_pass2_size_cols<false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
             uint32_t per_cu = std::min(6u, (uint32_t)occ);      // six workgroups per CU measured best (8: 1.36x the time)
+            // ... alone on the chip.  Beside the dictionary sort (second stream, ensure_dict) three leave the sort's launch-bound
+            // kernels room: 10 GB, sort + sizes 3.6 + 1.6 ms with six (no better than one after the other), 3.2 + 3.9 with three
+            if (a.background) per_cu = std::min(per_cu, 3u);
             if (const char *e = getenv("ZDW_P2_SIZE_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
             if (staged) hipLaunchKernelGGL(k_pass2_size_cols<true>, dim3(grid), dim3(256), lds, s, a);

@@ -414,6 +414,13 @@ int ensure_dict(zdw_ctx *c)
     return ZDW_OK;
 }
 
+// the block's ranges, dictionary or halo row have changed: row lengths computed ahead (start_pass2_size) are void
+void invalidate_pass2(zdw_ctx *c)
+{
+    if (c->p2_size_done) { (void)hipStreamSynchronize(c->stream2); c->p2_size_done = false; }
+    c->p2_done = false;
+}
+
 // ---- column widths and bases (writeLookupColumnStats, ConvertToZDW.cpp:417-483) ----------------
 int ensure_stats(zdw_ctx *c)
 {
@@ -440,11 +447,11 @@ int ensure_stats(zdw_ctx *c)
 }
 
 // uploads the per-used-column tables pass 2 reads and fills the kernel arguments
-int prepare_pass2(zdw_ctx *c, Pass2Args &a)
+int prepare_pass2(zdw_ctx *c, Pass2Args &a, hipStream_t s = nullptr)
 {
     int rc = ensure_stats(c);
     if (rc) return rc;
-    hipStream_t s = c->stream;
+    if (!s) s = c->stream;
     const uint32_t nu = (uint32_t)c->used.size();
     memset(&a, 0, sizeof a);
     a.nrows = c->nrows; a.nused = nu; a.rec_stride = c->rec_stride;
@@ -469,29 +476,60 @@ int prepare_pass2(zdw_ctx *c, Pass2Args &a)
     a.used_recoff = c->d_used_recoff.as<uint32_t>(); a.used_kind = c->d_used_kind.as<uint8_t>();
     a.used_size = c->d_used_size.as<uint8_t>(); a.used_base = c->d_used_base.as<uint64_t>();
     a.id_off = c->slot_off.as<uint32_t>(); a.nids = c->nids; a.prev0 = c->d_prev0.as<uint64_t>();
+    a.prev_is_zero = c->have_prev ? 0u : 1u;
     a.last_stored = c->d_last.as<uint64_t>();
+    return ZDW_OK;
+}
+
+int pass2_size_buffers(zdw_ctx *c, Pass2Args &a)
+{
+    HIP_TRY(c, c->row_len.ensure((c->nrows + 1ull) * 4));
+    HIP_TRY(c, c->row_off.ensure((c->nrows + 2ull) * 8));
+    HIP_TRY(c, c->scan_tmp2.ensure(scan_tmp_bytes(c->nrows + 1ull)));
+    HIP_TRY(c, c->batch_pre.ensure(((uint64_t)c->nrows + 1) * ((a.nused + 63) / 64) * 2));
+    a.row_len = c->row_len.as<uint32_t>(); a.row_off = c->row_off.as<uint64_t>(); a.out = nullptr;
+    a.batch_pre = c->batch_pre.as<uint16_t>();
+    return ZDW_OK;
+}
+
+// row lengths + their scan on the second stream (no dictionary offset is needed for them: ensure_dict)
+int start_pass2_size(zdw_ctx *c)
+{
+    if (c->p2_size_done || c->p2_done) return ZDW_OK;
+    Pass2Args a;
+    int rc = prepare_pass2(c, a, c->stream2);
+    if (rc) return rc;
+    if (a.nused == 0 || c->nrows == 0) return ZDW_OK;
+    rc = pass2_size_buffers(c, a);
+    if (rc) return rc;
+    {
+        StageScope ts(c, ZDW_STAGE_PASS2_SIZE, c->stream2);
+        a.background = 1;
+        launch_pass2_size(a, c->stream2);
+        launch_scan_u32_to_u64(a.row_len, c->row_off.as<uint64_t>(), c->nrows, c->scan_tmp2.p, nullptr, c->stream2);
+    }
+    c->p2_size_done = true;
     return ZDW_OK;
 }
 
 int run_pass2(zdw_ctx *c)
 {
     if (c->p2_done) return ZDW_OK;
+    int rc = ensure_dict(c);                    // the rows store dictionary offsets
+    if (rc) return rc;
+    if (c->p2_size_done) HIP_TRY(c, hipStreamSynchronize(c->stream2));      // row lengths started while the dictionary was being sorted
     Pass2Args a;
-    int rc = prepare_pass2(c, a);
+    rc = prepare_pass2(c, a);
     if (rc) return rc;
     hipStream_t s = c->stream;
     c->rows_len = 0;
     if (a.nused == 0 || c->nrows == 0) { c->p2_done = true; HIP_TRY(c, c->rows_out.ensure(16)); return ZDW_OK; }
-    HIP_TRY(c, c->row_len.ensure((c->nrows + 1ull) * 4));
-    HIP_TRY(c, c->row_off.ensure((c->nrows + 2ull) * 8));
-    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(c->nrows + 1ull)));
-    HIP_TRY(c, c->batch_pre.ensure(((uint64_t)c->nrows + 1) * ((a.nused + 63) / 64) * 2));
-    a.row_len = c->row_len.as<uint32_t>(); a.row_off = c->row_off.as<uint64_t>(); a.out = nullptr;
-    a.batch_pre = c->batch_pre.as<uint16_t>();
-    {
+    rc = pass2_size_buffers(c, a);
+    if (rc) return rc;
+    if (!c->p2_size_done) {
         StageScope ts(c, ZDW_STAGE_PASS2_SIZE);
         launch_pass2_size(a, s);
-        launch_scan_u32_to_u64(a.row_len, c->row_off.as<uint64_t>(), c->nrows, c->scan_tmp.p, nullptr, s);
+        launch_scan_u32_to_u64(a.row_len, c->row_off.as<uint64_t>(), c->nrows, c->scan_tmp2.p, nullptr, s);
     }
     uint64_t total = 0;
     HIP_TRY(c, hipMemcpyAsync(&total, c->row_off.as<uint64_t>() + c->nrows, 8, hipMemcpyDeviceToHost, s));
@@ -546,9 +584,24 @@ int zdw_ctx_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opt
         return rc;
     }
     c->device = dev;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest);
+    }
     if (e != hipSuccess) {
         int rc = fail(nullptr, ZDW_UNKNOWN_ERROR, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    {   // the second stream yields to the first: what runs on it fills the gaps of the launch-bound dictionary sort
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least);
+    }
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, ZDW_UNKNOWN_ERROR, "hipStreamCreate: %s", hipGetErrorString(e));
+        (void)hipStreamDestroy(c->stream);
         delete c;
         return rc;
     }
@@ -585,11 +638,13 @@ void zdw_ctx_destroy(zdw_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     collect_times(c);
     for (DevBuf *b : all_device_buffers(c)) b->release();
     c->h_dict.release(); c->h_rows.release();
     for (int i = 0; i < 2; ++i) { c->h_piece[i].release(); if (c->piece_ev[i]) (void)hipEventDestroy(c->piece_ev[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
 }
 
@@ -1040,7 +1095,8 @@ int zdw_shard_import_ranges(zdw_ctx *c, const uint64_t *col_min, const uint64_t 
         if (col_max) c->h_max[k] = col_max[k];
         if (col_seen) c->h_seen[k] = col_seen[k];
     }
-    c->stats_done = false; c->p2_done = false;
+    c->stats_done = false;
+    invalidate_pass2(c);
     return ZDW_OK;
 }
 
@@ -1108,7 +1164,8 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
         return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table (%llu slots) too small for the merged dictionary: raise zdw_opts.dict_slots",
                     (unsigned long long)c->nslots);
     c->extra_bytes = nbytes;
-    c->dict_done = c->stats_done = c->p2_done = false;
+    c->dict_size_done = c->dict_done = c->stats_done = false;
+    invalidate_pass2(c);
     return ZDW_OK;
 }
 
@@ -1131,7 +1188,7 @@ int zdw_shard_set_prev_row(zdw_ctx *c, const uint64_t *stored)
     if (!c) return ZDW_UNKNOWN_ERROR;
     c->have_prev = stored != nullptr;
     if (stored) c->prev_row.assign(stored, stored + c->ncols);
-    c->p2_done = false;
+    invalidate_pass2(c);
     return ZDW_OK;
 }
 
@@ -1139,8 +1196,10 @@ int zdw_shard_last_row(zdw_ctx *c, uint64_t *stored)
 {
     if (!c || !stored) return ZDW_UNKNOWN_ERROR;
     (void)hipSetDevice(c->device);
+    int rc = ensure_dict(c);                    // stored values of text columns are dictionary offsets
+    if (rc) return rc;
     Pass2Args a;
-    int rc = prepare_pass2(c, a);
+    rc = prepare_pass2(c, a);
     if (rc) return rc;
     // unused columns carry 0; a shard without rows passes its predecessor's row through
     for (uint32_t k = 0; k < c->ncols; ++k) stored[k] = (c->nrows == 0 && c->have_prev) ? c->prev_row[k] : 0;
@@ -1412,8 +1471,9 @@ int zdw_shard_set_offsets(zdw_ctx *c, const void *d_offsets, uint64_t count, uin
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     c->nuniq = dict_size > 1 ? std::max<uint64_t>(real, 1) : 0;
-    c->dict_done = true;
-    c->stats_done = false; c->p2_done = false;
+    c->dict_size_done = c->dict_done = true;
+    c->stats_done = false;
+    invalidate_pass2(c);
     return ZDW_OK;
 }
 

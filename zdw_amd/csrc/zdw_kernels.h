@@ -73,11 +73,14 @@ struct Pass2Args {
     const uint32_t *id_off;        // dictionary offset per unique id
     uint32_t nids;                 // entries of id_off
     const uint64_t *prev0;         // stored values of the row before row 0 (per used column)
+    uint32_t prev_is_zero;         // 1: no row precedes row 0 (prev0 is all zero): its text flags are "the field is not empty", decided
+                                   // without the dictionary (offsets are >= 1), so the row lengths can be computed while it is sorted
     uint32_t *row_len;             // out (size kernel)
     uint16_t *batch_pre;           // column kernels, size kernel -> emit kernel: per (row, 64-column batch) the value bytes of the batches before it
     const uint64_t *row_off;       // in (emit kernel): exclusive scan of row_len
     uint8_t *out;
     uint64_t *last_stored;         // k_last_row only: stored values of the last row (per used column)
+    uint32_t background;           // size kernel: it runs beside the dictionary sort (second stream): a smaller grid
 };
 
 // ---- launchers (all asynchronous on `s`) ----
