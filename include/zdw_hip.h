@@ -66,7 +66,12 @@ typedef struct zdw_opts {
     uint64_t max_device_bytes;     /* device memory this context may hold; 0 = no limit of its own.  A block whose buffers do not
                                       fit (this limit or the device itself) ends earlier, as the reference ends a block when its
                                       memory limit trips (--mem-limit, stringheap.cpp:74-86) */
-    uint64_t reserved[2];
+    uint64_t mem_limit_mb;         /* convertDWfile --mem-limit=<MB> (convertDWfile.cpp:161-163, default 3072 there; 0 here = off): the
+                                      reference ends a block when its StringHeap takes a new 64 MiB arena while the process is at or
+                                      beyond this virtual size (stringheap.cpp:74-86, memory.cpp:76-81).  Reproduced as a
+                                      deterministic model of that size (fitted to the reference build on this image):
+                                      2.6 + 64 x arenas + 64 B x dictionary entries.  A zdw_split_hint overrides it. */
+    uint64_t reserved[1];
 } zdw_opts;
 
 /* Where a block must end when it cannot hold the whole remaining input (reference: memory-driven,
@@ -124,6 +129,11 @@ int zdw_set_input_device(zdw_ctx *ctx, const void *d_tsv, uint64_t len);
 /* parseInput(): consumes rows from the current position up to the end of input or the split hint
  * (NULL = no limit).  Returns 0, 15 (res->bad_row set), 7 (a block of zero rows was forced) or 20. */
 int zdw_block_pass1(zdw_ctx *ctx, const zdw_split_hint *hint, zdw_pass1_result *res);
+/* pass-1 kernel launches of this context so far (a block that the memory-limit model ends takes two, see zdw_opts.mem_limit_mb) */
+uint64_t zdw_ctx_pass1_launches(const zdw_ctx *ctx);
+/* leading fields of the row after the current block that its pass 1 visited (zdw_split_hint.partial_fields as taken: what the caller
+ * passed, or what the memory-limit model found; 0 for a block that ends the input or that device memory ended) */
+uint32_t zdw_block_partial_fields(const zdw_ctx *ctx);
 
 /* Dictionary::write(): the dictionary section exactly as it appears in the file
  * (dictionary.cpp:76-111): 00 for an empty dictionary, else index_size, size (index_size bytes LE),
@@ -196,6 +206,32 @@ int zdw_shard_partition(zdw_ctx *ctx, uint32_t nparts, const uint64_t *splitters
 int zdw_owner_build(zdw_ctx *ctx, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes, uint64_t *slice_bytes);
 int zdw_owner_offsets(zdw_ctx *ctx, uint64_t base /* dictionary offset of the range's first string */, const void **d_offsets);
 int zdw_shard_set_offsets(zdw_ctx *ctx, const void *d_offsets, uint64_t count, uint64_t dict_size, int first_range);
+
+/* ---- the same exchange inside the library: one process, several GPUs of one node -----------------
+ * One ZDW block row-sharded over `ndev` devices: a zdw_ctx and a host thread per device, column ranges by
+ * ncclAllReduce, the range-partitioned dictionary by grouped ncclSend / ncclRecv over the xGMI links (RCCL,
+ * ncclCommInitAll: no second process, nothing re-executed), the row halo by the host.  The bytes are the ones a single
+ * context writes for the whole input, whatever ndev is.  A device may be listed more than once (tests on a one-GPU
+ * box): the exchange then runs as device-to-device copies.  convertDWfile --gpus=N (not in the reference tool) uses it.
+ * The whole input is ONE block: a dictionary beyond 2^32 bytes, or a shard that does not fit its device, returns 7. */
+typedef struct zdw_multi zdw_multi;
+typedef struct zdw_multi_block {
+    uint32_t num_rows;        /* block header fields 1-3 (ConvertToZDW.cpp:839-842) */
+    uint32_t longest_line;
+    uint32_t is_last_block;
+    uint32_t bad_row;         /* 1-based row within the block when zdw_multi_encode returns 15, else 0 */
+    uint64_t dict_bytes;      /* Dictionary::getSize() of the whole block */
+} zdw_multi_block;
+int zdw_multi_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opts, const int32_t *devices, uint32_t ndev, zdw_multi **out);
+void zdw_multi_destroy(zdw_multi *m);
+const char *zdw_multi_last_error(const zdw_multi *m);   /* m may be NULL: last zdw_multi_create error */
+/* cuts the image into ndev pieces at row boundaries and copies piece i to device i; tsv must stay valid until zdw_multi_encode returns */
+int zdw_multi_set_input_host(zdw_multi *m, const uint8_t *tsv, uint64_t len);
+int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk);
+int zdw_multi_stats(zdw_multi *m, uint8_t *col_size, uint64_t *col_base, uint32_t *used);
+/* dictionary section / rows of the block, shard after shard, through the writer (see zdw_block_dict_write) */
+int zdw_multi_dict_write(zdw_multi *m, zdw_write_fn write, void *user, uint64_t *section_len);
+int zdw_multi_rows_write(zdw_multi *m, zdw_write_fn write, void *user, uint64_t *rows_len);
 
 #ifdef __cplusplus
 }

@@ -44,12 +44,17 @@ def lib():
             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Info)]
         _lib.zdwo_free.argtypes = [C.c_void_p]
+        _lib.zdwo_set_mem_limit.argtypes = [C.c_double]
+        _lib.zdwo_set_mem_limit.restype = None
     return _lib
 
 
-def encode(desc: bytes, tsv, metadata=None, trim=False, split_rows=(), split_cols=None):
-    """Returns (rc, zdw_bytes_or_None, Info).  `tsv` is bytes or a C-contiguous uint8 numpy array."""
+def encode(desc: bytes, tsv, metadata=None, trim=False, split_rows=(), split_cols=None, mem_limit_mb=0.0):
+    """Returns (rc, zdw_bytes_or_None, Info).  `tsv` is bytes or a C-contiguous uint8 numpy array.
+    mem_limit_mb: the reference's --mem-limit as the deterministic model of zdw_oracle.c (0 = blocks end only
+    where split_rows says)."""
     L = lib()
+    L.zdwo_set_mem_limit(float(mem_limit_mb))
     meta = list((metadata or {}).items())
     arr = (C.c_char_p * (2 * len(meta) or 1))()
     for i, (k, v) in enumerate(meta):

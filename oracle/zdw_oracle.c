@@ -333,9 +333,10 @@ static int64_t dict_find(const dict *d, const uint8_t *p, size_t len)
     return -1;
 }
 
-static void dict_insert(dict *d, const uint8_t *p, size_t len)
+/* returns 1 when the string is new to the dictionary */
+static int dict_insert(dict *d, const uint8_t *p, size_t len)
 {
-    if (dict_find(d, p, len) >= 0) return;
+    if (dict_find(d, p, len) >= 0) return 0;
     if ((d->n + 1) * 2 > d->nslot) dict_rehash(d, d->nslot ? d->nslot * 2 : 1024);
     if (d->n == d->cap) { d->cap = d->cap ? d->cap * 2 : 1024; d->ent = (dent *)realloc(d->ent, d->cap * sizeof(dent)); }
     d->ent[d->n].p = p; d->ent[d->n].len = (uint32_t)len; d->ent[d->n].off = 0;
@@ -343,6 +344,7 @@ static void dict_insert(dict *d, const uint8_t *p, size_t len)
     while (d->slot[i] >= 0) i = (i + 1) & (d->nslot - 1);
     d->slot[i] = (int64_t)d->n++;
     d->bytes += len + 1;
+    return 1;
 }
 
 static int dent_cmp(const void *a, const void *b)
@@ -402,6 +404,25 @@ static int meta_cmp(const void *a, const void *b)
     const char *const *x = (const char *const *)a, *const *y = (const char *const *)b;
     return strcmp(x[0], y[0]);   /* std::map<std::string,...> order == unsigned byte order for NUL-free keys */
 }
+
+/*
+ * The reference's block limit (Q9), as a deterministic model.  A block ends when StringHeap allocates an arena
+ * (64 MiB, or the string's size when that is more; the rest of the arena before it is wasted: stringheap.cpp:31-64)
+ * while the process is at or beyond --mem-limit MB of virtual size (stringheap.cpp:74-86, memory.cpp:76-81,
+ * default 3072: convertDWfile.cpp:161-163).  The virtual size is not reproducible across machines; what is
+ * measured with the static reference build of oracle/Makefile on this image (bisecting --mem-limit on tables of
+ * unique strings) fits
+ *        vsize_MB = 2.6 + 64 * (arenas of this block) + 64 bytes * (strings in this block's std::map) / 2^20
+ * to the megabyte: a red-black node of the map is a 64-byte malloc chunk, the arenas and the nodes go back to the
+ * system when a block ends.  The string whose arena trips the limit is still inserted (dictionary.cpp:31-51); the
+ * fields after it in its row are not visited and the row moves to the next block (ConvertToZDW.cpp:338,404).
+ * 0 = no limit of this kind (blocks end only where split_rows says).
+ */
+static double g_mem_limit_mb = 0.0;
+void zdwo_set_mem_limit(double mb) { g_mem_limit_mb = mb; }
+#define ZDWO_ARENA_BYTES (64ull << 20)
+#define ZDWO_VSIZE_BASE_MB 2.6
+#define ZDWO_NODE_BYTES 64.0
 
 /*
  * Encode a whole file image.
@@ -474,6 +495,7 @@ int zdwo_encode(const zdwo_schema *sc,
         const size_t block_start = rr.pos;
         size_t s, e;
         int tripped = 0;
+        uint64_t arena_free = 0, arenas = 0;       /* the memory-limit model: see g_mem_limit_mb */
         while (!tripped) {
             size_t save = rr.pos;
             if (!next_row(&rr, &s, &e)) break;
@@ -492,7 +514,24 @@ int zdwo_encode(const zdwo_schema *sc,
                 const uint8_t *p = tsv + fv.f[c].s; size_t len = fv.f[c].e - fv.f[c].s;
                 if (!len) continue;                 /* empty fields are skipped entirely (:340-341) */
                 uint8_t ty = sc->types[c];
-                if (type_is_text(ty)) { seen[c] = 1; dict_insert(&d, p, len); continue; }
+                if (type_is_text(ty)) {
+                    seen[c] = 1;
+                    if (dict_insert(&d, p, len) && g_mem_limit_mb > 0.0) {
+                        const uint64_t need = (uint64_t)len + 1;
+                        if (need > arena_free) {               /* a new arena; what was left of the old one is wasted */
+                            ++arenas;
+                            arena_free = need > ZDWO_ARENA_BYTES ? need : ZDWO_ARENA_BYTES;
+                            const double vsize = ZDWO_VSIZE_BASE_MB + 64.0 * (double)arenas + ZDWO_NODE_BYTES * (double)d.n / 1048576.0;
+                            if (vsize >= g_mem_limit_mb && !tripped) {
+                                tripped = 1;                   /* this row moves to the next block; fields after c stay unvisited */
+                                rr.pos = save;
+                                limit = c + 1;
+                            }
+                        }
+                        arena_free -= need;
+                    }
+                    continue;
+                }
                 uint64_t v;
                 if (ty == T_CHAR) v = char_val(p, len, 0, 0);
                 else if (type_is_int(ty)) v = parse_u64(p, len);

@@ -131,3 +131,20 @@ def test_reference_multiblock_files(case):
     # without the partial-row pollution the bytes differ: the fixture really pins it
     rc2, out2, _ = oracle.encode(case["desc"], tsv, split_rows=case["split_rows"], split_cols=[0] * len(case["split_rows"]))
     assert rc2 == 0 and hashlib.sha256(out2).hexdigest() != case["zdw_sha256"]
+
+
+@pytest.mark.parametrize("case", __import__("tests.parity_util", fromlist=["x"]).multiblock_cases(), ids=lambda c: c["name"])
+def test_memory_limit_model_finds_the_reference_split(case):
+    """--mem-limit as a deterministic model (zdw_oracle.c: 2.6 + 64 x arenas + 64 B x dictionary entries, checked when the
+    string heap takes a new 64 MiB arena): told only the limit, the oracle ends its blocks where the real reference did and
+    writes the same bytes; one MB above the largest limit that trips, it writes one block like the reference."""
+    from tests import parity_util as pu
+    tsv = pu.multiblock_tsv(case)
+    rc, out, info = oracle.encode(case["desc"], tsv, mem_limit_mb=case["mem_limit"])
+    assert rc == 0 and info.nblocks == len(case["blocks"])
+    assert hashlib.sha256(out).hexdigest() == case["zdw_sha256"]
+    if case["name"] == "p19_two_text_columns":      # bisected with the reference build: two blocks up to 223, one from 224 on; none at all up to 66
+        assert oracle.encode(case["desc"], tsv, mem_limit_mb=223)[2].nblocks == 2
+        assert oracle.encode(case["desc"], tsv, mem_limit_mb=224)[2].nblocks == 1
+        assert oracle.encode(case["desc"], tsv[:44000], mem_limit_mb=66)[0] == 7
+        assert oracle.encode(case["desc"], tsv[:44000], mem_limit_mb=67)[0] == 0

@@ -12,7 +12,7 @@ STAGE_NAMES = ["scan_rows", "pass1", "dict_compact", "dict_sort", "dict_emit", "
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("trim_trailing_spaces", C.c_uint32),
-                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("max_dict_bytes", C.c_uint64), ("max_device_bytes", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("max_dict_bytes", C.c_uint64), ("max_device_bytes", C.c_uint64), ("mem_limit_mb", C.c_uint64), ("reserved", C.c_uint64 * 1)]
 
 
 class SplitHint(C.Structure):
@@ -26,6 +26,13 @@ class Pass1Result(C.Structure):
 
 class StageTimes(C.Structure):
     _fields_ = [("ms", C.c_float * NUM_STAGES), ("launches", C.c_uint32 * NUM_STAGES)]
+
+
+class MultiBlock(C.Structure):
+    _fields_ = [("num_rows", C.c_uint32), ("longest_line", C.c_uint32), ("is_last_block", C.c_uint32), ("bad_row", C.c_uint32), ("dict_bytes", C.c_uint64)]
+
+
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64)
 
 
 class ZdwError(RuntimeError):
@@ -57,6 +64,10 @@ def lib():
         L.zdw_set_input_host.argtypes = [vp, vp, C.c_uint64]
         L.zdw_set_input_device.argtypes = [vp, vp, C.c_uint64]
         L.zdw_block_pass1.argtypes = [vp, C.POINTER(SplitHint), C.POINTER(Pass1Result)]
+        L.zdw_ctx_pass1_launches.argtypes = [vp]
+        L.zdw_ctx_pass1_launches.restype = C.c_uint64
+        L.zdw_block_partial_fields.argtypes = [vp]
+        L.zdw_block_partial_fields.restype = C.c_uint32
         L.zdw_block_dict.argtypes = [vp, C.POINTER(vp), u64p, u8p]
         L.zdw_block_dict_device.argtypes = [vp, C.POINTER(vp), u64p, u8p]
         L.zdw_block_stats.argtypes = [vp, u8p, u64p, u32p]
@@ -76,8 +87,74 @@ def lib():
         L.zdw_shard_last_row.argtypes = [vp, u64p]
         L.zdw_shard_set_prev_row.argtypes = [vp, u64p]
         L.zdw_shard_line_caps.argtypes = [vp, u32p]
+        L.zdw_multi_create.argtypes = [u8p, C.c_uint32, C.POINTER(Opts), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(vp)]
+        L.zdw_multi_destroy.argtypes = [vp]
+        L.zdw_multi_destroy.restype = None
+        L.zdw_multi_last_error.argtypes = [vp]
+        L.zdw_multi_last_error.restype = C.c_char_p
+        L.zdw_multi_set_input_host.argtypes = [vp, vp, C.c_uint64]
+        L.zdw_multi_encode.argtypes = [vp, C.POINTER(MultiBlock)]
+        L.zdw_multi_stats.argtypes = [vp, u8p, u64p, u32p]
+        L.zdw_multi_dict_write.argtypes = [vp, WRITE_FN, vp, u64p]
+        L.zdw_multi_rows_write.argtypes = [vp, WRITE_FN, vp, u64p]
         _lib = L
     return _lib
+
+
+class MultiEncoder:
+    """zdw_multi_*: one block row-sharded over several devices inside the library (RCCL between distinct devices)."""
+
+    def __init__(self, col_types, devices, trim=False):
+        self.L = lib()
+        self.ncols = len(col_types)
+        types = (C.c_uint8 * max(1, self.ncols))(*col_types)
+        o = Opts()
+        o.struct_size = C.sizeof(Opts)
+        o.trim_trailing_spaces = 1 if trim else 0
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.L.zdw_multi_create(types, self.ncols, C.byref(o), devs, len(devices), C.byref(h))
+        if rc:
+            raise ZdwError(rc, self.L.zdw_multi_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zdw_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def encode(self, data):
+        """data: bytes.  Returns (rc, block bytes as the file holds them -- block header, dictionary, stats, rows -- or None, MultiBlock)."""
+        import struct
+        buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else None
+        rc = self.L.zdw_multi_set_input_host(self.h, C.cast(buf, C.c_void_p) if buf is not None else None, len(data))
+        if rc:
+            raise ZdwError(rc, self.L.zdw_multi_last_error(self.h).decode())
+        blk = MultiBlock()
+        rc = self.L.zdw_multi_encode(self.h, C.byref(blk))
+        if rc or blk.num_rows == 0:
+            return rc, None, blk
+        out = bytearray(struct.pack("<IIB", blk.num_rows, blk.longest_line, 1))
+
+        def sink(_user, p, n):
+            out.extend(C.string_at(p, n))
+            return 0
+        cb = WRITE_FN(sink)
+        rc = self.L.zdw_multi_dict_write(self.h, cb, None, None)
+        cs = (C.c_uint8 * max(1, self.ncols))()
+        cbs = (C.c_uint64 * max(1, self.ncols))()
+        used = C.c_uint32()
+        if rc == 0:
+            rc = self.L.zdw_multi_stats(self.h, cs, cbs, C.byref(used))
+        if rc == 0:
+            out.extend(bytes(cs)[:self.ncols])
+            out.extend(struct.pack("<%dQ" % used.value, *list(cbs)[:used.value]))
+            rc = self.L.zdw_multi_rows_write(self.h, cb, None, None)
+        if rc:
+            raise ZdwError(rc, self.L.zdw_multi_last_error(self.h).decode())
+        return 0, bytes(out), blk
 
 
 class Block:
@@ -96,7 +173,7 @@ class Block:
 class Encoder:
     """One zdw_ctx: the per-block seam of ConvertToZDW::processFile (cplusplus/ConvertToZDW.cpp:805-872)."""
 
-    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0, max_dict_bytes=0, max_device_bytes=0):
+    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0, max_dict_bytes=0, max_device_bytes=0, mem_limit_mb=0):
         self.L = lib()
         self.ncols = len(col_types)
         types = (C.c_uint8 * max(1, self.ncols))(*col_types)
@@ -108,6 +185,7 @@ class Encoder:
         o.dict_slots = dict_slots
         o.max_dict_bytes = max_dict_bytes
         o.max_device_bytes = max_device_bytes
+        o.mem_limit_mb = mem_limit_mb
         h = C.c_void_p()
         rc = self.L.zdw_ctx_create(types, self.ncols, C.byref(o), C.byref(h))
         if rc:
@@ -155,6 +233,12 @@ class Encoder:
             hint = C.byref(SplitHint(max_rows, partial_fields))
         rc = self.L.zdw_block_pass1(self.h, hint, C.byref(res))
         return rc, res
+
+    def pass1_launches(self):
+        return int(self.L.zdw_ctx_pass1_launches(self.h))
+
+    def partial_fields(self):
+        return int(self.L.zdw_block_partial_fields(self.h))
 
     def dict_section(self):
         p, n, w = C.c_void_p(), C.c_uint64(), C.c_uint8()

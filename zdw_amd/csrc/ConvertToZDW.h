@@ -61,6 +61,12 @@ public:
     // (SURVEY.md Q9): block i holds rows[i] rows and had visited fields[i] fields of the next row.
     void setBlockSplits(const std::vector<uint32_t> &rows, const std::vector<uint32_t> &fields);
     void setDevice(int hipDevice) { device = hipDevice; }
+    // convertDWfile --gpus=N / --devices=a,b,...: the file's one block is row-sharded over these devices (zdw_multi_*,
+    // include/zdw_hip.h); the bytes do not depend on how many there are
+    void setDevices(const std::vector<int> &hipDevices) { devices = hipDevices; }
+    // convertDWfile --mem-limit=<MB> (the reference keeps it in a process-wide static, memory.cpp:30; default 3072): where the
+    // reference's blocks end, as a deterministic model (include/zdw_hip.h, zdw_opts.mem_limit_mb); 0 = never
+    void setMemoryLimitMB(double mb) { memLimitMB = mb; }
     // File format version to write: 11 (default), or 10 / 9 for readers that stop there (the JVM readers,
     // format/.../ZDWHeader.scala:25-39).  Version 10 is version 11 without the header's metadata block
     // (ConvertToZDW.cpp:673-694); version 9 is version 10 without the mediumtext / longtext column types.
@@ -90,7 +96,9 @@ private:
     bool bTrimTrailingSpaces;
     const bool bStreamingInput;
     int device;
+    std::vector<int> devices;
     int formatVersion;
+    double memLimitMB;
     std::vector<uint32_t> splitRows, splitFields;
     std::string libError;
 };

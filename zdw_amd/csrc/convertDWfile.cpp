@@ -80,6 +80,8 @@ static int runCommandLine(int argc, char *argv[])
     }
 
     bool streaming = false, removeOld = false, trim = false, validate = false, quiet = false;
+    double memLimitMB = 3072.0;            // DEFAULT_PROCESS_MEMORY_THRESHOLD of the reference (memory.cpp:22)
+    std::vector<int> devices;
     ConvertToZDW::Compressor compressor = ConvertToZDW::GZIP;
     const char *outputDir = NULL, *zArgs = NULL;
     std::map<std::string, std::string> metadata;
@@ -110,9 +112,11 @@ static int runCommandLine(int argc, char *argv[])
             if (!strcmp(flag, "help")) { showVersion(); usage(program); return ConvertToZDW::OK; }
             if (!strcmp(flag, "ver") || !strcmp(flag, "version")) { showVersion(); return ConvertToZDW::OK; }
             if (!strncmp(flag, "mem-limit=", 10)) {
-                // Accepted for command-line compatibility.  Block boundaries on this build are decided by
-                // the 32-bit dictionary limit or an explicit ZDW_SPLIT_ROWS override, not by host RAM.
+                // The reference ends a block when its process is at or beyond this many MB of virtual size while the string
+                // heap takes a new arena (memory.cpp:60-81, stringheap.cpp:74-86).  Here that size is a deterministic model
+                // (zdw_opts.mem_limit_mb): same flag, same default, block ends where the reference build's would.
                 if (!(atof(flag + 10) > 0.0)) return badParam(program, a);
+                memLimitMB = atof(flag + 10);
                 break;
             }
             if (!strncmp(flag, "metadata:", 9)) {
@@ -131,6 +135,28 @@ static int runCommandLine(int argc, char *argv[])
                 break;
             }
             if (!strncmp(flag, "zargs=", 6)) { zArgs = flag + 6; break; }
+            if (!strncmp(flag, "gpus=", 5)) {
+                // not in the reference tool: row-shard the file's block over the first N devices of the node
+                const int ngpu = atoi(flag + 5);
+                if (ngpu < 1 || ngpu > 64) return badParam(program, a);
+                devices.clear();
+                for (int d = 0; d < ngpu; ++d) devices.push_back(d);
+                break;
+            }
+            if (!strncmp(flag, "devices=", 8)) {
+                // ... or over exactly these devices (a device may be listed more than once)
+                devices.clear();
+                for (const char *q = flag + 8; *q;) {
+                    char *end = NULL;
+                    const long d = strtol(q, &end, 10);
+                    if (end == q || d < 0) return badParam(program, a);
+                    devices.push_back(static_cast<int>(d));
+                    q = *end == ',' ? end + 1 : end;
+                    if (*end && *end != ',') return badParam(program, a);
+                }
+                if (devices.empty()) return badParam(program, a);
+                break;
+            }
             if (!strncmp(flag, "format-version=", 15)) {
                 // not in the reference tool: write an older header for readers that stop at version 10 (or 9)
                 char *end = NULL;
@@ -156,6 +182,8 @@ static int runCommandLine(int argc, char *argv[])
         }
         char filestub[1024];
         ConvertToZDW convert(quiet, streaming);
+        convert.setMemoryLimitMB(memLimitMB);
+        if (!devices.empty()) convert.setDevices(devices);
         convert.setFormatVersion(formatVersion);
         convert.compressor = compressor;
         if (trim) convert.trimTrailingSpaces();

@@ -523,6 +523,84 @@ void launch_scatter_offsets(const uint32_t *order, const uint32_t *offsets, uint
     if (n) hipLaunchKernelGGL(k_scatter_offsets, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, order, offsets, (uint32_t)n, id_off);
 }
 
+// ------------------------------------------------------------------------------------------
+// The reference's block limit as a deterministic model (DESIGN.md states the fit): a block ends
+// when StringHeap takes a new 64 MiB arena while the process is at or beyond --mem-limit.  The strings enter the
+// arenas in the order pass 1 first meets them, so: unique ids by position, prefix sums of len + 1, then a walk over
+// the arenas (a few dozen binary searches) finds the string whose arena trips the limit.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_model_keys(const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len, uint32_t n,
+                                                     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = uniq_len[i] ? (uniq_pos[i] & POS_MASK) : POS_MASK;      // holes (length 0) after every string
+    vals[i] = i;
+}
+
+// one thread: arenas[0] = index (in position order) of the string whose arena allocation trips the limit, or ~0
+__global__ void k_model_trip(const uint64_t *__restrict__ excl /* n + 1 */, uint32_t nreal, double base_mb, double node_bytes, double limit_mb,
+                             uint64_t arena_bytes, uint64_t *__restrict__ out)
+{
+    uint64_t start = 0, arenas = 0, trip = ~0ull;
+    while (start < nreal) {
+        ++arenas;
+        const double vsize = base_mb + 64.0 * (double)arenas + node_bytes * (double)(start + 1) / 1048576.0;
+        if (vsize >= limit_mb) { trip = start; break; }
+        const uint64_t need0 = excl[start + 1] - excl[start];
+        const uint64_t cap = need0 > arena_bytes ? need0 : arena_bytes;
+        // the arena holds strings start .. j - 1: the largest j with excl[j] - excl[start] <= cap
+        uint64_t lo = start + 1, hi = nreal;              // invariant: excl[lo] - excl[start] <= cap
+        const uint64_t lim = excl[start] + cap;
+        while (lo < hi) {
+            const uint64_t m = lo + (hi - lo + 1) / 2;
+            if (excl[m] <= lim) lo = m; else hi = m - 1;
+        }
+        start = lo;
+    }
+    out[0] = trip;
+    out[1] = arenas;
+}
+
+// Where in its row does position p lie?  One wave: out[0] = start of the row that holds p, out[1] = unescaped tabs
+// between the row's start and p (= the field's column).
+__global__ __launch_bounds__(64) void k_locate_field(const uint8_t *__restrict__ in, uint64_t lo, uint64_t p, uint64_t *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x;
+    uint64_t rs = lo;
+    for (uint64_t hi = p; hi > lo;) {                     // backwards, 64 bytes at a time: the last row terminator before p
+        const uint64_t q = hi - 1 - lane;
+        const bool t = hi > lo + lane && in[q] == '\n' && is_row_terminator(in, lo, q);
+        const uint64_t m = __ballot(t);
+        if (m) { rs = hi - (uint64_t)lowest_bit(m); break; }
+        hi = hi > lo + 64 ? hi - 64 : lo;
+    }
+    uint32_t tabs = 0;
+    for (uint64_t q = rs + lane; q < p; q += 64)
+        if (in[q] == '\t' && (backslashes_before(in, rs, q) & 1u) == 0) ++tabs;
+    uint32_t total;
+    wave_excl_sum(tabs, lane, total);
+    if (lane == 0) { out[0] = rs; out[1] = total; }
+}
+
+void launch_model_sort(const uint64_t *uniq_pos, const uint32_t *uniq_len, uint32_t n, SortBuffers &b, uint32_t **vals_out, hipStream_t s)
+{
+    uint64_t *keys = b.key_a, *keys_alt = b.key_b;
+    uint32_t *vals = b.val_a, *vals_alt = b.val_b;
+    hipLaunchKernelGGL(k_model_keys, dim3((n + 255) / 256), dim3(256), 0, s, uniq_pos, uniq_len, n, keys, vals);
+    radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, n, 0, (uint32_t)POS_BITS, b.hist, b.scan_tmp, s);
+    *vals_out = vals;
+}
+void launch_model_trip(const uint64_t *excl, uint32_t nreal, double base_mb, double node_bytes, double limit_mb, uint64_t arena_bytes, uint64_t *out,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(k_model_trip, dim3(1), dim3(1), 0, s, excl, nreal, base_mb, node_bytes, limit_mb, arena_bytes, out);
+}
+void launch_locate_field(const uint8_t *in, uint64_t lo, uint64_t p, uint64_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_locate_field, dim3(1), dim3(64), 0, s, in, lo, p, out);
+}
+
 // Persistent waves: a wave keeps its chunk of unique ids across the groups of 64 strings it handles (one
 // returning atomic on the id counter per wave and group would bound the kernel: ~30 M/s on one word).
 __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *__restrict__ lens,

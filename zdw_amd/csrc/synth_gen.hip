@@ -6,6 +6,7 @@
 //   0 word   : Zipf(1.1) rank over `vocab` words, word i = 4..24 chars of [a-z0-9_] from hash(i)
 //   1..4 int : uniform in [0, 2^7 | 2^15 | 2^31 | 2^47)
 //   5 char(1), 6 datetime "2024-01-DD HH:MM:SS", 7 decimal "<int>.<12 digits>"
+//   8 id     : 24-character token from the cell's own hash (C5's high-cardinality varchar(64) columns)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -72,6 +73,14 @@ __device__ inline uint32_t emit_field(uint8_t *q, uint64_t seed, uint64_t row, u
             if (WRITE) q[j] = (uint8_t)"abcdefghijklmnopqrstuvwxyz0123456789_"[w % 37];
         }
         return len;
+    }
+    case 8: {   // id-like token: 24 characters drawn from this cell's own hash (practically unique: the high-cardinality columns of C5)
+        uint64_t w = mix(h ^ 0xA24BAED4963EE407ull);
+        for (uint32_t j = 0; j < 24; ++j) {
+            if (j == 12) w = mix(w + h);
+            if (WRITE) q[j] = (uint8_t)"abcdefghijklmnopqrstuvwxyz0123456789_"[(w >> (5 * (j % 12))) % 37];
+        }
+        return 24;
     }
     case 1: return put_u64<WRITE>(q, r & 0x7Full);
     case 2: return put_u64<WRITE>(q, r & 0x7FFFull);

@@ -94,6 +94,13 @@ struct zdw_ctx {
     uint32_t row_cap_block = FIRST_ROW_CAP; // its value when the current block began (a re-run of the block starts from it again)
     uint64_t row_cap_block_lo = ~0ull;
     Budget budget;
+    double mem_limit_mb = 0.0;             // the reference's --mem-limit as a model of where its blocks end (0 = off)
+    uint64_t model_max_slots = 0;          // while the model drives pass 1: the dictionary table never grows beyond this
+    uint32_t model_rows_prev = 0;          // rows of the previous block the model ended (the next block's first window)
+    uint32_t partial_taken = 0;            // leading fields of the row after the current block that its pass 1 visited (zdw_block_partial_fields)
+    uint64_t pass1_launches = 0;           // pass-1 kernel launches of this context (zdw_ctx_pass1_launches)
+    uint32_t last_span_shift = 14;         // geometry of the last pass 1 (model_trip)
+    uint64_t last_span0 = 0;
     bool oom_seen = false;                 // a call ended in OUT_OF_MEMORY: the next pass 1 starts from released block buffers
     std::vector<LongRow> long_list;        // this block's rows of 16383 bytes or more, by position (zdw_shard_line_caps replays them)
     uint64_t long_read_end = 0;
@@ -134,6 +141,7 @@ struct zdw_ctx {
     bool own_built = false;
     bool p1_all_in_one = false;            // the deferred-field queue would outgrow its budget: use the all-in-one kernel
     uint64_t dq_learned = 0;               // queue entries an earlier pass of this context needed
+    double dq_rate = 0.0;                  // ... and the most it queued per input byte
     uint8_t index_size = 0;
     uint64_t dict_sec_off = 0, dict_sec_len = 0;
     uint32_t sort_rounds = 0;
@@ -279,6 +287,7 @@ int after_input(zdw_ctx *c)
     reset_block(c);
     c->lo = c->next_lo = 0;
     c->row_cap = c->first_row_cap;          // a new input starts with a fresh line buffer (ConvertToZDW.cpp:965)
+    c->model_rows_prev = 0;
     c->row_cap_block_lo = ~0ull;
     c->hi = 0;
     c->avg_row = 0;
@@ -411,6 +420,79 @@ int ensure_dict(zdw_ctx *c)
         HIP_TRY(c, hipStreamSynchronize(s));
     }
     c->dict_done = true;
+    return ZDW_OK;
+}
+
+// ---- where would the reference have ended this block?  (--mem-limit as a model: DESIGN.md) ----
+// vsize_MB = 2.6 + 64 x arenas + 64 B x strings / 2^20, checked whenever StringHeap takes a new 64 MiB arena; the strings
+// enter the arenas in the order pass 1 first meets them.  Pass 1 has just run over rows [0, nrows): *found = the limit
+// trips inside them, at field *fields - 1 of row *row (that row and everything after it belong to the next block).
+// The order of first occurrences is taken from uniq_pos, the occurrence that won the insertion: exact for strings that
+// occur once (the id-like columns that make dictionaries large); where an earlier occurrence of a string lost the race
+// to a later one the trip can move by that string's bytes -- the split is then not the reference's, the file still is
+// what the reference writes for that split (the re-run with the split hint decides every byte).
+constexpr double MODEL_BASE_MB = 2.6, MODEL_NODE_BYTES = 64.0;
+constexpr uint64_t MODEL_ARENA = 64ull << 20;
+
+int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uint32_t *row, uint32_t *fields)
+{
+    *found = false;
+    hipStream_t s = c->stream;
+    P1Status st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint64_t u = st.id_next, nreal = st.entries;
+    if (!nreal || u > c->id_cap) return ZDW_OK;
+    // cheap bound first: even with every arena wasting its tail the limit stays out of reach
+    HIP_TRY(c, c->lenp1.ensure((u + 1) * 4));
+    HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(u + 1)));
+    HIP_TRY(c, c->d_scalar.ensure(64));
+    launch_dict_lengths(nullptr, c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint64_t max_len = std::max<uint64_t>(st.max_len, 24) + 1;
+    const double arenas_ub = (double)(total / (MODEL_ARENA > 2 * max_len ? MODEL_ARENA - max_len : MODEL_ARENA / 2) + 1);
+    if (MODEL_BASE_MB + 64.0 * arenas_ub + MODEL_NODE_BYTES * (double)nreal / 1048576.0 < c->mem_limit_mb) return ZDW_OK;
+    // exact: unique ids by position, prefix sums of len + 1 in that order, the walk over the arenas
+    SortBuffers b{};
+    int rc = sort_buffers(c, u, b);
+    if (rc) return rc;
+    uint32_t *by_pos = nullptr;
+    launch_model_sort(c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), (uint32_t)u, b, &by_pos, s);
+    launch_dict_lengths(by_pos, c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+    launch_model_trip(c->off_excl.as<uint64_t>(), (uint32_t)nreal, MODEL_BASE_MB, MODEL_NODE_BYTES, c->mem_limit_mb, MODEL_ARENA, c->d_scalar.as<uint64_t>(), s);
+    uint64_t res[2] = {~0ull, 0};
+    HIP_TRY(c, hipMemcpyAsync(res, c->d_scalar.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (res[0] == ~0ull) return ZDW_OK;
+    uint32_t id = 0;
+    uint64_t pos = 0;
+    HIP_TRY(c, hipMemcpy(&id, by_pos + res[0], 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&pos, c->uniq_pos.as<uint64_t>() + id, 8, hipMemcpyDeviceToHost));
+    pos &= POS_MASK;
+    if (pos >= EXTRA_BASE) return ZDW_OK;                  // an imported string (multi-GPU merge): no position in this image
+    // the row and the column of that occurrence
+    launch_locate_field(c->d_in, c->lo, pos, c->d_scalar.as<uint64_t>(), s);
+    uint64_t loc[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(loc, c->d_scalar.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint64_t rs = loc[0];
+    const uint64_t si = (rs >> span_shift) - span0;        // the span the row starts in; rows that start before it: span_rowbase
+    uint32_t rowbase = 0, in_span = 0;
+    HIP_TRY(c, hipMemcpy(&rowbase, c->span_rowbase.as<uint32_t>() + si, 4, hipMemcpyDeviceToHost));
+    if (rs > std::max<uint64_t>((span0 + si) << span_shift, c->lo)) {
+        // ... and the rows that start inside it before this one: the row scan's own kernel on that piece
+        launch_count_row_starts(c->d_in, c->n, c->lo, rs, span0 + si, 1, span_shift, c->d_scalar.as<uint32_t>() + 8, c->status.as<P1Status>(), s);
+        HIP_TRY(c, hipMemcpyAsync(&in_span, c->d_scalar.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    *found = true;
+    *row = rowbase + in_span;
+    *fields = (uint32_t)loc[1] + 1;
     return ZDW_OK;
 }
 
@@ -625,6 +707,7 @@ int zdw_ctx_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opt
         c->slots_opt = opts->dict_slots;
         c->max_dict_bytes = opts->max_dict_bytes;
         if (opts->struct_size >= offsetof(zdw_opts, max_device_bytes) + sizeof(uint64_t)) c->budget.cap = opts->max_device_bytes;
+        if (opts->struct_size >= offsetof(zdw_opts, mem_limit_mb) + sizeof(uint64_t)) c->mem_limit_mb = (double)opts->mem_limit_mb;
     }
     for (DevBuf *b : all_device_buffers(c)) b->bud = &c->budget;
     int rc = upload_schema(c);
@@ -694,9 +777,49 @@ int zdw_set_input_device(zdw_ctx *c, const void *d_tsv, uint64_t len)
     return after_input(c);
 }
 
+static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *res);
+
+uint64_t zdw_ctx_pass1_launches(const zdw_ctx *c) { return c ? c->pass1_launches : 0; }
+uint32_t zdw_block_partial_fields(const zdw_ctx *c) { return c ? c->partial_taken : 0; }
+
 int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *res)
 {
     if (!c || !res) return ZDW_UNKNOWN_ERROR;
+    if (c->mem_limit_mb <= 0.0 || (hint && hint->max_rows != 0xFFFFFFFFu)) return pass1_impl(c, hint, res);      // (a caller's split overrides the model)
+    // The reference's block limit as a model (model_trip).  The block is parsed once over a window of rows -- everything that
+    // is left for a file's first block, one and a half times the block before after that -- and, when the limit trips
+    // inside the window, once more up to exactly that row and field: two pass-1 launches per block that the model ends, one
+    // for a last block, and the rows beyond a block are parsed by at most the window's excess.
+    uint64_t window = c->model_rows_prev ? (uint64_t)c->model_rows_prev + c->model_rows_prev / 2 + 1000 : 0xFFFFFFFFull;
+    {   // The limit is only looked at when an arena is taken: a block holds at most the strings that bring the process to the limit
+        // ((limit - first arena) / 64 B) plus one more arena of them (64 MiB of strings of a few bytes each: 2^24 as a bound for
+        // tables, not for adversaries -- beyond it the block ends where the table is full).  The table never needs more than twice that.
+        const double max_nodes = std::max(0.0, c->mem_limit_mb - MODEL_BASE_MB - 64.0) * 1048576.0 / MODEL_NODE_BYTES + (double)(1u << 24);
+        uint64_t ms = 1ull << 14;
+        while ((double)ms < 2.0 * max_nodes && ms < (1ull << 31)) ms <<= 1;
+        c->model_max_slots = ms;
+    }
+    struct Unset { zdw_ctx *c; ~Unset() { c->model_max_slots = 0; } } unset{c};
+    for (;;) {
+        zdw_split_hint w = {window >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)window, 0};
+        int rc = pass1_impl(c, w.max_rows == 0xFFFFFFFFu ? nullptr : &w, res);
+        if (rc) return rc;
+        bool found = false;
+        uint32_t row = 0, fields = 0;
+        rc = model_trip(c, c->last_span_shift, c->last_span0, &found, &row, &fields);
+        if (rc) return rc;
+        if (found && row <= res->num_rows) {
+            zdw_split_hint e = {row, fields};
+            c->model_rows_prev = row;
+            return pass1_impl(c, &e, res);
+        }
+        if (res->is_last_block || res->num_rows < w.max_rows) return ZDW_OK;      // all of the input, or a block that device memory ended
+        window = window * 2;                                                       // the block is longer than the window: again, wider
+    }
+}
+
+static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *res)
+{
     memset(res, 0, sizeof *res);
     if (!c->have_input) return fail(c, ZDW_UNKNOWN_ERROR, "no input set");
     (void)hipSetDevice(c->device);
@@ -864,17 +987,22 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             // characters: queue 19 / 27 ms, all-in-one 34 / 42 ms.)
             const bool defer = lds_ranges && !c->p1_all_in_one && !getenv("ZDW_P1_ALL_IN_ONE");
             if (defer) {
-                uint64_t dq_div = 1024;
+                uint64_t dq_div = 256;
                 if (const char *e = getenv("ZDW_DQ_DIV")) dq_div = std::max<uint64_t>(8, strtoull(e, nullptr, 10));      // experiments
-                const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>((hi - lo) / dq_div + 65536, c->dq_learned), 1ull << 31);
+                // (what earlier passes of this context queued per input byte, with a quarter to spare, when that is more)
+                const uint64_t by_rate = (uint64_t)((double)(hi - lo) * c->dq_rate * 1.25);
+                const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(std::max<uint64_t>((hi - lo) / dq_div + 65536, by_rate), c->dq_learned), 1ull << 31);
                 HIP_TRY(c, c->deferred_q.ensure(cap * 16));
                 a.dq = c->deferred_q.as<uint64_t>(); a.dq_cap = (uint32_t)cap;
             }
             launch_pass1(a, s);
+            ++c->pass1_launches;
+            c->last_span_shift = span_shift; c->last_span0 = span0;
             if (defer) {
                 HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
                 if (st.deferred_lost) {
+                    if (getenv("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] deferred queue of %u entries lost fields (%u queued): again\n", a.dq_cap, st.deferred);
                     const uint64_t need = (uint64_t)st.deferred + st.deferred / 8 + 65536;       // (a re-run hands out its chunks differently)
                     if (!dq_grown && need * 16 <= (hi - lo) + (64ull << 20) && need > a.dq_cap && need < (1ull << 31) && !st.overflow) {
                         c->dq_learned = need;
@@ -885,6 +1013,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
                     --attempt;
                     continue;
                 }
+                if (hi > lo) c->dq_rate = std::max(c->dq_rate, (double)st.deferred / (double)(hi - lo));
                 if (st.deferred && !st.overflow) launch_pass1_deferred(a, st.deferred, s);
             }
         }
@@ -894,11 +1023,21 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));
         if (st.nul_seen == 2) return fail(c, ZDW_UNKNOWN_ERROR, "a single field of 1 GiB or more is not supported");
         if (!st.overflow) break;
+        if (getenv("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] table of %llu slots overflowed (%u entries, %u ids of %u): again\n", (unsigned long long)nslots, st.entries, st.id_next, c->id_cap);
+        if (c->model_max_slots && nslots >= c->model_max_slots && nrows > 1) {
+            // The memory-limit model ends a block long before its dictionary needs a larger table than this: these rows hold
+            // more strings than any block may -- look at half of them instead of growing the table.
+            (void)fewer_rows();
+            attempt = -1;
+            continue;
+        }
         nslots <<= 2;                       // table too small for this block's uniques: grow and redo the pass
+        if (c->model_max_slots && nslots > c->model_max_slots) nslots = c->model_max_slots;
         if (attempt > 12) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
     }
     c->nrows = nrows;
     c->is_last = !tripped;
+    c->partial_taken = tripped ? partial : 0;
     res->table_slots = nslots;
     c->slots_learned = nslots; c->rows_learned = nrows;
     res->dict_entries = st.entries;

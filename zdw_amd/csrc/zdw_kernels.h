@@ -122,6 +122,11 @@ void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, 
 void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                            const uint32_t *order /* optional */, const uint64_t *off_excl, uint64_t n, uint8_t *bytes,
                            uint32_t *lens_out /* optional */, hipStream_t s);
+// the reference's --mem-limit as a deterministic model (block ends)
+void launch_model_sort(const uint64_t *uniq_pos, const uint32_t *uniq_len, uint32_t n, SortBuffers &b, uint32_t **vals_out, hipStream_t s);
+void launch_model_trip(const uint64_t *excl, uint32_t nreal, double base_mb, double node_bytes, double limit_mb, uint64_t arena_bytes, uint64_t *out,
+                       hipStream_t s);
+void launch_locate_field(const uint8_t *in, uint64_t lo, uint64_t p, uint64_t *out, hipStream_t s);
 // range-partitioned dictionary (multi-GPU)
 void launch_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                      const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys, hipStream_t s);

@@ -1,0 +1,492 @@
+// zdw_multi.hip — one ZDW block row-sharded over several GPUs of one node, inside the library (include/zdw_hip.h,
+// zdw_multi_*): what convertDWfile --gpus=N runs.  SURVEY.md §8e; the reference has no counterpart (one process, one core).
+//
+// One process, one zdw_ctx and one host thread per device.  Every shard holds a contiguous row range of ONE block whose
+// bytes must not depend on the number of shards, so after each shard's pass 1:
+//   1. column ranges        min / max / seen  -> ncclAllReduce (min, max, max) on every device
+//   2. dictionary           range-partitioned: every shard samples 16-byte prefix keys of its unique strings, the host
+//                           picks N - 1 splitters, strings travel to the owner of their key range (grouped ncclSend /
+//                           ncclRecv over the xGMI links: an all-to-all-v), the owner dedupes + sorts + lays out its range,
+//                           every string's offset travels back the same way.  The node-wide dictionary is sorted once,
+//                           1/N of it per device, and device r's section piece is range r
+//   3. row halo             stored values of a shard's last row -> "previous row" of the next shard (a few KB: host)
+// Sizes, counts, splitters and status codes are plain host values: all shards live in this process.
+//
+// Transport: RCCL (ncclCommInitAll, grouped point-to-point) when the devices are distinct; when the same device is
+// listed more than once (tests on a one-GPU box) the same exchange runs as device-to-device copies.
+#include "../../include/zdw_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Shard {
+    zdw_ctx *ctx = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;          // the exchange's stream on this device
+    ncclComm_t comm = nullptr;
+    uint64_t in_off = 0, in_len = 0;       // this shard's piece of the host image
+    zdw_pass1_result p1{};
+    int rc = 0;
+    std::string err;
+    // exchange buffers (device)
+    void *d_ranges = nullptr;              // 3 x ncols u64: ~min, max, seen
+    void *d_recv_lens = nullptr, *d_recv_bytes = nullptr, *d_recv_offs = nullptr, *d_back = nullptr;
+    size_t cap_recv_lens = 0, cap_recv_bytes = 0, cap_recv_offs = 0, cap_back = 0;
+    // partition results
+    std::vector<uint64_t> counts, nbytes;  // per destination range
+    const void *d_lens = nullptr, *d_bytes = nullptr;
+    const void *d_offsets = nullptr;
+    uint64_t slice = 0;
+};
+
+}  // namespace
+
+struct zdw_multi {
+    std::vector<Shard> sh;
+    uint32_t ncols = 0;
+    bool use_rccl = false;
+    std::string err;
+    const uint8_t *image = nullptr;
+    uint64_t image_len = 0;
+    bool encoded = false;
+    uint32_t longest_line = 16384;
+};
+
+namespace {
+
+thread_local std::string g_multi_create_error;
+
+int mfail(zdw_multi *m, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (m) m->err = buf; else g_multi_create_error = buf;
+    return code;
+}
+
+#define M_HIP(m, call)                                                                                                   \
+    do {                                                                                                                 \
+        hipError_t e_ = (call);                                                                                          \
+        if (e_ != hipSuccess) return mfail((m), e_ == hipErrorOutOfMemory ? ZDW_OUT_OF_MEMORY : ZDW_UNKNOWN_ERROR, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+#define M_NCCL(m, call)                                                                                                  \
+    do {                                                                                                                 \
+        ncclResult_t r_ = (call);                                                                                        \
+        if (r_ != ncclSuccess) return mfail((m), ZDW_UNKNOWN_ERROR, "%s: %s", #call, ncclGetErrorString(r_));            \
+    } while (0)
+
+int grow(zdw_multi *m, int device, void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap && *p) return ZDW_OK;
+    M_HIP(m, hipSetDevice(device));
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t want = bytes < 256 ? 256 : bytes + bytes / 16;
+    M_HIP(m, hipMalloc(p, want));
+    *cap = want;
+    return ZDW_OK;
+}
+
+// run f(shard index) on every shard, one host thread per device (the per-shard calls block on their device)
+template <typename F>
+void for_shards(zdw_multi *m, F f)
+{
+    if (m->sh.size() == 1) { f(0); return; }
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < m->sh.size(); ++i) th.emplace_back([&, i] { (void)hipSetDevice(m->sh[i].device); f(i); });
+    for (auto &t : th) t.join();
+}
+
+int first_failure(zdw_multi *m, const char *what)
+{
+    for (size_t i = 0; i < m->sh.size(); ++i)
+        if (m->sh[i].rc) return mfail(m, m->sh[i].rc, "%s failed on shard %zu (device %d): %s", what, i, m->sh[i].device, m->sh[i].err.c_str());
+    return ZDW_OK;
+}
+
+// is byte p of the host image an unescaped newline (a row terminator)?  (getnextrow.cpp:45-53)
+bool host_row_terminator(const uint8_t *in, uint64_t p)
+{
+    if (in[p] != '\n') return false;
+    uint64_t k = 0;
+    while (k < p && in[p - 1 - k] == '\\') ++k;
+    return (k & 1) == 0;
+}
+
+// all-to-all-v between the shards: piece (q -> r) = cnt[q][r] elements of `esize` bytes, taken from src[q] at the running
+// offset of shard q's pieces and delivered to dst[r] at the running offset of what r receives (pieces ordered by sender)
+int all_to_all_v(zdw_multi *m, const std::vector<const void *> &src, const std::vector<void *> &dst, const std::vector<std::vector<uint64_t>> &cnt,
+                 size_t esize)
+{
+    const size_t n = m->sh.size();
+    std::vector<uint64_t> recv_at(n, 0);
+    if (m->use_rccl) M_NCCL(m, ncclGroupStart());
+    for (size_t q = 0; q < n; ++q) {
+        uint64_t send_at = 0;
+        for (size_t r = 0; r < n; ++r) {
+            const uint64_t c = cnt[q][r];
+            if (c) {
+                const char *from = static_cast<const char *>(src[q]) + send_at * esize;
+                char *to = static_cast<char *>(dst[r]) + 0;
+                // where this piece lands in r's buffer: after the pieces of senders 0 .. q - 1
+                uint64_t land = 0;
+                for (size_t p = 0; p < q; ++p) land += cnt[p][r];
+                to += land * esize;
+                if (m->use_rccl) {
+                    M_NCCL(m, ncclSend(from, c * esize, ncclUint8, (int)r, m->sh[q].comm, m->sh[q].stream));
+                    M_NCCL(m, ncclRecv(to, c * esize, ncclUint8, (int)q, m->sh[r].comm, m->sh[r].stream));
+                } else {
+                    M_HIP(m, hipMemcpyPeerAsync(to, m->sh[r].device, from, m->sh[q].device, c * esize, m->sh[r].stream));
+                }
+            }
+            send_at += c;
+        }
+    }
+    if (m->use_rccl) M_NCCL(m, ncclGroupEnd());
+    for (size_t r = 0; r < n; ++r) { M_HIP(m, hipSetDevice(m->sh[r].device)); M_HIP(m, hipStreamSynchronize(m->sh[r].stream)); }
+    (void)recv_at;
+    return ZDW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *zdw_multi_last_error(const zdw_multi *m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
+
+void zdw_multi_destroy(zdw_multi *m)
+{
+    if (!m) return;
+    for (Shard &s : m->sh) {
+        (void)hipSetDevice(s.device);
+        if (s.ctx) zdw_ctx_destroy(s.ctx);
+        for (void *p : {s.d_ranges, s.d_recv_lens, s.d_recv_bytes, s.d_recv_offs, s.d_back}) if (p) (void)hipFree(p);
+        if (s.comm) (void)ncclCommDestroy(s.comm);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete m;
+}
+
+int zdw_multi_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opts, const int32_t *devices, uint32_t ndev, zdw_multi **out)
+{
+    if (!out || !devices || !ndev) return mfail(nullptr, ZDW_UNKNOWN_ERROR, "zdw_multi_create: bad arguments");
+    *out = nullptr;
+    zdw_multi *m = new (std::nothrow) zdw_multi();
+    if (!m) return mfail(nullptr, ZDW_OUT_OF_MEMORY, "zdw_multi_create: out of host memory");
+    m->ncols = ncols;
+    m->sh.resize(ndev);
+    std::set<int> distinct(devices, devices + ndev);
+    const char *tr = getenv("ZDW_MULTI_TRANSPORT");      // "copy": device-to-device copies even between distinct devices (A/B measurements)
+    m->use_rccl = distinct.size() == ndev && !(tr && !strcmp(tr, "copy"));
+    for (uint32_t i = 0; i < ndev; ++i) {
+        Shard &s = m->sh[i];
+        s.device = devices[i];
+        zdw_opts o;
+        memset(&o, 0, sizeof o);
+        if (opts) memcpy(&o, opts, std::min<size_t>(sizeof o, opts->struct_size ? opts->struct_size : sizeof o));
+        o.struct_size = sizeof o;
+        o.device = s.device;
+        o.mem_limit_mb = 0;                       // one block: where it ends is not a per-shard decision
+        const int rc = zdw_ctx_create(col_types, ncols, &o, &s.ctx);
+        if (rc) { const int r2 = mfail(nullptr, rc, "shard %u (device %d): %s", i, s.device, zdw_last_error(nullptr)); zdw_multi_destroy(m); return r2; }
+        if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+            const int r2 = mfail(nullptr, ZDW_UNKNOWN_ERROR, "shard %u: no stream on device %d", i, s.device);
+            zdw_multi_destroy(m);
+            return r2;
+        }
+    }
+    if (m->use_rccl) {
+        std::vector<ncclComm_t> comms(ndev);
+        std::vector<int> devs(devices, devices + ndev);
+        const ncclResult_t r = ncclCommInitAll(comms.data(), (int)ndev, devs.data());
+        if (r != ncclSuccess) { const int r2 = mfail(nullptr, ZDW_UNKNOWN_ERROR, "ncclCommInitAll: %s", ncclGetErrorString(r)); zdw_multi_destroy(m); return r2; }
+        for (uint32_t i = 0; i < ndev; ++i) m->sh[i].comm = comms[i];
+    }
+    *out = m;
+    return ZDW_OK;
+}
+
+// The host image is cut into one piece per shard at row boundaries (the first unescaped newline at or after i/N of it);
+// every piece goes to its device.  The image must stay valid until zdw_multi_encode has returned.
+int zdw_multi_set_input_host(zdw_multi *m, const uint8_t *tsv, uint64_t len)
+{
+    if (!m || (len && !tsv)) return m ? mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_set_input_host: tsv is NULL") : ZDW_UNKNOWN_ERROR;
+    const size_t n = m->sh.size();
+    m->image = tsv; m->image_len = len; m->encoded = false;
+    std::vector<uint64_t> cut(n + 1, len);
+    cut[0] = 0;
+    for (size_t i = 1; i < n; ++i) {
+        uint64_t p = std::max<uint64_t>(len / n * i, cut[i - 1]);
+        while (p < len && !host_row_terminator(tsv, p)) ++p;
+        cut[i] = p < len ? p + 1 : len;
+    }
+    for (size_t i = 0; i < n; ++i) { m->sh[i].in_off = cut[i]; m->sh[i].in_len = cut[i + 1] - cut[i]; }
+    for_shards(m, [&](size_t i) {
+        Shard &s = m->sh[i];
+        s.rc = zdw_set_input_host(s.ctx, tsv + s.in_off, s.in_len);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    });
+    return first_failure(m, "loading the input");
+}
+
+int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
+{
+    if (!m || !blk) return ZDW_UNKNOWN_ERROR;
+    memset(blk, 0, sizeof *blk);
+    const size_t n = m->sh.size();
+    const uint32_t nc = m->ncols;
+    // ---- pass 1 on every shard ----
+    for_shards(m, [&](size_t i) {
+        Shard &s = m->sh[i];
+        s.rc = zdw_block_pass1(s.ctx, nullptr, &s.p1);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    });
+    {
+        uint32_t rows_before = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (m->sh[i].rc == ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW) {       // the first bad row of the block (ConvertToZDW.cpp:810-812)
+                blk->bad_row = rows_before + m->sh[i].p1.bad_row;
+                return mfail(m, ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW, "Row %u had the problem", blk->bad_row);
+            }
+            if (m->sh[i].rc) break;
+            rows_before += m->sh[i].p1.num_rows;
+        }
+    }
+    int rc = first_failure(m, "pass 1");
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i)
+        if (!m->sh[i].p1.is_last_block) return mfail(m, ZDW_OUT_OF_MEMORY, "shard %zu does not fit its device as one block: use more devices or the one-GPU path", i);
+
+    // ---- 1. column ranges: all-reduce of [~min, max, seen] with max (~x reverses the unsigned order) ----
+    {
+        std::vector<std::vector<uint64_t>> host(n, std::vector<uint64_t>(3 * (size_t)nc + 1));
+        for (size_t i = 0; i < n; ++i) {
+            Shard &s = m->sh[i];
+            std::vector<uint64_t> mn(nc + 1), mx(nc + 1);
+            std::vector<uint8_t> seen(nc + 1);
+            rc = zdw_shard_export_ranges(s.ctx, mn.data(), mx.data(), seen.data());
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+            for (uint32_t k = 0; k < nc; ++k) { host[i][k] = ~mn[k]; host[i][nc + k] = mx[k]; host[i][2 * (size_t)nc + k] = seen[k]; }
+        }
+        const size_t cnt = 3 * (size_t)nc;
+        if (cnt && n > 1) {
+            for (size_t i = 0; i < n; ++i) {
+                Shard &s = m->sh[i];
+                size_t cap = s.d_ranges ? cnt * 8 : 0;
+                if (!s.d_ranges) { rc = grow(m, s.device, &s.d_ranges, &cap, cnt * 8); if (rc) return rc; }
+                M_HIP(m, hipSetDevice(s.device));
+                M_HIP(m, hipMemcpyAsync(s.d_ranges, host[i].data(), cnt * 8, hipMemcpyHostToDevice, s.stream));
+            }
+            if (m->use_rccl) {
+                M_NCCL(m, ncclGroupStart());
+                for (size_t i = 0; i < n; ++i) M_NCCL(m, ncclAllReduce(m->sh[i].d_ranges, m->sh[i].d_ranges, cnt, ncclUint64, ncclMax, m->sh[i].comm, m->sh[i].stream));
+                M_NCCL(m, ncclGroupEnd());
+                for (size_t i = 0; i < n; ++i) {
+                    M_HIP(m, hipSetDevice(m->sh[i].device));
+                    M_HIP(m, hipMemcpyAsync(host[i].data(), m->sh[i].d_ranges, cnt * 8, hipMemcpyDeviceToHost, m->sh[i].stream));
+                    M_HIP(m, hipStreamSynchronize(m->sh[i].stream));
+                }
+            } else {
+                for (size_t i = 0; i < n; ++i) { M_HIP(m, hipSetDevice(m->sh[i].device)); M_HIP(m, hipStreamSynchronize(m->sh[i].stream)); }
+                for (size_t k = 0; k < cnt; ++k) {
+                    uint64_t v = 0;
+                    for (size_t i = 0; i < n; ++i) v = std::max(v, host[i][k]);
+                    for (size_t i = 0; i < n; ++i) host[i][k] = v;
+                }
+            }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            std::vector<uint64_t> mn(nc + 1), mx(nc + 1);
+            std::vector<uint8_t> seen(nc + 1);
+            for (uint32_t k = 0; k < nc; ++k) { mn[k] = ~host[i][k]; mx[k] = host[i][nc + k]; seen[k] = host[i][2 * (size_t)nc + k] ? 1 : 0; }
+            rc = zdw_shard_import_ranges(m->sh[i].ctx, mn.data(), mx.data(), seen.data());
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
+        }
+    }
+
+    // ---- 2. dictionary, range-partitioned ----
+    constexpr uint32_t SAMPLES = 256;
+    std::vector<uint64_t> splitters;            // 2 words each, n - 1 of them
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> all;
+        for (size_t i = 0; i < n; ++i) {
+            uint64_t cnt = 0;
+            rc = zdw_shard_sort_uniques(m->sh[i].ctx, &cnt);
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
+            std::vector<uint64_t> keys(2 * SAMPLES);
+            rc = zdw_shard_sample_keys(m->sh[i].ctx, SAMPLES, keys.data());
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
+            for (uint32_t k = 0; k < SAMPLES; ++k)
+                if (!(keys[2 * k] == ~0ull && keys[2 * k + 1] == ~0ull)) all.emplace_back(keys[2 * k], keys[2 * k + 1]);      // "no string here" carries no information
+        }
+        if (all.empty()) all.emplace_back(~0ull, ~0ull);
+        std::sort(all.begin(), all.end());
+        for (size_t j = 1; j < n; ++j) {
+            const auto &k = all[std::min(all.size() - 1, j * all.size() / n)];
+            splitters.push_back(k.first); splitters.push_back(k.second);
+        }
+    }
+    std::vector<std::vector<uint64_t>> cnt(n, std::vector<uint64_t>(n)), nby(n, std::vector<uint64_t>(n));
+    for_shards(m, [&](size_t i) {
+        Shard &s = m->sh[i];
+        s.counts.assign(n, 0); s.nbytes.assign(n, 0);
+        s.rc = zdw_shard_partition(s.ctx, (uint32_t)n, splitters.data(), s.counts.data(), s.nbytes.data(), &s.d_lens, &s.d_bytes);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    });
+    rc = first_failure(m, "partitioning the dictionary");
+    if (rc) return rc;
+    for (size_t q = 0; q < n; ++q) for (size_t r = 0; r < n; ++r) { cnt[q][r] = m->sh[q].counts[r]; nby[q][r] = m->sh[q].nbytes[r]; }
+    std::vector<uint64_t> rc_cnt(n, 0), rc_by(n, 0);      // what every owner receives
+    for (size_t r = 0; r < n; ++r) for (size_t q = 0; q < n; ++q) { rc_cnt[r] += cnt[q][r]; rc_by[r] += nby[q][r]; }
+    {
+        std::vector<const void *> src_l(n), src_b(n);
+        std::vector<void *> dst_l(n), dst_b(n);
+        for (size_t i = 0; i < n; ++i) {
+            Shard &s = m->sh[i];
+            rc = grow(m, s.device, &s.d_recv_lens, &s.cap_recv_lens, rc_cnt[i] * 4 + 16); if (rc) return rc;
+            rc = grow(m, s.device, &s.d_recv_bytes, &s.cap_recv_bytes, rc_by[i] + 32); if (rc) return rc;
+            src_l[i] = s.d_lens; src_b[i] = s.d_bytes; dst_l[i] = s.d_recv_lens; dst_b[i] = s.d_recv_bytes;
+        }
+        rc = all_to_all_v(m, src_l, dst_l, cnt, 4); if (rc) return rc;
+        rc = all_to_all_v(m, src_b, dst_b, nby, 1); if (rc) return rc;
+    }
+    for_shards(m, [&](size_t i) {
+        Shard &s = m->sh[i];
+        s.rc = zdw_owner_build(s.ctx, s.d_recv_lens, s.d_recv_bytes, rc_cnt[i], rc_by[i], &s.slice);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    });
+    rc = first_failure(m, "building a dictionary range");
+    if (rc) return rc;
+    uint64_t dict_size = 1;                     // offset 0 is the origin byte (dictionary.cpp:96)
+    std::vector<uint64_t> base(n);
+    for (size_t i = 0; i < n; ++i) { base[i] = dict_size; dict_size += m->sh[i].slice; }
+    if (dict_size >= (1ull << 32)) return mfail(m, ZDW_OUT_OF_MEMORY, "the block's dictionary exceeds 2^32 bytes: it has to be split (one-GPU path)");
+    for_shards(m, [&](size_t i) {
+        Shard &s = m->sh[i];
+        s.rc = zdw_owner_offsets(s.ctx, base[i], &s.d_offsets);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    });
+    rc = first_failure(m, "dictionary offsets");
+    if (rc) return rc;
+    {
+        // the offsets travel back: owner r -> requester q, cnt[q][r] of them, in the order q sent its strings (range by range)
+        std::vector<std::vector<uint64_t>> back(n, std::vector<uint64_t>(n));
+        for (size_t r = 0; r < n; ++r) for (size_t q = 0; q < n; ++q) back[r][q] = cnt[q][r];
+        std::vector<const void *> src(n);
+        std::vector<void *> dst(n);
+        for (size_t i = 0; i < n; ++i) {
+            Shard &s = m->sh[i];
+            uint64_t mine = 0;
+            for (size_t r = 0; r < n; ++r) mine += cnt[i][r];
+            rc = grow(m, s.device, &s.d_back, &s.cap_back, mine * 4 + 16); if (rc) return rc;
+            src[i] = s.d_offsets; dst[i] = s.d_back;
+        }
+        rc = all_to_all_v(m, src, dst, back, 4); if (rc) return rc;
+    }
+    for_shards(m, [&](size_t i) {
+        Shard &s = m->sh[i];
+        uint64_t mine = 0;
+        for (size_t r = 0; r < n; ++r) mine += cnt[i][r];
+        s.rc = zdw_shard_set_offsets(s.ctx, s.d_back, mine, dict_size, i == 0 ? 1 : 0);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    });
+    rc = first_failure(m, "dictionary offsets");
+    if (rc) return rc;
+
+    // ---- 3. the row halo and the block's line buffer, chained over the shards in row order ----
+    {
+        std::vector<uint64_t> cur(nc + 1, 0);
+        bool have = false;
+        uint32_t cap = 16384;
+        for (size_t i = 0; i < n; ++i) {
+            Shard &s = m->sh[i];
+            rc = zdw_shard_set_prev_row(s.ctx, have ? cur.data() : nullptr);
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+            if (s.p1.num_rows) {
+                rc = zdw_shard_last_row(s.ctx, cur.data());
+                if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+                have = true;
+            }
+            uint32_t caps[ZDW_LINE_CAPS];
+            rc = zdw_shard_line_caps(s.ctx, caps);
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+            uint32_t k = 0;
+            while ((16384u << k) < cap && k + 1 < ZDW_LINE_CAPS) ++k;
+            cap = caps[k];
+        }
+        m->longest_line = cap;
+    }
+
+    // ---- the shards' outputs ----
+    for_shards(m, [&](size_t i) {
+        Shard &s = m->sh[i];
+        s.rc = zdw_block_pass2_device(s.ctx, nullptr, nullptr);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    });
+    rc = first_failure(m, "pass 2");
+    if (rc) return rc;
+    uint64_t rows = 0;
+    for (size_t i = 0; i < n; ++i) rows += m->sh[i].p1.num_rows;
+    if (rows >= 0xFFFFFFFFull) return mfail(m, ZDW_UNKNOWN_ERROR, "more than 2^32-2 rows in one block");
+    blk->num_rows = (uint32_t)rows;
+    blk->longest_line = m->longest_line;
+    blk->is_last_block = 1;
+    blk->dict_bytes = dict_size;
+    m->encoded = true;
+    return ZDW_OK;
+}
+
+int zdw_multi_stats(zdw_multi *m, uint8_t *col_size, uint64_t *col_base, uint32_t *used)
+{
+    if (!m || !m->encoded) return m ? mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_encode has not run") : ZDW_UNKNOWN_ERROR;
+    const int rc = zdw_block_stats(m->sh[0].ctx, col_size, col_base, used);      // the same on every shard (merged ranges, one dictionary size)
+    if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[0].ctx));
+    return ZDW_OK;
+}
+
+int zdw_multi_dict_write(zdw_multi *m, zdw_write_fn write, void *user, uint64_t *section_len)
+{
+    if (!m || !m->encoded || !write) return m ? mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_encode has not run") : ZDW_UNKNOWN_ERROR;
+    uint64_t total = 0;
+    for (Shard &s : m->sh) {            // the pieces of ranks 0 .. N-1 concatenate to the reference's section
+        uint64_t len = 0;
+        (void)hipSetDevice(s.device);
+        const int rc = zdw_block_dict_write(s.ctx, write, user, &len, nullptr);
+        if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+        total += len;
+    }
+    if (section_len) *section_len = total;
+    return ZDW_OK;
+}
+
+int zdw_multi_rows_write(zdw_multi *m, zdw_write_fn write, void *user, uint64_t *rows_len)
+{
+    if (!m || !m->encoded || !write) return m ? mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_encode has not run") : ZDW_UNKNOWN_ERROR;
+    uint64_t total = 0;
+    for (Shard &s : m->sh) {
+        uint64_t len = 0;
+        (void)hipSetDevice(s.device);
+        const int rc = zdw_block_pass2_write(s.ctx, write, user, &len);
+        if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+        total += len;
+    }
+    if (rows_len) *rows_len = total;
+    return ZDW_OK;
+}
+
+}  // extern "C"

@@ -48,11 +48,15 @@ def column_pattern():
     return out
 
 
-def schema(ncols=200):
+ID_SQL = "varchar(64)"          # C5's high-cardinality id columns: 24-character practically unique tokens
+
+
+def schema(ncols=200, id_every=0):
+    """id_every = k > 0: every k-th column (k/2, k/2 + k, ...) is an id column -- C5 is schema(1000, id_every=20): 50 of them"""
     pat = column_pattern()
-    sql = [pat[i % 200] for i in range(ncols)]
+    sql = [ID_SQL if (id_every and i % id_every == id_every // 2) else pat[i % 200] for i in range(ncols)]
     desc = "".join("c%d\t%s\n" % (i, t) for i, t in enumerate(sql)).encode()
-    return desc, [_TYPE_ID[t] for t in sql], [_GEN[t] for t in sql]
+    return desc, [0 if t == ID_SQL else _TYPE_ID[t] for t in sql], [8 if t == ID_SQL else _GEN[t] for t in sql]
 
 
 def _mix(x):
@@ -147,7 +151,7 @@ def _synth_lib():
 class DeviceTable:
     """Generates rows [row0, row0 + nrows) of the synthetic table into a torch uint8 CUDA tensor."""
 
-    def __init__(self, ncols=200, seed=SEED, vocab=VOCAB, device="cuda", word_maxlen=24, p_empty=0.25, dead_cols=0.0):
+    def __init__(self, ncols=200, seed=SEED, vocab=VOCAB, device="cuda", word_maxlen=24, p_empty=0.25, dead_cols=0.0, id_every=0):
         """word_maxlen: longest vocabulary word (24 = the benchmark's table; up to 279 for tables with long strings);
         p_empty: fraction of empty fields (0.25 = the benchmark's table); dead_cols: fraction of columns that are empty in
         every row (0 = the benchmark's table; the reference's analytics-hits: 0.88)"""
@@ -158,7 +162,7 @@ class DeviceTable:
         assert vocab < (1 << 24) + 1 and 24 <= word_maxlen <= 279
         vocab = min(vocab, (1 << 24) - 1) | ((word_maxlen - 24) << 24)
         self.ncols, self.seed, self.vocab, self.device = ncols, seed, vocab, device
-        self.desc, self.types, self.gens = schema(ncols)
+        self.desc, self.types, self.gens = schema(ncols, id_every)
         self.d_gens = torch.tensor(self.gens, dtype=torch.uint8, device=device)
 
     def generate(self, row0, nrows):
