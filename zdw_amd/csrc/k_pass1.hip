@@ -46,10 +46,10 @@ constexpr uint32_t RING_HEAD = 16;                // copy of its last bytes in f
 constexpr uint32_t RING_STRIDE = RING_HEAD + BYTE_RING + RING_TAIL;
 constexpr uint32_t P1_WPB = 8;                    // independent waves per workgroup; they share the column tables
 constexpr uint32_t LUT_ROWS = 25;                 // byte masks "first L bytes" for L = 0..24, 32 bytes per row
-// Descriptor ring entries per wave (u32 each): 512 for ordinary tables (a 2 KiB round holds ~220 boundaries), 2048 for
-// tables of mostly empty fields (a round of such data holds 1000+); a round that does not fit is emitted in eight
-// 16-lane pieces (<= 256 boundaries each), the ring drained in between.
-constexpr uint32_t QCAP_SMALL = 512, QCAP_LARGE = 2048;
+// Descriptor ring entries per wave (u32 each): 512 for ordinary tables (a 2 KiB round holds ~220 boundaries); 1024 for
+// tables of mostly empty fields (a round of such data holds 1000+), whose boundaries are then emitted chunk by chunk
+// (~540 each).  What still does not fit is emitted in 16-lane pieces (<= 256 boundaries each), the ring drained in between.
+constexpr uint32_t QCAP_SMALL = 512, QCAP_LARGE = 1024;
 
 // ------------------------------------------------------------------------------------------
 // per-lane byte classes of 16 bytes
@@ -334,6 +334,7 @@ struct WaveState {
     uint32_t row_cur, col_cur;   // row / column of the field that ends at the head descriptor
     uint32_t ring_lo;            // smallest relative position the byte ring still holds
     uint32_t rel_se1;            // relative position of the span's last byte: the visit ends with the first line end at or past it
+    uint32_t last_e;             // relative position of the last boundary that counted before the head descriptor (its field starts behind it)
     bool first_pending;          // the head descriptor is the visit's sentinel: the line end before the first owned row
     bool ignoring;               // the visit began inside a row of the span before: everything up to that row's end is not ours
     bool prev_nl;                // the boundary before the head descriptor is a line end
@@ -355,7 +356,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     const bool live = lane < cnt;
     const uint32_t di = ws.q_head + lane;
     const uint32_t e_pos = lds_u32(ws.desc | ((di << 2) & QM));
-    uint32_t pe_pos = lds_u32(ws.desc | (((di - 1u) << 2) & QM));
+    // the boundary before mine: my left neighbour's, lane 0: the last one of the batch before (one DPP move, no second LDS read)
+    uint32_t pe_pos = (uint32_t)__builtin_amdgcn_update_dpp((int)ws.last_e, (int)e_pos, DPP_WAVE_SHR1, 0xf, 0xf, false);
+    const uint32_t e_last = lane_value(e_pos, (int)cnt - 1);
     // ---- what kind of boundary is mine?  The tokeniser only said "a tab or a newline": the byte itself and the one
     // ---- before it (a backslash?) come from the byte ring
     const uint32_t ea = ws.bytes + (e_pos & (BYTE_RING - 1u));
@@ -370,7 +373,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // longer holds, a visit that has not found its first row yet, the end of the span: all rare, all in one branch.
     const bool odd = live & !at_sentinel & ((bp == '\\') | (e_pos <= ws.ring_lo));
     const uint64_t oddm = __ballot(odd);
-    if ((oddm != 0) | ws.ignoring | (lane_value(e_pos, (int)cnt - 1) >= ws.rel_se1)) {
+    if ((oddm != 0) | ws.ignoring | (e_last >= ws.rel_se1)) {
         if (oddm) {
             // exact: the byte and the parity of the backslash run before it, from the image (Q1, Q4: special iff an even
             // number of backslashes precedes)
@@ -387,7 +390,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         // a visit that began inside a row of the span before: that row's end is the line end before our first row
         if (ws.ignoring) {
             const uint64_t nl0 = __ballot(e_nl);
-            if (!nl0) return 0;                                         // all of it foreign
+            if (!nl0) { ws.last_e = e_last; return 0; }                 // all of it foreign
             sent_lane = (uint32_t)lowest_bit(nl0);
             if (lane < sent_lane) { dead = true; e_nl = false; }
             ws.ignoring = false;
@@ -399,10 +402,25 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             ws.done = true;
         }
     }
-    const bool sentinel = lane == sent_lane;
     const uint64_t nlm = __ballot(e_nl);                               // line ends that count
     uint32_t fs = pe_pos + 1u;                                          // a field begins one byte after the boundary before it
-    uint32_t pnl = wave_shr1(e_nl ? 1u : 0u);                           // ... which is a line end?
+    uint32_t raw_len, len, row, col;
+    bool in_block, is_field;
+    if (nlm == 0 && vm == 0 && !ws.first_pending) {
+        // The common batch: 64 fields of one row, nothing out of the ordinary -- no line end, so no row ends, no blank line, no
+        // sentinel: the row is the wave's, the column counts on.  (Seven in ten batches of the benchmark's table, nineteen in
+        // twenty of a table of mostly empty fields.)
+        raw_len = len = e_pos - fs;
+        row = ws.row_cur;
+        col = ws.col_cur + lane;
+        in_block = row < a.row_limit;
+        is_field = !dead & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) & !(a.debug_skip & 1u);
+        ws.col_cur += cnt;
+        ws.prev_nl = false;
+        ws.last_e = e_last;
+    } else {
+    const bool sentinel = lane == sent_lane;
+    uint32_t pnl = wave_shr1(e_nl ? 1u : 0u);                           // the boundary before mine is a line end?
     if (lane == 0) pnl = ws.prev_nl ? 1u : 0u;
     uint64_t realm = 0;                                                 // (vm != 0 only) boundaries that count
     if (vm) {
@@ -417,25 +435,15 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 pnl = (uint32_t)(nlm >> p) & 1u;
             }
         } else if (!dead && lane > 0) {                                 // none in this batch: the one before the batch
-            pe_pos = lds_u32(ws.desc | (((ws.q_head - 1u) << 2) & QM));
+            pe_pos = ws.last_e;
             fs = pe_pos + 1u;
             pnl = ws.prev_nl ? 1u : 0u;
         }
-        // the next batch must find a boundary that counts in front of it
-        __builtin_amdgcn_wave_barrier();
-        const uint64_t mine = realm & mask_lt((int)cnt);
-        if (!((mine >> (cnt - 1u)) & 1ull)) {
-            const uint32_t slot = ws.desc | (((ws.q_head + cnt - 1u) << 2) & QM);
-            if (mine) { if (lane == (uint32_t)highest_bit(mine)) *reinterpret_cast<uint32_t *>(zdw_lds + slot) = e_pos; }
-            else if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + slot) = lds_u32(ws.desc | (((ws.q_head - 1u) << 2) & QM));
-        }
-        __builtin_amdgcn_wave_barrier();
     }
-    const uint32_t raw_len = e_pos - fs;
-    uint32_t len = raw_len;
+    raw_len = len = e_pos - fs;
     const bool blank = e_nl & (pnl != 0) & (len == 0) & !sentinel;    // line end right after a line end: no row (getnextrow.cpp:38-43)
     const bool ends_row = e_nl & !blank & !sentinel;
-    uint32_t row = ws.row_cur, col = ws.col_cur + lane;
+    row = ws.row_cur; col = ws.col_cur + lane;
     uint64_t rm = 0;
     if (nlm) {
         rm = __ballot(ends_row);
@@ -468,20 +476,29 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (row + 1 == a.row_limit) a.st->split_pos = ws.vbase + e_pos + 1;  // the next block starts after this row
         }
     }
-    const bool in_block = row < a.row_limit;
-    const bool is_field = !dead & !sentinel & !blank & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) &
-                          !(a.debug_skip & 1u);
+    in_block = row < a.row_limit;
+    is_field = !dead & !sentinel & !blank & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) &
+               !(a.debug_skip & 1u);
     // state for the next call
     ws.row_cur += popc64(rm);
     if (vm) {
         ws.col_cur = nlm ? popc64(realm & ~mask_le(highest_bit(nlm))) : ws.col_cur + popc64(realm);
-        if (realm) ws.prev_nl = ((nlm >> highest_bit(realm)) & 1ull) != 0;
+        if (realm) {                     // the next batch's first field begins behind the last boundary that counted
+            const int h = highest_bit(realm);
+            ws.prev_nl = ((nlm >> h) & 1ull) != 0;
+            ws.last_e = lane_value(e_pos, h);
+        }
     } else {
         ws.col_cur = nlm ? cnt - 1u - (uint32_t)highest_bit(nlm) : ws.col_cur + cnt;
         ws.prev_nl = ((nlm >> (cnt - 1u)) & 1ull) != 0;          // (lanes a foreign row or the end of the visit took out: nothing reads it then)
+        ws.last_e = e_last;
     }
     ws.first_pending = false;
+    }
 
+    // tables of mostly empty fields: the record matrix was zeroed beforehand (one streaming write instead of a scattered 4- or
+    // 8-byte store per empty field), so an empty field -- no record but zero, no range, no string (ConvertToZDW.cpp:340-341) -- is done
+    if (a.rec_zeroed) is_field = is_field & (raw_len != 0);
     uint32_t meta = 0;
     if (is_field && t.cols_in_lds) meta = lds_u32(t.meta + 4u * col);
     const uint32_t kind = meta & 3u;
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     ws.desc = L.desc + wv * QCAP * 4u;
     ws.bytes = L.bytes + wv * RING_STRIDE + RING_HEAD;
     ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.rel_se1 = 0; ws.first_pending = false; ws.vbase = 0;
-    ws.ignoring = false; ws.prev_nl = false; ws.done = false; ws.row_start = 0;
+    ws.ignoring = false; ws.prev_nl = false; ws.done = false; ws.row_start = 0; ws.last_e = 0;
     ws.ids.cur = ws.ids.end = 0;
     if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
@@ -709,6 +726,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         ws.ignoring = !at_row_start;         // the row open at ss began in an earlier span and belongs to it; its line end is our sentinel
         ws.prev_nl = false; ws.done = false;
         ws.row_start = ss;
+        ws.last_e = (uint32_t)(ss - 1 - ws.vbase);
         if (at_row_start) {
             // (every lane stores the same word: a branch on the lane number here would make q_count divergent for the compiler)
             *reinterpret_cast<uint32_t *>(zdw_lds + ws.desc) = (uint32_t)(ss - 1 - ws.vbase);
@@ -758,31 +776,40 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         //               has outgrown its relative positions moves its base here too
         //   step END    the image ended: whatever is pending
         enum : uint32_t { STEP_A = 0, STEP_B = 1, STEP_PIECE = 2, STEP_END = 3 };
-        uint32_t step = relb < rel_hi ? STEP_A : STEP_END, piece = 0;
+        uint32_t step = relb < rel_hi ? STEP_A : STEP_END, piece = 0, piece_stop = 8;
         uint32_t mA = 0, mB = 0, ex2 = 0, tot2 = 0;
         bool rebase = false, near_end = false;
         for (;;) {
             uint32_t keep = 0;                    // descriptors that may stay pending after this step
-            if (step == STEP_A) {
-                const uint32_t slot = relb & (BYTE_RING - 1u);                        // 0 or 2048 (the base is a multiple of the ring)
-                const uint4 v = P;
-                *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + slot + 16u * lane) = v;
-                if (slot == 0 && lane < RING_TAIL / 16u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + BYTE_RING + 16u * lane) = v;
-                P = load_chunk(lane_ptr + WROUND);
-                mA = boundaries16(v);
-                ws.ring_lo = relb + WROUND > BYTE_RING + first_rel ? relb + WROUND - BYTE_RING : first_rel;      // the ring holds [relb - 3072, relb + 1024)
-                keep = 63;
-                step = STEP_B;
-            } else if (step == STEP_B) {
-                const uint32_t slot = relb & (BYTE_RING - 1u);
+            if (step <= STEP_B) {
+                // a chunk: into the ring, the next one requested, its boundaries found.  (ONE place issues the load and ONE takes
+                // its result: two would meet in a phi, and hipcc resolves that with register copies right behind the load --
+                // a vmcnt(0) that waits for the chunk the moment it is requested)
+                const bool second = step == STEP_B;
+                const uint32_t at = (relb & (BYTE_RING - 1u)) + (second ? WROUND : 0u);     // 0, 1024, 2048 or 3072 (the base is a multiple of the ring)
+                uint32_t mN;
                 {
                     const uint4 v = P;
-                    *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + slot + WROUND + 16u * lane) = v;
-                    if (slot != 0 && lane == 63u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes - RING_HEAD) = v;      // the ring's last 16 bytes, in front of it
-                    P = load_chunk(lane_ptr + ROUND);
-                    mB = boundaries16(v);
+                    *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + at + 16u * lane) = v;
+                    if (at == 0 && lane < RING_TAIL / 16u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + BYTE_RING + 16u * lane) = v;
+                    if (at == BYTE_RING - WROUND && lane == 63u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes - RING_HEAD) = v;      // the ring's last 16 bytes, in front of it
+                    mN = boundaries16(v);
                 }
-                ws.ring_lo = relb > ROUND + first_rel ? relb - ROUND : first_rel;             // ... now [relb - 2048, relb + 2048)
+                // (the chunk's registers are dead here: the next one is loaded into the same ones.  Requested while its
+                // predecessor is still looked at it would land in other registers and be copied over at the loop's end,
+                // behind a wait for it)
+                uint32_t ahead = second ? ROUND : WROUND;
+                asm volatile("" : "+v"(mN), "+v"(ahead));      // (an empty statement both values pass through: the boundaries are found before the address of the load exists)
+                P = load_chunk(lane_ptr + ahead);
+                constexpr bool DENSE = QCAP == QCAP_LARGE;      // boundaries of a chunk are emitted right away (two prefix sums per round)
+                if (!second) ws.ring_lo = relb + WROUND > BYTE_RING + first_rel ? relb + WROUND - BYTE_RING : first_rel;      // the ring holds [relb - 3072, relb + 1024)
+                else ws.ring_lo = relb > ROUND + first_rel ? relb - ROUND : first_rel;                                         // ... now [relb - 2048, relb + 2048)
+                if (!second && !DENSE) {
+                    mA = mN;
+                    keep = 63;
+                    step = STEP_B;
+                } else {
+                if (second) { mB = mN; if (DENSE) mA = 0; } else { mA = mN; mB = 0; }
                 const uint32_t lrel = relb + 16u * lane;                                      // relative position of my first byte of chunk A
                 // positions that exist for this visit: [ss, hi)
                 if (relb < rel_ss || relb + ROUND > rel_hi) {
@@ -803,23 +830,26 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                     emit(mB, lrel + WROUND, tail + totA + (ex2 >> 16));
                     ws.q_count += nb_total;
                     keep = near_end ? 0u : 127u;
-                    relb += ROUND; lane_ptr += ROUND;
-                    step = relb < rel_hi ? STEP_A : STEP_END;
+                    if (second) {
+                        relb += ROUND; lane_ptr += ROUND;
+                        step = relb < rel_hi ? STEP_A : STEP_END;
+                    } else {
+                        step = STEP_B;
+                    }
                 } else {
                     rebase = relb >= a.rebase_at;                                             // relative positions must stay below 2^31
-                    piece = 0;
+                    piece = second ? (DENSE ? 4u : 0u) : 0u;                                  // (dense: the other chunk's mask is empty)
+                    piece_stop = second ? 8u : 4u;
                     step = STEP_PIECE;                                                        // (first: everything that is pending)
+                }
                 }
             } else if (step == STEP_PIECE) {
                 if (rebase) {
-                    // nothing is pending: move the visit base up; the head's predecessor moves with it
+                    // nothing is pending: move the visit base up; the boundary before the head moves with it
                     const uint32_t delta = (relb - 2u * BYTE_RING) & ~(BYTE_RING - 1u);
                     if (!ws.first_pending) {
-                        const uint32_t pa = ws.desc | (((ws.q_head - 1u) << 2) & QM);
-                        uint32_t pp = lds_u32(pa);
-                        if (pp < delta) { pp = delta; if (lane == 0) a.st->nul_seen = 2; }      // a single field of 1 GiB or more
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + pa) = pp - delta;
+                        if (ws.last_e < delta) { ws.last_e = delta; if (lane == 0) a.st->nul_seen = 2; }      // a single field of 1 GiB or more
+                        ws.last_e -= delta;
                     }
                     ws.vbase += delta; ws.ring_lo -= delta; relb -= delta;
                     first_rel = 0;
@@ -835,10 +865,14 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                 const uint32_t lrel = relb + 16u * lane;
                 emit(active ? (inB ? mB : mA) : 0u, inB ? lrel + WROUND : lrel, ws.q_head + ws.q_count + ex - piece_base);
                 ws.q_count += piece_end - piece_base;
-                if (++piece == 8u) {
+                if (++piece == piece_stop) {
                     keep = near_end ? 0u : 127u;
-                    relb += ROUND; lane_ptr += ROUND;
-                    step = relb < rel_hi ? STEP_A : STEP_END;
+                    if (piece_stop == 8u) {
+                        relb += ROUND; lane_ptr += ROUND;
+                        step = relb < rel_hi ? STEP_A : STEP_END;
+                    } else {
+                        step = STEP_B;                                                        // (dense: chunk A's pieces are out, on to chunk B)
+                    }
                 }
             }
             // ---- the one place descriptors are handled: 64 at a time while more than `keep` are pending ----

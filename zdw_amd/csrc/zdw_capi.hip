@@ -586,7 +586,9 @@ int start_pass2_size(zdw_ctx *c)
     if (rc) return rc;
     {
         StageScope ts(c, ZDW_STAGE_PASS2_SIZE, c->stream2);
-        a.background = 1;
+        // (a smaller grid beside the sort -- unless the record matrix is so large that the row lengths, not the sort, are the longer
+        // of the two: wide sparse tables)
+        a.background = (uint64_t)c->nrows * c->rec_stride <= (8ull << 30) ? 1u : 0u;
         launch_pass2_size(a, c->stream2);
         launch_scan_u32_to_u64(a.row_len, c->row_off.as<uint64_t>(), c->nrows, c->scan_tmp2.p, nullptr, c->stream2);
     }
@@ -978,6 +980,11 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             a.dense_boundaries = c->dense_boundaries ? 1u : 0u;
             if (const char *e = getenv("ZDW_P1_LARGE_RING")) a.dense_boundaries = atoi(e) != 0;      // tests
+            if (a.dense_boundaries && nrows) {
+                // mostly empty fields: zero the record matrix in one streaming write; pass 1 then skips every empty field
+                HIP_TRY(c, hipMemsetAsync(c->rec.p, 0, (uint64_t)nrows * c->rec_stride, s));
+                a.rec_zeroed = 1;
+            }
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
             // Fields that need the general form (long strings, signed / padded numbers, contended slots) are
             // queued by the main kernel (16 bytes each) and handled by a second one.  The queue starts at about 1 %

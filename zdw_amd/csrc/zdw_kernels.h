@@ -59,6 +59,7 @@ struct Pass1Args {
     uint32_t rebase_at;                   // relative position at which a visit moves its base (2^30; tests lower it)
     uint64_t *dq; uint32_t dq_cap;        // deferred fields (two words each: position | column << 40, length | row << 32); dq == nullptr: none, one kernel does everything
     uint32_t debug_skip;                  // profiling only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary
+    uint32_t rec_zeroed;                  // 1: rec was zeroed before the launch: empty fields leave nothing to do
     uint32_t dense_boundaries;            // 1: the input averages more boundaries per round than the small descriptor ring takes (tables of mostly empty fields): large ring
 };
 

@@ -17,7 +17,8 @@
 #include "../../include/zdw_hip.h"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is loaded on first use (below)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -30,6 +31,43 @@
 #include <vector>
 
 namespace {
+
+// RCCL is taken from the process when it is already there (a host application -- PyTorch, say -- brings its own copy, and two
+// copies of it in one process end in a double free at exit), else loaded from the ROCm installation; a context that never
+// talks to a second device never loads it.
+struct Rccl {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    bool ok = false;
+};
+const Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return x;
+        x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(h, "ncclAllReduce"));
+        x.Send = reinterpret_cast<decltype(x.Send)>(dlsym(h, "ncclSend"));
+        x.Recv = reinterpret_cast<decltype(x.Recv)>(dlsym(h, "ncclRecv"));
+        x.ok = x.CommInitAll && x.CommDestroy && x.GetErrorString && x.GroupStart && x.GroupEnd && x.AllReduce && x.Send && x.Recv;
+        return x;
+    }();
+    return r;
+}
 
 struct Shard {
     zdw_ctx *ctx = nullptr;
@@ -87,7 +125,7 @@ int mfail(zdw_multi *m, int code, const char *fmt, ...)
 #define M_NCCL(m, call)                                                                                                  \
     do {                                                                                                                 \
         ncclResult_t r_ = (call);                                                                                        \
-        if (r_ != ncclSuccess) return mfail((m), ZDW_UNKNOWN_ERROR, "%s: %s", #call, ncclGetErrorString(r_));            \
+        if (r_ != ncclSuccess) return mfail((m), ZDW_UNKNOWN_ERROR, "%s: %s", #call, rccl().GetErrorString(r_));        \
     } while (0)
 
 int grow(zdw_multi *m, int device, void **p, size_t *cap, size_t bytes)
@@ -135,7 +173,7 @@ int all_to_all_v(zdw_multi *m, const std::vector<const void *> &src, const std::
 {
     const size_t n = m->sh.size();
     std::vector<uint64_t> recv_at(n, 0);
-    if (m->use_rccl) M_NCCL(m, ncclGroupStart());
+    if (m->use_rccl) M_NCCL(m, rccl().GroupStart());
     for (size_t q = 0; q < n; ++q) {
         uint64_t send_at = 0;
         for (size_t r = 0; r < n; ++r) {
@@ -148,8 +186,8 @@ int all_to_all_v(zdw_multi *m, const std::vector<const void *> &src, const std::
                 for (size_t p = 0; p < q; ++p) land += cnt[p][r];
                 to += land * esize;
                 if (m->use_rccl) {
-                    M_NCCL(m, ncclSend(from, c * esize, ncclUint8, (int)r, m->sh[q].comm, m->sh[q].stream));
-                    M_NCCL(m, ncclRecv(to, c * esize, ncclUint8, (int)q, m->sh[r].comm, m->sh[r].stream));
+                    M_NCCL(m, rccl().Send(from, c * esize, ncclUint8, (int)r, m->sh[q].comm, m->sh[q].stream));
+                    M_NCCL(m, rccl().Recv(to, c * esize, ncclUint8, (int)q, m->sh[r].comm, m->sh[r].stream));
                 } else {
                     M_HIP(m, hipMemcpyPeerAsync(to, m->sh[r].device, from, m->sh[q].device, c * esize, m->sh[r].stream));
                 }
@@ -157,7 +195,7 @@ int all_to_all_v(zdw_multi *m, const std::vector<const void *> &src, const std::
             send_at += c;
         }
     }
-    if (m->use_rccl) M_NCCL(m, ncclGroupEnd());
+    if (m->use_rccl) M_NCCL(m, rccl().GroupEnd());
     for (size_t r = 0; r < n; ++r) { M_HIP(m, hipSetDevice(m->sh[r].device)); M_HIP(m, hipStreamSynchronize(m->sh[r].stream)); }
     (void)recv_at;
     return ZDW_OK;
@@ -176,7 +214,7 @@ void zdw_multi_destroy(zdw_multi *m)
         (void)hipSetDevice(s.device);
         if (s.ctx) zdw_ctx_destroy(s.ctx);
         for (void *p : {s.d_ranges, s.d_recv_lens, s.d_recv_bytes, s.d_recv_offs, s.d_back}) if (p) (void)hipFree(p);
-        if (s.comm) (void)ncclCommDestroy(s.comm);
+        if (s.comm) (void)rccl().CommDestroy(s.comm);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     delete m;
@@ -211,10 +249,11 @@ int zdw_multi_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *o
         }
     }
     if (m->use_rccl) {
+        if (!rccl().ok) { const int r2 = mfail(nullptr, ZDW_UNKNOWN_ERROR, "RCCL (librccl.so.1) is not available: %s", dlerror() ? dlerror() : "symbols missing"); zdw_multi_destroy(m); return r2; }
         std::vector<ncclComm_t> comms(ndev);
         std::vector<int> devs(devices, devices + ndev);
-        const ncclResult_t r = ncclCommInitAll(comms.data(), (int)ndev, devs.data());
-        if (r != ncclSuccess) { const int r2 = mfail(nullptr, ZDW_UNKNOWN_ERROR, "ncclCommInitAll: %s", ncclGetErrorString(r)); zdw_multi_destroy(m); return r2; }
+        const ncclResult_t r = rccl().CommInitAll(comms.data(), (int)ndev, devs.data());
+        if (r != ncclSuccess) { const int r2 = mfail(nullptr, ZDW_UNKNOWN_ERROR, "ncclCommInitAll: %s", rccl().GetErrorString(r)); zdw_multi_destroy(m); return r2; }
         for (uint32_t i = 0; i < ndev; ++i) m->sh[i].comm = comms[i];
     }
     *out = m;
@@ -293,9 +332,9 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
                 M_HIP(m, hipMemcpyAsync(s.d_ranges, host[i].data(), cnt * 8, hipMemcpyHostToDevice, s.stream));
             }
             if (m->use_rccl) {
-                M_NCCL(m, ncclGroupStart());
-                for (size_t i = 0; i < n; ++i) M_NCCL(m, ncclAllReduce(m->sh[i].d_ranges, m->sh[i].d_ranges, cnt, ncclUint64, ncclMax, m->sh[i].comm, m->sh[i].stream));
-                M_NCCL(m, ncclGroupEnd());
+                M_NCCL(m, rccl().GroupStart());
+                for (size_t i = 0; i < n; ++i) M_NCCL(m, rccl().AllReduce(m->sh[i].d_ranges, m->sh[i].d_ranges, cnt, ncclUint64, ncclMax, m->sh[i].comm, m->sh[i].stream));
+                M_NCCL(m, rccl().GroupEnd());
                 for (size_t i = 0; i < n; ++i) {
                     M_HIP(m, hipSetDevice(m->sh[i].device));
                     M_HIP(m, hipMemcpyAsync(host[i].data(), m->sh[i].d_ranges, cnt * 8, hipMemcpyDeviceToHost, m->sh[i].stream));
