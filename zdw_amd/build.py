@@ -10,13 +10,14 @@ LIB_CLI = os.path.join(LIBDIR, "libzdw_cli.so")
 CLI_EXE = os.path.join(LIBDIR, "convertDWfile")
 LIB_SYNTH = os.path.join(LIBDIR, "libzdw_synth.so")
 DECODER_EXE = os.path.join(LIBDIR, "unconvertDWfile")
+TRIM_EXE = os.path.join(LIBDIR, "trim_spaces")
 
 
 def build(jobs=4, quiet=True):
     """(Re)build libzdw_hip.so, libzdw_cli.so and convertDWfile.  make decides what is stale."""
     cmd = ["make", "-C", CSRC, "-j%d" % jobs, "all"]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL if quiet else None)
-    for p in (LIB_HIP, LIB_CLI, CLI_EXE, LIB_SYNTH, DECODER_EXE):
+    for p in (LIB_HIP, LIB_CLI, CLI_EXE, LIB_SYNTH, DECODER_EXE, TRIM_EXE):
         if not os.path.exists(p):
             raise RuntimeError("native build did not produce " + p)
     return LIB_HIP
