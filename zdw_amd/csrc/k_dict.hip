@@ -601,6 +601,65 @@ void launch_locate_field(const uint8_t *in, uint64_t lo, uint64_t p, uint64_t *o
     hipLaunchKernelGGL(k_locate_field, dim3(1), dim3(64), 0, s, in, lo, p, out);
 }
 
+// ---- a block cut back to the row and field where the model ends it (zdw_capi.hip: trim_block) ----
+// Pass 1 ran over more rows than the block keeps.  What the block's rows -- [0, rows) and the first `partial` fields of row `rows`
+// -- leave behind is rebuilt from their records: the strings they refer to (every other unique id becomes a hole), the columns they
+// fill, the ranges of their numbers.  A record holds what pass 2 writes; the range takes a char(1) field's first byte alone unless
+// that byte is a backslash (zdw_field_dev.h, ConvertToZDW.cpp:358-361 against :543-547).
+__global__ __launch_bounds__(256) void k_trim_scan(const uint8_t *__restrict__ rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *__restrict__ col_kind,
+                                                   const uint32_t *__restrict__ col_recoff, uint32_t rows, uint32_t partial, uint8_t *__restrict__ live,
+                                                   uint64_t *__restrict__ col_min, uint64_t *__restrict__ col_max, uint8_t *__restrict__ col_seen)
+{
+    constexpr uint32_t TILE = 32;
+    const uint64_t r0 = (uint64_t)blockIdx.x * TILE;
+    const uint64_t last = (uint64_t)rows + (partial ? 1u : 0u);
+    const uint64_t r1 = r0 + TILE < last ? r0 + TILE : last;
+    for (uint32_t col = threadIdx.x; col < ncols; col += 256) {
+        const uint32_t kind = col_kind[col], off = col_recoff[col];
+        const uint64_t stop = (r1 > rows && col >= partial) ? rows : r1;       // the partial row: its first fields only
+        uint64_t mn = ~0ull, mx = 0;
+        bool seen = false;
+        for (uint64_t r = r0; r < stop; ++r) {
+            const uint8_t *p = rec + r * rec_stride + off;
+            if (kind == K_TEXT) {
+                const uint32_t id1 = *reinterpret_cast<const uint32_t *>(p);
+                if (id1) { live[id1 - 1u] = 1; seen = true; }
+            } else {
+                uint64_t v = *reinterpret_cast<const uint64_t *>(p);
+                if (kind == K_CHAR && (v & 0xffu) != (uint64_t)'\\') v = (uint64_t)(int64_t)(int8_t)(v & 0xffu);
+                if (v) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+            }
+        }
+        if (kind == K_TEXT) {
+            if (seen && !col_seen[col]) col_seen[col] = 1;
+        } else if (mx) {
+            if (mn < col_min[col]) atomicMin(reinterpret_cast<unsigned long long *>(&col_min[col]), (unsigned long long)mn);
+            if (mx > col_max[col]) atomicMax(reinterpret_cast<unsigned long long *>(&col_max[col]), (unsigned long long)mx);
+        }
+    }
+}
+// unique ids no kept row refers to become holes; *entries = the strings that stay
+__global__ __launch_bounds__(256) void k_trim_ids(const uint8_t *__restrict__ live, uint32_t *__restrict__ uniq_len, uint32_t n, uint32_t *__restrict__ entries)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (i < n && uniq_len[i]) {
+        keep = live[i] != 0;
+        if (!keep) uniq_len[i] = 0;
+    }
+    const uint32_t k = popc64(__ballot(keep));
+    if (k && lane_id() == 0) atomicAdd(entries, k);
+}
+void launch_trim_block(const uint8_t *rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff, uint32_t rows,
+                       uint32_t partial, uint8_t *live, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids,
+                       uint32_t *entries, hipStream_t s)
+{
+    const uint64_t last = (uint64_t)rows + (partial ? 1u : 0u);
+    if (last) hipLaunchKernelGGL(k_trim_scan, dim3((uint32_t)((last + 31) / 32)), dim3(256), 0, s, rec, rec_stride, ncols, col_kind, col_recoff, rows, partial,
+                                 live, col_min, col_max, col_seen);
+    if (nids) hipLaunchKernelGGL(k_trim_ids, dim3((nids + 255) / 256), dim3(256), 0, s, live, uniq_len, nids, entries);
+}
+
 // Persistent waves: a wave keeps its chunk of unique ids across the groups of 64 strings it handles (one
 // returning atomic on the id counter per wave and group would bound the kernel: ~30 M/s on one word).
 __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *__restrict__ lens,

@@ -6,6 +6,7 @@
 #include "zdw_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,9 @@ thread_local std::string g_create_error;
 // callers that share a GPU make the encoder end its blocks early instead of failing.
 struct Budget { size_t used = 0, cap = 0; };
 
+static double g_alloc_ms = 0.0;      // time inside hipMalloc / hipFree (ZDW_DEBUG_RETRY prints it)
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -38,14 +42,18 @@ struct DevBuf {
         if (want >= (1u << 20)) want += want / 32;
         if (p) { want += want / 8; release(); }
         if (bud && bud->cap && bud->used + want > bud->cap) return hipErrorOutOfMemory;
+        const double t0 = now_ms();
         hipError_t e = hipMalloc(&p, want);
+        g_alloc_ms += now_ms() - t0;
         if (e == hipSuccess) { cap = want; if (bud) bud->used += want; }
         else { p = nullptr; (void)hipGetLastError(); }      // handled here: do not leave the error behind for a later hipGetLastError()
         return e;
     }
     void release()
     {
+        const double t0 = now_ms();
         if (p) { (void)hipFree(p); if (bud) bud->used -= cap; }
+        g_alloc_ms += now_ms() - t0;
         p = nullptr; cap = 0;
     }
     template <typename T> T *as() const { return static_cast<T *>(p); }
@@ -97,6 +105,8 @@ struct zdw_ctx {
     double mem_limit_mb = 0.0;             // the reference's --mem-limit as a model of where its blocks end (0 = off)
     uint64_t model_max_slots = 0;          // while the model drives pass 1: the dictionary table never grows beyond this
     uint32_t model_rows_prev = 0;          // rows of the previous block the model ended (the next block's first window)
+    uint32_t model_rows_prev2 = 0;         // ... and of the one before it
+    double model_vsize_end = 0.0;          // the model's upper bound of the process size at the end of the rows pass 1 last saw (MB)
     uint32_t partial_taken = 0;            // leading fields of the row after the current block that its pass 1 visited (zdw_block_partial_fields)
     uint64_t pass1_launches = 0;           // pass-1 kernel launches of this context (zdw_ctx_pass1_launches)
     uint32_t last_span_shift = 14;         // geometry of the last pass 1 (model_trip)
@@ -107,6 +117,7 @@ struct zdw_ctx {
     bool long_tail = false;
     uint64_t slots_opt = 0, slots_learned = 0, max_dict_bytes = 0;
     uint32_t rows_learned = 0;             // rows of the block slots_learned was enough for
+    double entries_per_row = 0.0;          // dictionary entries per row of the last pass 1 that completed
     // input image
     const uint8_t *d_in = nullptr;
     uint64_t n = 0;
@@ -287,7 +298,8 @@ int after_input(zdw_ctx *c)
     reset_block(c);
     c->lo = c->next_lo = 0;
     c->row_cap = c->first_row_cap;          // a new input starts with a fresh line buffer (ConvertToZDW.cpp:965)
-    c->model_rows_prev = 0;
+    c->model_rows_prev = c->model_rows_prev2 = 0;
+    c->entries_per_row = 0.0;
     c->row_cap_block_lo = ~0ull;
     c->hi = 0;
     c->avg_row = 0;
@@ -434,7 +446,7 @@ int ensure_dict(zdw_ctx *c)
 constexpr double MODEL_BASE_MB = 2.6, MODEL_NODE_BYTES = 64.0;
 constexpr uint64_t MODEL_ARENA = 64ull << 20;
 
-int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uint32_t *row, uint32_t *fields)
+int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uint32_t *row, uint32_t *fields, uint64_t *row_start)
 {
     *found = false;
     hipStream_t s = c->stream;
@@ -455,7 +467,8 @@ int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uin
     HIP_TRY(c, hipStreamSynchronize(s));
     const uint64_t max_len = std::max<uint64_t>(st.max_len, 24) + 1;
     const double arenas_ub = (double)(total / (MODEL_ARENA > 2 * max_len ? MODEL_ARENA - max_len : MODEL_ARENA / 2) + 1);
-    if (MODEL_BASE_MB + 64.0 * arenas_ub + MODEL_NODE_BYTES * (double)nreal / 1048576.0 < c->mem_limit_mb) return ZDW_OK;
+    c->model_vsize_end = MODEL_BASE_MB + 64.0 * arenas_ub + MODEL_NODE_BYTES * (double)nreal / 1048576.0;
+    if (c->model_vsize_end < c->mem_limit_mb) return ZDW_OK;
     // exact: unique ids by position, prefix sums of len + 1 in that order, the walk over the arenas
     SortBuffers b{};
     int rc = sort_buffers(c, u, b);
@@ -493,6 +506,58 @@ int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uin
     *found = true;
     *row = rowbase + in_span;
     *fields = (uint32_t)loc[1] + 1;
+    *row_start = rs;
+    return ZDW_OK;
+}
+
+// The block that pass 1 has just parsed ends earlier, at field `fields` of row `row` (which starts at input position row_start and
+// has a record: row < the rows pass 1 kept).  Instead of a second pass 1 up to there, what the rows beyond that point added is
+// taken back (k_trim_scan: launch_trim_block): strings only they hold become holes among the unique ids, ranges and used columns
+// are rebuilt from the records that stay, the line buffer is replayed up to the new end.
+int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res)
+{
+    hipStream_t s = c->stream;
+    P1Status st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint32_t u = st.id_next;
+    HIP_TRY(c, c->lenp1.ensure((uint64_t)u + 64));                   // a byte per unique id: some kept row refers to it
+    HIP_TRY(c, hipMemsetAsync(c->lenp1.p, 0, (uint64_t)u + 64, s));
+    HIP_TRY(c, hipMemsetAsync(c->col_min.p, 0xFF, c->ncols * 8 + 8, s));
+    HIP_TRY(c, hipMemsetAsync(c->col_max.p, 0, c->ncols * 8 + 8, s));
+    HIP_TRY(c, hipMemsetAsync(c->col_seen.p, 0, c->ncols + 8, s));
+    uint32_t *d_entries = &c->status.as<P1Status>()->entries;
+    HIP_TRY(c, hipMemsetAsync(d_entries, 0, 4, s));
+    {
+        StageScope ts(c, ZDW_STAGE_PASS1);
+        launch_trim_block(c->rec.as<uint8_t>(), c->rec_stride, c->ncols, c->d_kind.as<uint8_t>(), c->d_recoff.as<uint32_t>(), row, fields,
+                          c->lenp1.as<uint8_t>(), c->col_min.as<uint64_t>(), c->col_max.as<uint64_t>(), c->col_seen.as<uint8_t>(),
+                          c->uniq_len.as<uint32_t>(), u, d_entries, s);
+    }
+    HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "block trim launch: %s", hipGetErrorString(le));
+    c->nrows = row;
+    c->is_last = false;
+    c->partial_taken = fields;
+    c->next_lo = row_start;
+    c->row_cap = c->row_cap_block;                                    // the line buffer: again from the block's start, up to the new end
+    c->long_read_end = row_start;
+    c->long_tail = false;
+    int rc = replay_long_rows(c, &c->row_cap);
+    if (rc) return rc;
+    res->num_rows = row;
+    res->is_last_block = 0;
+    res->longest_line = c->row_cap;
+    res->bytes_consumed = row_start;
+    res->dict_entries = st.entries;
+    if (c->ncols) {
+        HIP_TRY(c, hipMemcpy(c->h_min.data(), c->col_min.p, c->ncols * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_max.data(), c->col_max.p, c->ncols * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_seen.data(), c->col_seen.p, c->ncols, hipMemcpyDeviceToHost));
+    }
+    if (row == 0) return fail(c, ZDW_OUT_OF_MEMORY, "block limit leaves no room for a single row");
     return ZDW_OK;
 }
 
@@ -788,11 +853,22 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
 {
     if (!c || !res) return ZDW_UNKNOWN_ERROR;
     if (c->mem_limit_mb <= 0.0 || (hint && hint->max_rows != 0xFFFFFFFFu)) return pass1_impl(c, hint, res);      // (a caller's split overrides the model)
-    // The reference's block limit as a model (model_trip).  The block is parsed once over a window of rows -- everything that
-    // is left for a file's first block, one and a half times the block before after that -- and, when the limit trips
-    // inside the window, once more up to exactly that row and field: two pass-1 launches per block that the model ends, one
+    // The reference's block limit as a model (model_trip).  The block is parsed once over a window of rows and, when the limit
+    // trips inside the window, once more up to exactly that row and field: two pass-1 launches per block that the model ends, one
     // for a last block, and the rows beyond a block are parsed by at most the window's excess.
-    uint64_t window = c->model_rows_prev ? (uint64_t)c->model_rows_prev + c->model_rows_prev / 2 + 1000 : 0xFFFFFFFFull;
+    // The window, in rows.  After a block the model ended: the rows of that block plus a half -- plus a tenth when the two blocks
+    // before were of one size (tables of id-like columns end their blocks every N rows).  For an input's first block: the rows
+    // that four times the limit's bytes of input hold (C5: a row's id fields cost 0.44 bytes of the modelled process per input
+    // byte); when the limit does not trip inside a window, the next one is sized from the process size the model saw at its end.
+    uint64_t window;
+    if (c->model_rows_prev) {
+        const uint64_t a = c->model_rows_prev, b = c->model_rows_prev2;
+        const bool steady = b && (a > b ? a - b : b - a) <= a / 32;
+        window = a + (steady ? a / 10 : a / 2) + 1000;
+    } else {
+        const double bytes = 4.0 * c->mem_limit_mb * 1048576.0;
+        window = (uint64_t)(bytes / (double)(c->avg_row ? c->avg_row : 1)) + 1000;
+    }
     {   // The limit is only looked at when an arena is taken: a block holds at most the strings that bring the process to the limit
         // ((limit - first arena) / 64 B) plus one more arena of them (64 MiB of strings of a few bytes each: 2^24 as a bound for
         // tables, not for adversaries -- beyond it the block ends where the table is full).  The table never needs more than twice that.
@@ -808,15 +884,25 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         if (rc) return rc;
         bool found = false;
         uint32_t row = 0, fields = 0;
-        rc = model_trip(c, c->last_span_shift, c->last_span0, &found, &row, &fields);
+        uint64_t row_start = 0;
+        c->model_vsize_end = 0.0;
+        rc = model_trip(c, c->last_span_shift, c->last_span0, &found, &row, &fields, &row_start);
         if (rc) return rc;
         if (found && row <= res->num_rows) {
-            zdw_split_hint e = {row, fields};
+            c->model_rows_prev2 = c->model_rows_prev;
             c->model_rows_prev = row;
+            // the rows beyond the end are taken back out of what pass 1 left (trim_block); ZDW_MODEL_RERUN=1 (tests) or an end
+            // on the window's last row, which has no record: a second pass 1 up to exactly there instead
+            if (row < res->num_rows && !getenv("ZDW_MODEL_RERUN")) return trim_block(c, row, fields, row_start, res);
+            zdw_split_hint e = {row, fields};
             return pass1_impl(c, &e, res);
         }
         if (res->is_last_block || res->num_rows < w.max_rows) return ZDW_OK;      // all of the input, or a block that device memory ended
-        window = window * 2;                                                       // the block is longer than the window: again, wider
+        // the block is longer than the window: again, as wide as the growth seen so far says (with a quarter to spare), at least twice
+        double grow = 2.0;
+        if (c->model_vsize_end > MODEL_BASE_MB + 64.0)
+            grow = std::max(2.0, 1.25 * (c->mem_limit_mb - MODEL_BASE_MB) / (c->model_vsize_end - MODEL_BASE_MB));
+        window = (uint64_t)std::min(4.0e9, (double)window * std::min(grow, 64.0)) + 1000;
     }
 }
 
@@ -915,6 +1001,10 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             const uint64_t bytes = total_rows ? (uint64_t)((double)(hi > lo ? hi - lo : 0) * rows_in_block / (double)total_rows) : 0;
             while (ns < bytes / 32 && ns < (1ull << 25)) ns <<= 1;
             if (c->slots_learned > ns && rows_in_block >= c->rows_learned) ns = c->slots_learned;
+            // what the rows of this input have held so far, per row (load limit 5/8, 15 % to spare)
+            const double est = (double)rows_in_block * c->entries_per_row * 1.6 * 1.15;
+            while ((double)ns < est && ns < (1ull << 31)) ns <<= 1;
+            if (c->model_max_slots && ns > c->model_max_slots) ns = c->model_max_slots;
         }
         uint64_t p2 = 1;
         while (p2 < ns) p2 <<= 1;
@@ -1042,11 +1132,13 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
         if (c->model_max_slots && nslots > c->model_max_slots) nslots = c->model_max_slots;
         if (attempt > 12) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
     }
+    if (getenv("ZDW_DEBUG_RETRY")) { fprintf(stderr, "[pass1] %u rows, table %llu slots, %u entries; hipMalloc/hipFree so far %.1f ms\n", nrows, (unsigned long long)nslots, st.entries, g_alloc_ms); }
     c->nrows = nrows;
     c->is_last = !tripped;
     c->partial_taken = tripped ? partial : 0;
     res->table_slots = nslots;
     c->slots_learned = nslots; c->rows_learned = nrows;
+    if (nrows) c->entries_per_row = (double)st.entries / (double)nrows;      // (rows beyond a split add theirs: an upper bound)
     res->dict_entries = st.entries;
 
     if (st.bad_row != 0xFFFFFFFFu && st.bad_row <= row_limit) {          // ConvertToZDW.cpp:810-812
