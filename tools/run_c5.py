@@ -83,15 +83,19 @@ def main():
         rc, p1 = enc.pass1()
         if rc:
             raise capi.ZdwError(rc, "pass1")
+        t_1 = time.perf_counter()
         dptr, dlen, _ = enc.dict_section_device()
+        t_2 = time.perf_counter()
         col_size, col_base = enc.stats()
         rptr, rlen = enc.pass2_device()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t_b) * 1e3
+        t_3 = time.perf_counter()
+        ms = (t_3 - t_b) * 1e3
+        calls_ms = {"pass1": round((t_1 - t_b) * 1e3, 1), "dict": round((t_2 - t_1) * 1e3, 1), "stats_pass2": round((t_3 - t_2) * 1e3, 1)}
         launches = enc.pass1_launches()
         b = {"rows": int(p1.num_rows), "dict_entries": int(p1.dict_entries), "dict_bytes": int(dlen), "row_bytes": int(rlen), "done": int(p1.is_last_block),
              "longest_line": int(p1.longest_line), "pass1_launches": launches - launches_before, "partial_fields": 0 if p1.is_last_block else enc.partial_fields(),
-             "ms": round(ms, 3)}
+             "ms": round(ms, 3), "calls_ms": calls_ms}
         launches_before = launches
         # ---- checks of this block's outputs (outside the clock of the next block: the clock restarts at t_b) ----
         sec = sharded._wrap(dptr, dlen, "|u1", "cuda:0")

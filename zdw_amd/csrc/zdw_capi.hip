@@ -878,16 +878,20 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         c->model_max_slots = ms;
     }
     struct Unset { zdw_ctx *c; ~Unset() { c->model_max_slots = 0; } } unset{c};
+    const bool dbg = getenv("ZDW_DEBUG_RETRY") != nullptr;
     for (;;) {
         zdw_split_hint w = {window >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)window, 0};
+        const double t0 = now_ms();
         int rc = pass1_impl(c, w.max_rows == 0xFFFFFFFFu ? nullptr : &w, res);
         if (rc) return rc;
+        const double t1 = now_ms();
         bool found = false;
         uint32_t row = 0, fields = 0;
         uint64_t row_start = 0;
         c->model_vsize_end = 0.0;
         rc = model_trip(c, c->last_span_shift, c->last_span0, &found, &row, &fields, &row_start);
         if (rc) return rc;
+        if (dbg) fprintf(stderr, "[model] window %llu rows: pass 1 %.1f ms, model %.1f ms (alloc so far %.1f)\n", (unsigned long long)window, t1 - t0, now_ms() - t1, g_alloc_ms);
         if (found && row <= res->num_rows) {
             c->model_rows_prev2 = c->model_rows_prev;
             c->model_rows_prev = row;
@@ -921,7 +925,8 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             if (b != &c->in_owned && b != &c->d_kind && b != &c->d_recoff && b != &c->d_numidx) b->release();
         c->oom_seen = false;
     }
-    const uint64_t lo = c->lo, hi = c->hi;
+    const uint64_t lo = c->lo;
+    uint64_t hi = c->hi;
     // a block that is run again (smaller split hint after an oversized dictionary) starts from the line buffer the block
     // began with: rows that move to the next block must not have grown it
     if (c->row_cap_block_lo == lo) c->row_cap = c->row_cap_block;
@@ -937,6 +942,15 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     uint64_t total_rows = 0;
     uint32_t nspans = 0, span_shift = SPAN_SHIFT_MIN;
     uint64_t span0 = 0;
+    // A caller that wants max_rows rows does not need the rows of everything that is left counted (a file of many blocks: the
+    // sum over its blocks of what is left): the image is looked at as far as those rows should reach, by the bytes per row seen so
+    // far and a quarter more, and twice as far again while that turns out too short.
+    const bool windowed = hint && hint->max_rows != 0xFFFFFFFFu && c->avg_row;
+    if (windowed) {
+        const double reach = (double)hint->max_rows * (double)c->avg_row * 1.25 + 1048576.0;
+        if (reach < (double)(c->hi - lo)) hi = lo + (uint64_t)reach;
+    }
+    for (;;) {
     if (hi > lo) {
         StageScope ts(c, ZDW_STAGE_SCAN_ROWS);
         // span size by block size: visits cost a few microseconds of start-up latency each, so large blocks take
@@ -968,6 +982,9 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
         HIP_TRY(c, hipMemcpyAsync(&st0, c->status.p, sizeof st0, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         if (st0.nul_seen) return fail(c, ZDW_UNKNOWN_ERROR, "input contains a NUL byte: not representable in ZDW (C strings)");
+    }
+    if (hi < c->hi && total_rows <= hint->max_rows) { hi = (c->hi - lo) / 2 < hi - lo ? c->hi : lo + 2 * (hi - lo); continue; }
+    break;
     }
     if (total_rows >= 0xFFFFFFFFull) return fail(c, ZDW_UNKNOWN_ERROR, "more than 2^32-2 rows in one block");
 
