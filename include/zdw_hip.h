@@ -126,6 +126,22 @@ int zdw_ctx_stage_times(const zdw_ctx *ctx, zdw_stage_times *out);
 int zdw_set_input_host(zdw_ctx *ctx, const uint8_t *tsv, uint64_t len);
 int zdw_set_input_device(zdw_ctx *ctx, const void *d_tsv, uint64_t len);
 
+/* The input as a stream (the reference reads its FILE* row by row, and with -i tees stdin into a temporary file that it rewinds for
+ * pass 2: ConvertToZDW.cpp:786-803,854-868, convertDWfile.cpp:144): `read` is called from a thread of the library, in order, with a
+ * buffer of host memory to fill; it returns the bytes it delivered (fewer than cap only at the end of the input), 0 at the end and a
+ * negative number on failure (reported as 20 by the next zdw_block_pass1).  The bytes travel to the device in pieces while earlier
+ * blocks are encoded; no host copy of the input is kept (the device image is: pass 2 and the dictionary read it again).
+ * zdw_block_pass1 waits until the rows its block needs have arrived -- all of the input for a block without a limit, its row
+ * window for a block under zdw_opts.mem_limit_mb or a split hint.  size_hint = the input's length when it is known (a file), else 0
+ * (the device image then grows by doubling).  The call returns at once.  zdw_ctx_destroy, or setting another input, waits for a
+ * `read` in progress to return and makes no further call. */
+typedef int64_t (*zdw_read_fn)(void *user, uint8_t *buf, uint64_t cap);
+int zdw_set_input_stream(zdw_ctx *ctx, zdw_read_fn read, void *user, uint64_t size_hint);
+/* The same for an input that already lies in host memory (a mapped file): the library's thread copies it to the device from where
+ * it lies, piece by piece, while earlier blocks are encoded; the call returns at once and `tsv` must stay valid until the context
+ * is destroyed or given another input.  (zdw_set_input_host copies everything before it returns.) */
+int zdw_set_input_host_async(zdw_ctx *ctx, const uint8_t *tsv, uint64_t len);
+
 /* parseInput(): consumes rows from the current position up to the end of input or the split hint
  * (NULL = no limit).  Returns 0, 15 (res->bad_row set), 7 (a block of zero rows was forced) or 20. */
 int zdw_block_pass1(zdw_ctx *ctx, const zdw_split_hint *hint, zdw_pass1_result *res);

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gb", type=float, default=1.0)
+    ap.add_argument("--no-gzip", action="store_true")
     args = ap.parse_args()
     import torch
     from zdw_amd import build, synth
@@ -27,8 +28,12 @@ def main():
         with open(p, "w") as f:
             f.write("#!/bin/sh\nexec cat\n")
         os.chmod(p, os.stat(p).st_mode | stat.S_IXUSR)
-        for label, path in (("cat", shim + os.pathsep + os.environ["PATH"]), ("gzip", os.environ["PATH"])):
-            env = dict(os.environ, PATH=path, ZDW_CLI_TIMING="1")
+        runs = [("cat", shim + os.pathsep + os.environ["PATH"], {}), ("cat, whole input first", shim + os.pathsep + os.environ["PATH"], {"ZDW_CLI_WHOLE_INPUT": "1"}),
+                ("cat", shim + os.pathsep + os.environ["PATH"], {})]
+        if not args.no_gzip:
+            runs.append(("gzip", os.environ["PATH"], {}))
+        for label, path, extra in runs:
+            env = dict(os.environ, PATH=path, ZDW_CLI_TIMING="1", **extra)
             t0 = time.perf_counter()
             r = subprocess.run([build.CLI_EXE, "-q", os.path.join(d, "t.sql")], env=env)
             dt = time.perf_counter() - t0

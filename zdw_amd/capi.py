@@ -33,6 +33,7 @@ class MultiBlock(C.Structure):
 
 
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64)
+READ_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64)
 
 
 class ZdwError(RuntimeError):
@@ -63,6 +64,8 @@ def lib():
         L.zdw_ctx_stage_times.argtypes = [vp, C.POINTER(StageTimes)]
         L.zdw_set_input_host.argtypes = [vp, vp, C.c_uint64]
         L.zdw_set_input_device.argtypes = [vp, vp, C.c_uint64]
+        L.zdw_set_input_stream.argtypes = [vp, READ_FN, vp, C.c_uint64]
+        L.zdw_set_input_host_async.argtypes = [vp, C.c_char_p, C.c_uint64]
         L.zdw_block_pass1.argtypes = [vp, C.POINTER(SplitHint), C.POINTER(Pass1Result)]
         L.zdw_ctx_pass1_launches.argtypes = [vp]
         L.zdw_ctx_pass1_launches.restype = C.c_uint64
@@ -225,6 +228,25 @@ class Encoder:
     def set_input_device(self, ptr, nbytes, keepalive=None):
         self._keep = keepalive
         self._chk(self.L.zdw_set_input_device(self.h, C.c_void_p(ptr), nbytes))
+
+    def set_input_host_async(self, data):
+        """bytes that stay where they are: the library copies them to the device piece by piece while blocks are encoded"""
+        self._keep = data
+        self._chk(self.L.zdw_set_input_host_async(self.h, data, len(data)))
+
+    def set_input_stream(self, reader, size_hint=0):
+        """reader(cap) -> bytes (at most cap of them; b"" = end of input); called from a thread of the library"""
+        def cb(_user, buf, cap):
+            try:
+                data = reader(int(cap))
+            except Exception:  # noqa: BLE001
+                return -1
+            if data:
+                C.memmove(buf, data, len(data))
+            return len(data)
+        self._reader = READ_FN(cb)
+        self._keep = None
+        self._chk(self.L.zdw_set_input_stream(self.h, self._reader, None, size_hint))
 
     def pass1(self, max_rows=None, partial_fields=0):
         res = Pass1Result()

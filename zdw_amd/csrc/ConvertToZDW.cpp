@@ -13,12 +13,17 @@
 
 #include "zdw_hip.h"
 
+#include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
+#include <mutex>
 #include <sstream>
+#include <thread>
 #include <strings.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -199,16 +204,100 @@ ConvertToZDW::ERR_CODE ConvertToZDW::validate(const char *zdwFile, const std::ve
 
 namespace {
 
+// The compressor's pipe behind a writer thread: put() copies into a queue of at most QUEUE_LIMIT bytes and returns, the thread
+// writes.  So the next piece of a block leaves the device while the one before goes down the pipe, and the next block's pass 1
+// runs while the last pieces of this one drain (the reference writes and parses in turn).
 struct OutPipe {
     FILE *f = nullptr;
-    bool put(const void *p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; }
+    static constexpr size_t QUEUE_LIMIT = 512u << 20;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable can_put, can_get;
+    std::deque<std::vector<unsigned char> > q;
+    std::vector<std::vector<unsigned char> > spare;          // emptied pieces, their memory kept
+    size_t queued = 0;
+    bool closing = false, failed = false, started = false;
+
+    void run()
+    {
+        for (;;) {
+            std::vector<unsigned char> piece;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                can_get.wait(lk, [&] { return closing || !q.empty(); });
+                if (q.empty()) return;
+                piece.swap(q.front());
+                q.pop_front();
+            }
+            const bool ok = failed || fwrite(piece.data(), 1, piece.size(), f) == piece.size();      // (after a failure: drain without writing)
+            {
+                std::lock_guard<std::mutex> g(m);
+                queued -= piece.size();
+                if (!ok) failed = true;
+                if (spare.size() < 4) { piece.clear(); spare.push_back(std::move(piece)); }
+            }
+            can_put.notify_all();
+        }
+    }
+    bool put(const void *p, size_t n)
+    {
+        if (n == 0) return true;
+        if (!started) { started = true; th = std::thread([this] { run(); }); }
+        std::vector<unsigned char> piece;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if (failed) return false;
+            can_put.wait(lk, [&] { return queued == 0 || queued + n <= QUEUE_LIMIT; });
+            if (!spare.empty()) { piece.swap(spare.back()); spare.pop_back(); }
+            queued += n;
+        }
+        // small writes (headers, column statistics) ride on the piece before them when it has not left yet
+        piece.assign(static_cast<const unsigned char *>(p), static_cast<const unsigned char *>(p) + n);
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (n < 4096 && !q.empty() && q.back().size() < (1u << 20)) q.back().insert(q.back().end(), piece.begin(), piece.end());
+            else q.push_back(std::move(piece));
+        }
+        can_get.notify_one();
+        return true;
+    }
     bool le(uint64_t v, unsigned bytes)
     {
         unsigned char b[8];
         for (unsigned i = 0; i < 8; ++i) b[i] = static_cast<unsigned char>(v >> (8 * i));
         return put(b, bytes);
     }
+    // everything queued is written (or dropped after a failure); returns false when a write failed
+    bool finish()
+    {
+        if (started) {
+            { std::lock_guard<std::mutex> g(m); closing = true; }
+            can_get.notify_all();
+            th.join();
+            started = false;
+        }
+        return !failed;
+    }
+    ~OutPipe() { finish(); }
 };
+
+// The input read from a descriptor by the library's feeder thread (zdw_set_input_stream); with -i -v the bytes are also teed into
+// the temporary file the validation compares against (ConvertToZDW.cpp:786-803: the reference tees stdin the same way).
+struct InSource {
+    int fd = -1;
+    FILE *tee = nullptr;
+    bool teeFailed = false;
+};
+int64_t readSource(void *user, uint8_t *buf, uint64_t cap)
+{
+    InSource *src = static_cast<InSource *>(user);
+    for (;;) {
+        const ssize_t r = read(src->fd, buf, cap > (1u << 30) ? (1u << 30) : static_cast<size_t>(cap));
+        if (r < 0 && errno == EINTR) continue;
+        if (r > 0 && src->tee && fwrite(buf, 1, static_cast<size_t>(r), src->tee) != static_cast<size_t>(r)) src->teeFailed = true;
+        return static_cast<int64_t>(r);
+    }
+}
 
 // ZDW_CLI_TIMING=1: wall time of the host-side phases of one file, on stderr
 struct PhaseClock {
@@ -250,7 +339,7 @@ struct CtxGuard {
 }  // namespace
 
 ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char> *hostImage, const char *mappedImage, uint64_t imageLen,
-                                                 const Schema &schema, const char *filestub, bool bValidate, const char *exeName,
+                                                 int streamFd, const Schema &schema, const char *filestub, bool bValidate, const char *exeName,
                                                  const char *outputDir, const char *zArgs,
                                                  const std::map<std::string, std::string> &metadata)
 {
@@ -358,6 +447,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
                 res = static_cast<ERR_CODE>(rc);
             }
         }
+        ok = out.finish() && ok;
         const int childStatus = pclose(out.f);
         out.f = NULL;
         if (res == OK && (!ok || childStatus != 0)) {
@@ -377,6 +467,10 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         }
         return res;
     }
+    // (declared before the context: its feeder thread reads through `source` until the context is destroyed)
+    InSource source;
+    std::string teeName;
+    struct TeeGuard { InSource &s; ~TeeGuard() { if (s.tee) pclose(s.tee); } } teeGuard{source};
     // ---- GPU context first: nothing is created on disk when no device is usable ----
     CtxGuard guard;
     {
@@ -400,7 +494,21 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
     clock.mark("ctx_create");
     const unsigned char *image = hostImage ? hostImage->data() : reinterpret_cast<const unsigned char *>(mappedImage);
     {
-        const int rc = zdw_set_input_host(ctx, image, imageLen);
+        int rc;
+        if (streamFd >= 0) {
+            // the input is read while its blocks are encoded; with -i -v it is teed into <base>.tmp.1.gz on the way
+            source.fd = streamFd;
+            if (bValidate && bStreamingInput) {
+                teeName = base + ".tmp.1.gz";
+                source.tee = popen(("gzip > " + teeName).c_str(), "w");
+                if (!source.tee) return CANT_OPEN_TEMP_FILE;
+            }
+            rc = zdw_set_input_stream(ctx, readSource, &source, imageLen);
+        } else if (!hostImage && !getenv("ZDW_CLI_WHOLE_INPUT")) {
+            rc = zdw_set_input_host_async(ctx, image, imageLen);      // a mapped file: copied from the page cache while the blocks are encoded
+        } else {
+            rc = zdw_set_input_host(ctx, image, imageLen);
+        }
         if (rc != ZDW_OK) {
             libError = zdw_last_error(ctx);
             statusOutput(ERROR, "%s\n", libError.c_str());
@@ -520,6 +628,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         zdw_block_next(ctx);
     }
 
+    ok = out.finish() && ok;
     const int childStatus = pclose(out.f);
     out.f = NULL;
     clock.mark("compressor_drain");
@@ -532,7 +641,13 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
     if (res == OK && bValidate) {
         std::vector<std::string> src;
         std::string tmpGz;
-        if (bStreamingInput) {
+        if (bStreamingInput && source.tee) {
+            tmpGz = teeName;                                   // the copy of stdin made while it was read
+            const int st = pclose(source.tee);
+            source.tee = NULL;
+            if (st != 0 || source.teeFailed) res = CANT_OPEN_TEMP_FILE;
+            else src.push_back(tmpGz);
+        } else if (bStreamingInput) {
             tmpGz = base + ".tmp.1.gz";
             FILE *gz = popen(("gzip > " + tmpGz).c_str(), "w");
             if (!gz) res = CANT_OPEN_TEMP_FILE;
@@ -550,6 +665,9 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
             else { statusOutput(INFO, "%s BAD\n", finalName.c_str()); res = v; }
         }
         if (!tmpGz.empty()) unlink(tmpGz.c_str());
+    } else if (!teeName.empty()) {
+        if (source.tee) { pclose(source.tee); source.tee = NULL; }
+        unlink(teeName.c_str());
     }
 
     if (res == OK) {
@@ -605,12 +723,15 @@ ConvertToZDW::ERR_CODE ConvertToZDW::convertFile(const char *infile, const char 
     }
 
     try {
+        const bool several = devices.size() > 1 || (devices.size() == 1 && getenv("ZDW_MULTI_ALWAYS"));
+        const bool whole = several || getenv("ZDW_CLI_WHOLE_INPUT");      // several devices cut a host image into their pieces
         if (bStreamingInput) {
+            if (!whole) return processFile(NULL, NULL, 0, 0 /* stdin */, schema, filestub, bValidate, exeName, outputDir, zArgs, meta);
             std::vector<unsigned char> image;
             unsigned char buf[1 << 16];
             size_t got;
             while ((got = fread(buf, 1, sizeof buf, stdin)) > 0) image.insert(image.end(), buf, buf + got);
-            return processFile(&image, NULL, image.size(), schema, filestub, bValidate, exeName, outputDir, zArgs, meta);
+            return processFile(&image, NULL, image.size(), -1, schema, filestub, bValidate, exeName, outputDir, zArgs, meta);
         }
         const std::string sqlName = std::string(filestub) + "." + getInputFileExtension();
         const int fd = open(sqlName.c_str(), O_RDONLY);
@@ -618,13 +739,21 @@ ConvertToZDW::ERR_CODE ConvertToZDW::convertFile(const char *infile, const char 
         struct stat st;
         if (fstat(fd, &st) != 0) { close(fd); return MISSING_SQL_FILE; }
         const uint64_t len = static_cast<uint64_t>(st.st_size);
+        if (!whole && (!S_ISREG(st.st_mode) || getenv("ZDW_CLI_READ_INPUT"))) {
+            // not a regular file (a FIFO ...): read in pieces by the library while the blocks are encoded, length unknown
+            const ERR_CODE r = processFile(NULL, NULL, S_ISREG(st.st_mode) ? len : 0, fd, schema, filestub, bValidate, exeName, outputDir, zArgs, meta);
+            close(fd);
+            return r;
+        }
+        // a regular file: mapped; the library copies it to the device from the page cache piece by piece while the blocks are
+        // encoded (read() into a pinned buffer first costs a host copy: 12 GB/s against 44)
         const char *map = NULL;
         if (len) {
             void *m = mmap(NULL, len, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m == MAP_FAILED) { close(fd); return MISSING_SQL_FILE; }
             map = static_cast<const char *>(m);
         }
-        const ERR_CODE r = processFile(NULL, map, len, schema, filestub, bValidate, exeName, outputDir, zArgs, meta);
+        const ERR_CODE r = processFile(NULL, map, len, -1, schema, filestub, bValidate, exeName, outputDir, zArgs, meta);
         if (map) munmap(const_cast<char *>(map), len);
         close(fd);
         return r;

@@ -84,7 +84,9 @@ private:
     static const unsigned BAD_FIELD = static_cast<unsigned>(-1);
     unsigned readDescFile(FILE *f, Schema &s) const;
     bool validateMetadata(const std::map<std::string, std::string> &metadata) const;
-    ERR_CODE processFile(const std::vector<unsigned char> *hostImage, const char *mappedImage, uint64_t imageLen, const Schema &schema,
+    // the input: a host image (several devices), or a descriptor that is read while the blocks are encoded (streamFd >= 0; imageLen = its
+    // length when known, else 0)
+    ERR_CODE processFile(const std::vector<unsigned char> *hostImage, const char *mappedImage, uint64_t imageLen, int streamFd, const Schema &schema,
                          const char *filestub, bool bValidate, const char *exeName, const char *outputDir, const char *zArgs,
                          const std::map<std::string, std::string> &metadata);
     ERR_CODE validate(const char *zdwFile, const std::vector<std::string> &srcFiles, const char *exeName, const char *outputDir);

@@ -7,6 +7,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -85,6 +88,28 @@ struct TimedSpan { hipEvent_t a, b; int stage; };
 
 }  // namespace
 
+// ---- an input that arrives through a read callback while earlier blocks are encoded (zdw_set_input_stream) ----
+// A feeder thread reads pieces into pinned buffers and copies them to the device image on its own stream; the image of a stream
+// of unknown length grows by doubling (a device-to-device copy; the smaller image lives on until the block that may be reading
+// it is done).  Pass 1 takes a snapshot (pointer, bytes that have arrived, end seen?) and waits when the block needs more.
+struct InputStream {
+    zdw_read_fn read = nullptr;
+    void *user = nullptr;
+    const uint8_t *host = nullptr;         // instead of `read`: the input lies in host memory (a mapped file), size_hint bytes of it
+    int device = 0;
+    uint64_t size_hint = 0, piece_bytes = 32ull << 20, first_cap = 256ull << 20;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    // under m:
+    void *img = nullptr;
+    uint64_t cap = 0, uploaded = 0;
+    bool final = false, stop = false;
+    int error = 0;                         // 1: the callback failed, 2: a device call failed
+    std::string error_text;
+    std::vector<void *> retired;           // earlier images: freed when the context moves on to its next block
+};
+
 struct zdw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -123,6 +148,8 @@ struct zdw_ctx {
     uint64_t n = 0;
     DevBuf in_owned;
     bool have_input = false;
+    InputStream *in_stream = nullptr;      // the input arrives through a callback (zdw_set_input_stream)
+    bool input_open = false;               // ... and its end has not been seen yet: the image is a prefix, its last row may be incomplete
     uint64_t hi = 0;                       // effective end: last row terminator + 1
     uint64_t lo = 0;                       // start of the current block
     uint64_t next_lo = 0;                  // start of the next block (set by pass 1)
@@ -293,7 +320,26 @@ int upload_schema(zdw_ctx *c)
     return ZDW_OK;
 }
 
-int after_input(zdw_ctx *c)
+// average row length and boundary density from the image's first 64 KiB (span size, descriptor ring: zdw_block_pass1)
+int sample_input(zdw_ctx *c)
+{
+    c->avg_row = 0;
+    c->dense_boundaries = false;
+    if (!c->n) return ZDW_OK;
+    uint8_t sample[1 << 16];
+    const uint64_t take = std::min<uint64_t>(sizeof sample, c->n);
+    HIP_TRY(c, hipMemcpyAsync(sample, c->d_in, take, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t lines = 0, tabs = 0;
+    for (uint64_t i = 0; i < take; ++i) { lines += sample[i] == '\n'; tabs += sample[i] == '\t'; }
+    c->avg_row = take / (lines ? lines : 1);
+    // field boundaries per 2 KiB round of pass 1: tables of mostly empty fields get the large descriptor ring
+    c->dense_boundaries = take && (lines + tabs) * 2048 / take > 330;
+    return ZDW_OK;
+}
+
+// a new input: everything that persists across the blocks of one input starts over
+void reset_input_state(zdw_ctx *c)
 {
     reset_block(c);
     c->lo = c->next_lo = 0;
@@ -304,22 +350,175 @@ int after_input(zdw_ctx *c)
     c->hi = 0;
     c->avg_row = 0;
     c->dense_boundaries = false;
+    c->input_open = false;
+}
+
+int after_input(zdw_ctx *c)
+{
+    reset_input_state(c);
     if (c->n) {
         HIP_TRY(c, c->d_scalar.ensure(64));
         launch_find_effective_end(c->d_in, c->n, 0, c->d_scalar.as<uint64_t>(), c->stream);
         HIP_TRY(c, hipMemcpyAsync(&c->hi, c->d_scalar.p, 8, hipMemcpyDeviceToHost, c->stream));
-        // average row length from the first 64 KiB (for the span size, zdw_block_pass1)
-        uint8_t sample[1 << 16];
-        const uint64_t take = std::min<uint64_t>(sizeof sample, c->n);
-        HIP_TRY(c, hipMemcpyAsync(sample, c->d_in, take, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        uint64_t lines = 0, tabs = 0;
-        for (uint64_t i = 0; i < take; ++i) { lines += sample[i] == '\n'; tabs += sample[i] == '\t'; }
-        c->avg_row = take / (lines ? lines : 1);
-        // field boundaries per 2 KiB round of pass 1: tables of mostly empty fields get the large descriptor ring
-        c->dense_boundaries = take && (lines + tabs) * 2048 / take > 330;
+        int rc = sample_input(c);
+        if (rc) return rc;
     }
     c->have_input = true;
+    return ZDW_OK;
+}
+
+// ---- streamed input ----
+void stream_fail(InputStream *is, int code, const std::string &text)
+{
+    std::lock_guard<std::mutex> g(is->m);
+    if (!is->error) { is->error = code; is->error_text = text; }
+    is->final = true;
+    is->cv.notify_all();
+}
+
+void stream_feeder(InputStream *is)
+{
+    (void)hipSetDevice(is->device);
+    hipStream_t s = nullptr;
+    constexpr int NP = 3;
+    void *piece[NP] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[NP] = {nullptr, nullptr, nullptr};
+    bool issued[NP] = {false, false, false};
+    uint64_t upto[NP] = {0, 0, 0};
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        (void)hipGetLastError();
+        stream_fail(is, 2, std::string(what) + ": " + hipGetErrorString(e));
+        return false;
+    };
+    bool ok = hip_ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "input stream");
+    if (ok && is->host) {
+        // host memory of the caller's: copied from where it lies, piece by piece, each published as it lands
+        void *img = nullptr;
+        ok = hip_ok(hipMalloc(&img, is->size_hint + 64), "device image of the input");
+        if (ok) { std::lock_guard<std::mutex> g(is->m); is->img = img; is->cap = is->size_hint + 64; }
+        uint64_t off = 0;
+        while (ok && off < is->size_hint) {
+            { std::lock_guard<std::mutex> g(is->m); if (is->stop) break; }
+            const uint64_t n = std::min<uint64_t>(is->piece_bytes, is->size_hint - off);
+            ok = hip_ok(hipMemcpyAsync(static_cast<uint8_t *>(img) + off, is->host + off, n, hipMemcpyHostToDevice, s), "input copy") &&
+                 hip_ok(hipStreamSynchronize(s), "input copy");
+            if (!ok) break;
+            off += n;
+            std::lock_guard<std::mutex> g(is->m);
+            is->uploaded = off;
+            is->cv.notify_all();
+        }
+        if (ok) {
+            std::lock_guard<std::mutex> g(is->m);
+            is->final = off == is->size_hint;
+            if (!is->final && !is->error) { is->error = 2; is->error_text = "stopped"; is->final = true; }
+            is->cv.notify_all();
+        }
+        if (s) (void)hipStreamDestroy(s);
+        return;
+    }
+    for (int i = 0; ok && i < NP; ++i) {
+        ok = hip_ok(hipHostMalloc(&piece[i], is->piece_bytes, hipHostMallocDefault), "pinned input piece") &&
+             hip_ok(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "input event");
+    }
+    auto publish = [&](uint64_t bytes) {
+        std::lock_guard<std::mutex> g(is->m);
+        is->uploaded = bytes;
+        is->cv.notify_all();
+    };
+    uint64_t off = 0;
+    bool eof = false;
+    for (int k = 0; ok && !eof; ++k) {
+        const int p = k % NP;
+        if (issued[p]) {                                    // the piece is free again once its copy has landed: those bytes are there
+            ok = hip_ok(hipEventSynchronize(ev[p]), "input copy");
+            if (!ok) break;
+            publish(upto[p]);
+            issued[p] = false;
+        }
+        { std::lock_guard<std::mutex> g(is->m); if (is->stop) break; }
+        uint64_t got = 0;
+        while (got < is->piece_bytes) {
+            if (got) { std::lock_guard<std::mutex> g(is->m); if (is->stop) { ok = false; break; } }      // (a slow producer: do not fill the piece first)
+            const int64_t r = is->read(is->user, static_cast<uint8_t *>(piece[p]) + got, is->piece_bytes - got);
+            if (r < 0) { stream_fail(is, 1, "the input's read callback failed"); ok = false; break; }
+            if (r == 0) { eof = true; break; }
+            got += (uint64_t)r;
+        }
+        if (!ok || !got) break;
+        if (off + got + 64 > is->cap) {
+            // a larger image: everything that has been sent so far moves over (this stream has carried all of it)
+            uint64_t want = is->size_hint > off + got ? is->size_hint + 64 : std::max<uint64_t>({2 * is->cap, off + got + 64, is->first_cap});
+            void *bigger = nullptr;
+            ok = hip_ok(hipMalloc(&bigger, want), "device image of the input");
+            if (!ok) break;
+            if (off) ok = hip_ok(hipMemcpyAsync(bigger, is->img, off, hipMemcpyDeviceToDevice, s), "input image copy");
+            ok = ok && hip_ok(hipStreamSynchronize(s), "input image copy");
+            if (!ok) { (void)hipFree(bigger); break; }
+            std::lock_guard<std::mutex> g(is->m);
+            if (is->img) is->retired.push_back(is->img);
+            is->img = bigger;
+            is->cap = want;
+        }
+        ok = hip_ok(hipMemcpyAsync(static_cast<uint8_t *>(is->img) + off, piece[p], got, hipMemcpyHostToDevice, s), "input copy") &&
+             hip_ok(hipEventRecord(ev[p], s), "input event");
+        if (!ok) break;
+        off += got;
+        issued[p] = true;
+        upto[p] = off;
+    }
+    if (ok && s) ok = hip_ok(hipStreamSynchronize(s), "input copy");
+    if (ok) {
+        std::lock_guard<std::mutex> g(is->m);
+        is->uploaded = off;
+        is->final = true;
+        is->cv.notify_all();
+    }
+    for (int i = 0; i < NP; ++i) { if (piece[i]) (void)hipHostFree(piece[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+    if (s) (void)hipStreamDestroy(s);
+}
+
+void stream_close(zdw_ctx *c)
+{
+    InputStream *is = c->in_stream;
+    if (!is) return;
+    { std::lock_guard<std::mutex> g(is->m); is->stop = true; }
+    if (is->th.joinable()) is->th.join();
+    for (void *p : is->retired) (void)hipFree(p);
+    if (is->img) (void)hipFree(is->img);
+    delete is;
+    c->in_stream = nullptr;
+    c->input_open = false;
+    c->d_in = nullptr; c->n = 0; c->have_input = false;
+}
+
+// The image as far as it has arrived, at least `need` bytes of it unless the input ends earlier.
+int stream_snapshot(zdw_ctx *c, uint64_t need)
+{
+    InputStream *is = c->in_stream;
+    const void *img = nullptr;
+    uint64_t len = 0;
+    bool final = false;
+    {
+        std::unique_lock<std::mutex> lk(is->m);
+        is->cv.wait(lk, [&] { return is->error || is->final || is->uploaded >= need; });
+        if (is->error) return fail(c, ZDW_UNKNOWN_ERROR, "input stream: %s", is->error_text.c_str());
+        img = is->img; len = is->uploaded; final = is->final;
+    }
+    if (len >= EXTRA_BASE) return fail(c, ZDW_OUT_OF_MEMORY, "input of %llu bytes is beyond this build's 2^39 limit", (unsigned long long)len);
+    const bool first = c->n == 0 && len != 0;
+    c->d_in = static_cast<const uint8_t *>(img);
+    c->n = len;
+    c->input_open = !final;
+    c->hi = c->lo;
+    if (len > c->lo) {
+        HIP_TRY(c, c->d_scalar.ensure(64));
+        launch_find_effective_end(c->d_in, c->n, c->lo, c->d_scalar.as<uint64_t>(), c->stream);
+        HIP_TRY(c, hipMemcpyAsync(&c->hi, c->d_scalar.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (first) return sample_input(c);
     return ZDW_OK;
 }
 
@@ -790,6 +989,7 @@ void zdw_ctx_destroy(zdw_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     collect_times(c);
+    stream_close(c);
     for (DevBuf *b : all_device_buffers(c)) b->release();
     c->h_dict.release(); c->h_rows.release();
     for (int i = 0; i < 2; ++i) { c->h_piece[i].release(); if (c->piece_ev[i]) (void)hipEventDestroy(c->piece_ev[i]); }
@@ -822,6 +1022,7 @@ int zdw_set_input_host(zdw_ctx *c, const uint8_t *tsv, uint64_t len)
     if (len && !tsv) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_set_input_host: tsv is NULL");
     if (len >= EXTRA_BASE) return fail(c, ZDW_OUT_OF_MEMORY, "input of %llu bytes is beyond this build's 2^39 limit", (unsigned long long)len);
     (void)hipSetDevice(c->device);
+    stream_close(c);
     HIP_TRY(c, c->in_owned.ensure(len + 64));
     {
         StageScope ts(c, ZDW_STAGE_H2D);
@@ -839,9 +1040,54 @@ int zdw_set_input_device(zdw_ctx *c, const void *d_tsv, uint64_t len)
     if (reinterpret_cast<uintptr_t>(d_tsv) & 15u) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_set_input_device: buffer must be 16-byte aligned");
     if (len >= EXTRA_BASE) return fail(c, ZDW_OUT_OF_MEMORY, "input of %llu bytes is beyond this build's 2^39 limit", (unsigned long long)len);
     (void)hipSetDevice(c->device);
+    stream_close(c);
     c->d_in = static_cast<const uint8_t *>(d_tsv);
     c->n = len;
     return after_input(c);
+}
+
+int zdw_set_input_stream(zdw_ctx *c, zdw_read_fn read, void *user, uint64_t size_hint)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    if (!read) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_set_input_stream: read is NULL");
+    (void)hipSetDevice(c->device);
+    stream_close(c);
+    c->in_owned.release();
+    reset_input_state(c);
+    InputStream *is = new (std::nothrow) InputStream;
+    if (!is) return fail(c, ZDW_OUT_OF_MEMORY, "out of host memory");
+    is->read = read; is->user = user; is->device = c->device; is->size_hint = size_hint;
+    if (const char *e = getenv("ZDW_STREAM_PIECE")) is->piece_bytes = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));      // tests
+    if (const char *e = getenv("ZDW_STREAM_CAP0")) is->first_cap = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));         // tests
+    c->in_stream = is;
+    c->d_in = nullptr; c->n = 0;
+    c->input_open = true;
+    c->have_input = true;
+    is->th = std::thread(stream_feeder, is);
+    return ZDW_OK;
+}
+
+int zdw_set_input_host_async(zdw_ctx *c, const uint8_t *tsv, uint64_t len)
+{
+    if (!c) return ZDW_UNKNOWN_ERROR;
+    if (len && !tsv) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_set_input_host_async: tsv is NULL");
+    if (len >= EXTRA_BASE) return fail(c, ZDW_OUT_OF_MEMORY, "input of %llu bytes is beyond this build's 2^39 limit", (unsigned long long)len);
+    (void)hipSetDevice(c->device);
+    stream_close(c);
+    c->in_owned.release();
+    reset_input_state(c);
+    InputStream *is = new (std::nothrow) InputStream;
+    if (!is) return fail(c, ZDW_OUT_OF_MEMORY, "out of host memory");
+    is->host = tsv ? tsv : reinterpret_cast<const uint8_t *>("");
+    is->device = c->device; is->size_hint = len;
+    is->piece_bytes = std::min<uint64_t>(std::max<uint64_t>(len / 8, 64ull << 20), 1ull << 30);      // (a copy from pageable memory costs ~1 ms to start)
+    if (const char *e = getenv("ZDW_STREAM_PIECE")) is->piece_bytes = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));      // tests
+    c->in_stream = is;
+    c->d_in = nullptr; c->n = 0;
+    c->input_open = true;
+    c->have_input = true;
+    is->th = std::thread(stream_feeder, is);
+    return ZDW_OK;
 }
 
 static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *res);
@@ -860,6 +1106,11 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     // before were of one size (tables of id-like columns end their blocks every N rows).  For an input's first block: the rows
     // that four times the limit's bytes of input hold (C5: a row's id fields cost 0.44 bytes of the modelled process per input
     // byte); when the limit does not trip inside a window, the next one is sized from the process size the model saw at its end.
+    if (c->in_stream && c->n == 0) {         // a streamed input's first bytes: the row length the first window is sized by
+        (void)hipSetDevice(c->device);
+        const int rc0 = stream_snapshot(c, 1);
+        if (rc0) return rc0;
+    }
     uint64_t window;
     if (c->model_rows_prev) {
         const uint64_t a = c->model_rows_prev, b = c->model_rows_prev2;
@@ -926,7 +1177,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
         c->oom_seen = false;
     }
     const uint64_t lo = c->lo;
-    uint64_t hi = c->hi;
+    uint64_t hi = 0;
     // a block that is run again (smaller split hint after an oversized dictionary) starts from the line buffer the block
     // began with: rows that move to the next block must not have grown it
     if (c->row_cap_block_lo == lo) c->row_cap = c->row_cap_block;
@@ -935,9 +1186,9 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     res->is_last_block = 1;
     res->bytes_consumed = lo;
     c->is_last = true;
-    c->next_lo = c->n;
     HIP_TRY(c, c->status.ensure(sizeof(P1Status)));
     HIP_TRY(c, c->d_scalar.ensure(64));
+    if (c->in_stream && c->n == 0) { int rc0 = stream_snapshot(c, 1); if (rc0) return rc0; }      // (the row length below comes from the first bytes)
 
     uint64_t total_rows = 0;
     uint32_t nspans = 0, span_shift = SPAN_SHIFT_MIN;
@@ -946,10 +1197,14 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     // sum over its blocks of what is left): the image is looked at as far as those rows should reach, by the bytes per row seen so
     // far and a quarter more, and twice as far again while that turns out too short.
     const bool windowed = hint && hint->max_rows != 0xFFFFFFFFu && c->avg_row;
-    if (windowed) {
-        const double reach = (double)hint->max_rows * (double)c->avg_row * 1.25 + 1048576.0;
-        if (reach < (double)(c->hi - lo)) hi = lo + (uint64_t)reach;
-    }
+    const double reach = windowed ? (double)hint->max_rows * (double)c->avg_row * 1.25 + 1048576.0 : 0.0;
+    // A streamed input: the block is looked at once the bytes it should need have arrived -- everything for a block without a
+    // row limit -- and again, with more of them, while the input is still open and the block reaches to the end of what is there.
+    uint64_t need = windowed && reach < 1.0e18 ? lo + (uint64_t)reach : ~0ull;
+    for (;;) {
+    if (c->in_stream) { int rcs = stream_snapshot(c, need); if (rcs) return rcs; }
+    hi = c->hi;
+    if (windowed && reach < (double)(c->hi - lo)) hi = lo + (uint64_t)reach;
     for (;;) {
     if (hi > lo) {
         StageScope ts(c, ZDW_STAGE_SCAN_ROWS);
@@ -986,6 +1241,13 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     if (hi < c->hi && total_rows <= hint->max_rows) { hi = (c->hi - lo) / 2 < hi - lo ? c->hi : lo + 2 * (hi - lo); continue; }
     break;
     }
+    if (c->input_open && !(hint && hint->max_rows != 0xFFFFFFFFu && hint->max_rows < total_rows)) {
+        need = need == ~0ull ? need : c->n + std::max<uint64_t>(c->n / 4, 64ull << 20);
+        continue;
+    }
+    break;
+    }
+    c->next_lo = c->n;
     if (total_rows >= 0xFFFFFFFFull) return fail(c, ZDW_UNKNOWN_ERROR, "more than 2^32-2 rows in one block");
 
     uint32_t row_limit = 0xFFFFFFFFu, partial = 0;
@@ -1327,6 +1589,12 @@ int zdw_block_next(zdw_ctx *c)
     if (!c) return ZDW_UNKNOWN_ERROR;
     c->lo = c->next_lo;
     reset_block(c);
+    if (c->in_stream) {                     // images the stream has outgrown: no block reads them any more
+        std::vector<void *> old;
+        { std::lock_guard<std::mutex> g(c->in_stream->m); old.swap(c->in_stream->retired); }
+        if (!old.empty()) { (void)hipStreamSynchronize(c->stream); if (c->stream2) (void)hipStreamSynchronize(c->stream2); }
+        for (void *p : old) (void)hipFree(p);
+    }
     return ZDW_OK;
 }
 
