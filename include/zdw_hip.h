@@ -249,6 +249,40 @@ int zdw_multi_stats(zdw_multi *m, uint8_t *col_size, uint64_t *col_base, uint32_
 int zdw_multi_dict_write(zdw_multi *m, zdw_write_fn write, void *user, uint64_t *section_len);
 int zdw_multi_rows_write(zdw_multi *m, zdw_write_fn write, void *user, uint64_t *rows_len);
 
+/* ---- decode: a raw ZDW stream back to its TSV rows -----------------------------------------------
+ * The other direction of the format, block by block, on the device: what UnconvertFromZDW does in readHeader / readNextBlock /
+ * readNextRow (cplusplus/UnconvertFromZDW.cpp:758-1000, 1270-1462; versions 9-11, the column types the encoder writes).  The rows
+ * come out as the reference prints them: tab-separated, one line per row, an unused column as its default ("" for text-like
+ * columns and char(1), 0 for integers, 0.000000000000 for decimal).  Return values are the reference decoder's ERR_CODE numbers
+ * (cplusplus/zdw/UnconvertFromZDW.h:34-56): 0 OK, 5 unsupported version, 6 the data ends before the block does, 7 unexpected
+ * column type, 9 corrupted data; 20 for a device error (zdw_dec_last_error has the text). */
+typedef struct zdw_dec zdw_dec;
+typedef struct zdw_dec_block {
+    uint32_t num_rows;
+    uint32_t longest_line;
+    uint32_t is_last_block;
+    uint32_t reserved;
+    uint64_t text_bytes;      /* length of the block's rows as text */
+    uint64_t zdw_bytes;       /* bytes of the stream this block took, its 9-byte header included */
+    uint64_t dict_bytes;
+    uint64_t walk_passes;     /* how often the row chain had to be walked again from corrected entries (1 = the guesses were right) */
+} zdw_dec_block;
+int zdw_dec_create(int device, zdw_dec **out);
+void zdw_dec_destroy(zdw_dec *d);
+const char *zdw_dec_last_error(const zdw_dec *d);      /* d may be NULL: last zdw_dec_create error */
+/* the whole stream (uncompressed .zdw) in host memory: copied to the device, file header parsed */
+int zdw_dec_set_input_host(zdw_dec *d, const uint8_t *zdw, uint64_t len);
+int zdw_dec_header(const zdw_dec *d, uint32_t *version, uint32_t *ncols);
+/* column i: name (NUL-terminated, valid until the next input), type id, char size field */
+int zdw_dec_column(const zdw_dec *d, uint32_t i, const char **name, uint8_t *type, uint16_t *char_size);
+/* decodes the next block on the device; returns 0 and blk->num_rows == 0 with is_last_block set when the stream holds no (more) blocks */
+int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk);
+/* the block's rows as text: left on the device, or handed to a writer in pieces (see zdw_block_dict_write) */
+int zdw_dec_text_device(zdw_dec *d, const void **d_text, uint64_t *text_len);
+int zdw_dec_text_write(zdw_dec *d, zdw_write_fn write, void *user, uint64_t *text_len);
+/* milliseconds of device work of the last block by stage: 0 row chain, 1 expand, 2 repeat-fill, 3 text lengths + offsets, 4 text */
+int zdw_dec_stage_ms(const zdw_dec *d, float ms[5]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,11 @@ WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64)
 READ_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64)
 
 
+class DecBlock(C.Structure):
+    _fields_ = [("num_rows", C.c_uint32), ("longest_line", C.c_uint32), ("is_last_block", C.c_uint32), ("reserved", C.c_uint32),
+                ("text_bytes", C.c_uint64), ("zdw_bytes", C.c_uint64), ("dict_bytes", C.c_uint64), ("walk_passes", C.c_uint64)]
+
+
 class ZdwError(RuntimeError):
     def __init__(self, code, text):
         super().__init__("zdw error %d: %s" % (code, text))
@@ -98,6 +103,18 @@ def lib():
         L.zdw_multi_set_input_host.argtypes = [vp, vp, C.c_uint64]
         L.zdw_multi_encode.argtypes = [vp, C.POINTER(MultiBlock)]
         L.zdw_multi_stats.argtypes = [vp, u8p, u64p, u32p]
+        L.zdw_dec_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.zdw_dec_destroy.argtypes = [vp]
+        L.zdw_dec_destroy.restype = None
+        L.zdw_dec_last_error.argtypes = [vp]
+        L.zdw_dec_last_error.restype = C.c_char_p
+        L.zdw_dec_set_input_host.argtypes = [vp, C.c_char_p, C.c_uint64]
+        L.zdw_dec_header.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.zdw_dec_column.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)]
+        L.zdw_dec_next_block.argtypes = [vp, C.POINTER(DecBlock)]
+        L.zdw_dec_text_device.argtypes = [vp, C.POINTER(vp), u64p]
+        L.zdw_dec_text_write.argtypes = [vp, WRITE_FN, vp, u64p]
+        L.zdw_dec_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 5)]
         L.zdw_multi_dict_write.argtypes = [vp, WRITE_FN, vp, u64p]
         L.zdw_multi_rows_write.argtypes = [vp, WRITE_FN, vp, u64p]
         _lib = L
@@ -158,6 +175,86 @@ class MultiEncoder:
         if rc:
             raise ZdwError(rc, self.L.zdw_multi_last_error(self.h).decode())
         return 0, bytes(out), blk
+
+
+class Decoder:
+    """zdw_dec_*: a raw ZDW stream back to its TSV rows, block by block, on the device (UnconvertFromZDW.cpp:758-1000, 1270-1462)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.zdw_dec_create(device, C.byref(h))
+        if rc:
+            raise ZdwError(rc, self.L.zdw_dec_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zdw_dec_destroy(self.h)
+            self.h = None
+
+    def error(self):
+        return self.L.zdw_dec_last_error(self.h).decode()
+
+    def set_input(self, data):
+        """returns the reference decoder's ERR_CODE (0 = OK)"""
+        self._keep = data
+        return self.L.zdw_dec_set_input_host(self.h, data, len(data))
+
+    def columns(self):
+        v, n = C.c_uint32(), C.c_uint32()
+        self.L.zdw_dec_header(self.h, C.byref(v), C.byref(n))
+        cols = []
+        for i in range(n.value):
+            name, t, cs = C.c_char_p(), C.c_uint8(), C.c_uint16()
+            self.L.zdw_dec_column(self.h, i, C.byref(name), C.byref(t), C.byref(cs))
+            cols.append((name.value, t.value, cs.value))
+        return v.value, cols
+
+    def next_block(self):
+        blk = DecBlock()
+        rc = self.L.zdw_dec_next_block(self.h, C.byref(blk))
+        return rc, blk
+
+    def text_device(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        rc = self.L.zdw_dec_text_device(self.h, C.byref(p), C.byref(n))
+        if rc:
+            raise ZdwError(rc, self.error())
+        return p.value, n.value
+
+    def text(self):
+        parts = []
+
+        def sink(_user, p, n):
+            parts.append(C.string_at(p, n))
+            return 0
+        cb = WRITE_FN(sink)
+        rc = self.L.zdw_dec_text_write(self.h, cb, None, None)
+        if rc:
+            raise ZdwError(rc, self.error())
+        return b"".join(parts)
+
+    def stage_ms(self):
+        ms = (C.c_float * 5)()
+        self.L.zdw_dec_stage_ms(self.h, C.byref(ms))
+        return dict(zip(("row_chain", "expand", "repeat_fill", "text_lengths", "text"), [round(float(x), 3) for x in ms]))
+
+    def decode_all(self, data):
+        """(rc, text of all blocks, [DecBlock])"""
+        rc = self.set_input(data)
+        if rc:
+            return rc, b"", []
+        out, blocks = [], []
+        while True:
+            rc, blk = self.next_block()
+            if rc:
+                return rc, b"".join(out), blocks
+            if blk.num_rows:
+                out.append(self.text())
+                blocks.append(blk)
+            if blk.is_last_block:
+                return 0, b"".join(out), blocks
 
 
 class Block:
