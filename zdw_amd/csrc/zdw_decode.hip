@@ -47,16 +47,69 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v, uint32_t lane)
     return total;
 }
 
+// A wave's view of the row section: two consecutive 8 KiB blocks in an LDS ring, the block after them on its way in registers
+// (requested when the walk enters the second block, put into the ring when it enters the third): the chain's steps read their
+// flag bytes from LDS and the memory latency of a block is paid while the block before it is walked.
+constexpr uint32_t DEC_BLK = 8192, DEC_BLK_SHIFT = 13;
+
+struct DecWindow {
+    const uint8_t *rows;
+    uint64_t limit;          // bytes of the section that exist (16-byte reads up to 64 bytes past it stay inside the allocation)
+    uint32_t lds;            // byte offset of the ring (2 x DEC_BLK) in zdw_lds
+    uint64_t cur;            // blocks cur and cur + 1 are in the ring
+    uint4 next[8];           // block cur + 2
+};
+__device__ __forceinline__ void dec_win_request(DecWindow &w, uint64_t blk, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        const uint64_t q = (blk << DEC_BLK_SHIFT) + (uint64_t)(i * 64u + lane) * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < w.limit) __builtin_memcpy(&v, w.rows + q, 16);                       // (the section starts at any byte: an alignment-1 load, which gfx950 takes as one dwordx4)
+        w.next[i] = v;
+    }
+}
+__device__ __forceinline__ void dec_win_commit(DecWindow &w, uint64_t blk, uint32_t lane)
+{
+    uint8_t *slot = zdw_lds + w.lds + (uint32_t)(blk & 1ull) * DEC_BLK;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(slot + (i * 64u + lane) * 16u) = w.next[i];
+}
+__device__ __forceinline__ void dec_win_seek(DecWindow &w, uint64_t p, uint32_t lane)
+{
+    const uint64_t b = p >> DEC_BLK_SHIFT;
+    if (b == w.cur) return;
+    if (b == w.cur + 1) {                      // the common step: the block in flight has long arrived
+        dec_win_commit(w, w.cur + 2, lane);
+        w.cur = b;
+    } else {                                   // far away (the first call, a row longer than a block)
+        dec_win_request(w, b, lane);
+        dec_win_commit(w, b, lane);
+        dec_win_request(w, b + 1, lane);
+        dec_win_commit(w, b + 1, lane);
+        w.cur = b;
+    }
+    dec_win_request(w, w.cur + 2, lane);
+    __builtin_amdgcn_wave_barrier();
+}
+
 // bytes of values the flag bytes at p announce, + the flag bytes themselves: the row's length
 template <bool TBL_LDS>
-__device__ __forceinline__ uint32_t dec_row_len(const uint8_t *__restrict__ rows, uint64_t limit, uint64_t p, uint32_t nflag, const uint16_t *__restrict__ tbl,
-                                                uint32_t lane)
+__device__ __forceinline__ uint32_t dec_row_len(DecWindow &w, uint64_t p, uint32_t nflag, const uint16_t *__restrict__ tbl, uint32_t lane)
 {
     uint32_t sum = 0;
-    for (uint32_t j = lane; j < nflag; j += 64) {
-        const uint64_t q = p + j;
-        const uint32_t b = q < limit ? rows[q] : 0u;
-        sum += TBL_LDS ? reinterpret_cast<const uint16_t *>(zdw_lds)[j * 256u + b] : tbl[j * 256u + b];
+    if (TBL_LDS) {
+        dec_win_seek(w, p, lane);
+        for (uint32_t j = lane; j < nflag; j += 64) {
+            const uint32_t b = zdw_lds[w.lds + (uint32_t)((p + j) & (2u * DEC_BLK - 1u))];
+            sum += reinterpret_cast<const uint16_t *>(zdw_lds)[j * 256u + b];
+        }
+    } else {                                   // schemas of more than 512 used columns: flag bytes and table from memory
+        for (uint32_t j = lane; j < nflag; j += 64) {
+            const uint64_t q = p + j;
+            const uint32_t b = q < w.limit ? w.rows[q] : 0u;
+            sum += tbl[j * 256u + b];
+        }
     }
     return nflag + wave_sum(sum, lane);
 }
@@ -69,6 +122,9 @@ __global__ __launch_bounds__(64) void k_dec_walk(const uint8_t *__restrict__ row
                                                  const uint64_t *__restrict__ rowbase, uint64_t *__restrict__ rstart, uint64_t max_rows)
 {
     const uint32_t lane = threadIdx.x;
+    DecWindow w;
+    w.rows = rows; w.limit = limit; w.cur = ~0ull - 8;
+    w.lds = (nflag * 512u + 15u) & ~15u;
     if (TBL_LDS) {
         for (uint32_t i = lane; i < nflag * 256u; i += 64) reinterpret_cast<uint16_t *>(zdw_lds)[i] = tbl[i];
         __builtin_amdgcn_wave_barrier();
@@ -81,14 +137,14 @@ __global__ __launch_bounds__(64) void k_dec_walk(const uint8_t *__restrict__ row
     else p = k == 0 ? 0 : entry_of[k - 1];
     uint32_t n = 0;
     const uint64_t base = MODE == 2 ? rowbase[k] : 0;
-    while (p < s1) {
+    while (p < s1 && p <= limit) {                           // (the section's end is a start too; nothing starts beyond it)
         if (MODE == 2) {
             const uint64_t idx = base + n;
             if (idx > max_rows) break;                       // (the starts of rows 0 .. max_rows: the last one is the section's end)
             if (lane == 0) rstart[idx] = p;
         }
         if (MODE != 0 || p >= s0) ++n;
-        p += dec_row_len<TBL_LDS>(rows, limit, p, nflag, tbl, lane);
+        p += dec_row_len<TBL_LDS>(w, p, nflag, tbl, lane);
     }
     if (MODE != 2 && lane == 0) {
         exit_out[k] = p;
@@ -247,49 +303,97 @@ __device__ __forceinline__ uint32_t dec_strlen(const uint8_t *__restrict__ s, ui
     }
     return n;
 }
-__device__ inline void dec_put_digits(uint8_t *dst, uint64_t v, uint32_t nd)
+// A field's text is put together in registers (three 64-bit words in memory order: numbers have at most 20 digits and a sign,
+// + the separator) and leaves in pieces of 8 / 4 / 2 / 1 bytes that add up to exactly its length: the bytes next to it belong to
+// other lanes.
+struct Text24 { uint64_t w0, w1, w2; };
+__device__ __forceinline__ void t24_push_front(Text24 &t, uint32_t c)
 {
-    for (uint32_t i = nd; i-- > 0;) { dst[i] = (uint8_t)('0' + v % 10); v /= 10; }
+    t.w2 = (t.w2 << 8) | (t.w1 >> 56);
+    t.w1 = (t.w1 << 8) | (t.w0 >> 56);
+    t.w0 = (t.w0 << 8) | c;
 }
-__device__ inline void dec_copy(uint8_t *dst, const uint8_t *src, uint32_t n)
+__device__ __forceinline__ void t24_set(Text24 &t, uint32_t at, uint32_t c)          // byte `at` (0..23) := c (it is zero before)
+{
+    const uint64_t v = (uint64_t)c << (8u * (at & 7u));
+    if (at < 8u) t.w0 |= v; else if (at < 16u) t.w1 |= v; else t.w2 |= v;
+}
+__device__ __forceinline__ void store_exact(uint8_t *dst, const Text24 &t, uint32_t n)
+{
+    uint32_t o = 0;
+    uint64_t w = t.w0;
+    if (n >= 8u) { __builtin_memcpy(dst, &t.w0, 8); o = 8; w = t.w1; if (n >= 16u) { __builtin_memcpy(dst + 8, &t.w1, 8); o = 16; w = t.w2; } }
+    const uint32_t r = n - o;
+    if (r & 4u) { const uint32_t x = (uint32_t)w; __builtin_memcpy(dst + o, &x, 4); w >>= 32; o += 4; }
+    if (r & 2u) { const uint16_t x = (uint16_t)w; __builtin_memcpy(dst + o, &x, 2); w >>= 16; o += 2; }
+    if (r & 1u) dst[o] = (uint8_t)w;
+}
+// decimal digits of v in front of what t holds (nd of them: dec_digits(v))
+__device__ __forceinline__ void t24_digits(Text24 &t, uint64_t v)
+{
+    if (v >> 32) {                                   // nine digits at a time while the value needs 64-bit arithmetic
+        do {
+            const uint64_t q = v / 1000000000ull;
+            uint32_t lo = (uint32_t)(v - q * 1000000000ull);
+            for (int i = 0; i < 9; ++i) { const uint32_t d = lo / 10u; t24_push_front(t, '0' + (lo - d * 10u)); lo = d; }
+            v = q;
+        } while (v >> 32);
+        if (v == 0) return;
+    }
+    uint32_t x = (uint32_t)v;
+    do { const uint32_t d = x / 10u; t24_push_front(t, '0' + (x - d * 10u)); x = d; } while (x);
+}
+// n bytes from src, then the separator
+__device__ inline void dec_copy_sep(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t sep)
 {
     uint32_t i = 0;
     for (; i + 8 <= n; i += 8) { uint64_t w; __builtin_memcpy(&w, src + i, 8); __builtin_memcpy(dst + i, &w, 8); }
-    for (; i < n; ++i) dst[i] = src[i];
+    uint64_t w;
+    __builtin_memcpy(&w, src + i, 8);                // (the dictionary carries 8 bytes of slack)
+    const uint32_t r = n - i;                        // < 8
+    w = (r ? (w & ((1ull << (8u * r)) - 1ull)) : 0ull) | ((uint64_t)sep << (8u * r));
+    Text24 t{w, 0, 0};
+    store_exact(dst + i, t, r + 1u);
 }
 
-// The text of one field: its length; EMIT: written to dst.  `used`: the column has values in this block (else: its default,
-// outputDefault, UnconvertFromZDW.cpp:1224-1267); val: the stored value after repeat-fill.
+// The text of one field and the separator behind it: its length (separator included); EMIT: written to dst.  `used`: the column has
+// values in this block (else: its default, outputDefault, UnconvertFromZDW.cpp:1224-1267); val: the stored value after repeat-fill.
 template <bool EMIT>
 __device__ __forceinline__ uint32_t dec_field(uint32_t type, bool used, uint64_t val, uint64_t base, const uint8_t *__restrict__ dict, uint64_t dsize,
-                                              uint8_t *dst)
+                                              uint8_t *dst, uint32_t sep)
 {
     const uint32_t cls = dec_class(type);
+    Text24 t{0, 0, 0};
+    uint32_t n = 0;
     if (cls <= 1) {
         if (used && val) {
             const uint64_t off = val + base;
-            if (off >= dsize) return 0;                                           // corrupt: reported by the host from the ranges
-            const uint32_t n = dec_strlen(dict + off, dsize - off);
-            if (EMIT) dec_copy(dst, dict + off, n);
-            return n;
+            if (off < dsize) {                                                       // (beyond it: corrupt data, printed as empty)
+                n = dec_strlen(dict + off, dsize - off);
+                if (EMIT) dec_copy_sep(dst, dict + off, n, sep);
+                return n + 1u;
+            }
+        } else if (cls == 1) {
+            t.w0 = 0x303030302e30ull | (0x3030ull << 48);                            // "0.000000" ...
+            t.w1 = 0x303030303030ull;                                                // ... "000000"
+            n = 14;
         }
-        if (cls == 1) { if (EMIT) { const char *z = "0.000000000000"; for (int i = 0; i < 14; ++i) dst[i] = (uint8_t)z[i]; } return 14; }
-        return 0;
+    } else if (cls == 2) {                                                           // :1396-1420
+        if (used && val) {
+            const uint64_t tuple = val + base;
+            const uint32_t b0 = (uint32_t)tuple & 0xffu, b1 = (uint32_t)(tuple >> 8) & 0xffu;
+            if (b0 != '\\') { if (b0) { t.w0 = b0; n = 1; } }
+            else { t.w0 = b0 | (b1 << 8); n = 2; }
+        }
+    } else {
+        uint64_t x = (used && val) ? val + base : 0;
+        uint32_t neg = 0;
+        if (cls == 4 && (int64_t)x < 0) { neg = 1; x = 0ull - x; }
+        n = neg + dec_digits(x);
+        if (EMIT) { t24_digits(t, x); if (neg) t24_push_front(t, '-'); }
     }
-    if (cls == 2) {                                                                // :1396-1420
-        if (!used || !val) return 0;
-        const uint64_t tuple = val + base;
-        const uint8_t b0 = (uint8_t)tuple, b1 = (uint8_t)(tuple >> 8);
-        if (b0 != '\\') { if (b0) { if (EMIT) dst[0] = b0; return 1; } return 0; }
-        if (EMIT) { dst[0] = b0; dst[1] = b1; }
-        return 2;
-    }
-    uint64_t x = (used && val) ? val + base : 0;
-    uint32_t neg = 0;
-    if (cls == 4 && (int64_t)x < 0) { neg = 1; x = 0ull - x; }
-    const uint32_t nd = dec_digits(x);
-    if (EMIT) { if (neg) dst[0] = '-'; dec_put_digits(dst + neg, x, nd); }
-    return neg + nd;
+    if (EMIT) { t24_set(t, n, sep); store_exact(dst, t, n + 1u); }
+    return n + 1u;
 }
 
 struct DecText {
@@ -301,59 +405,46 @@ struct DecText {
     const uint64_t *V, *carry;  // [nrows][nused], [ntiles][nused]
     const uint8_t *dict; uint64_t dsize;
     uint32_t *rowlen;           // [nrows] (LEN)
+    uint32_t *pre;              // [nrows][batches of 64 columns]: where the batch begins within its row's text (LEN writes, EMIT reads)
     const uint64_t *rowoff;     // [nrows] (EMIT)
     uint8_t *out;
 };
 
 // wave = tile of 64 rows; lane = column (batches of 64 schema columns), walking the tile's rows with the value so far in a
-// register.  LEN: the rows' text lengths (lane r keeps row r's).  EMIT: two sweeps: where each batch begins within its row
-// (LDS), then the text.
+// register.  LEN: the rows' text lengths (lane i keeps row i's) and where each batch begins within its row.  EMIT: the text.
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_dec_text(const DecText a, uint64_t ntiles, uint32_t nbatch)
 {
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    uint32_t *pre = reinterpret_cast<uint32_t *>(zdw_lds) + (size_t)wv * DEC_TILE * nbatch;      // EMIT: [row in tile][batch]
     for (uint64_t tile = wave; tile < ntiles; tile += nwaves) {
         const uint64_t r0 = tile * DEC_TILE, r1 = r0 + DEC_TILE < a.nrows ? r0 + DEC_TILE : a.nrows;
         uint32_t mylen = 0;                                    // lane i: text bytes of row r0 + i so far
-        for (int sweep = 0; sweep < (EMIT ? 2 : 1); ++sweep) {
-            for (uint32_t b = 0; b < nbatch; ++b) {
-                const uint32_t c = b * 64u + lane;
-                const bool col = c < a.ncols;
-                const int32_t u = col ? a.used_of[c] : -1;
-                const uint32_t type = col ? a.type[c] : 0u;
-                const uint64_t base = u >= 0 ? a.ubase[u] : 0ull;
-                uint64_t val = u >= 0 ? a.carry[tile * a.nused + (uint32_t)u] : 0ull;
-                for (uint64_t r = r0; r < r1; ++r) {
-                    const uint64_t p = a.rstart[r];
-                    if (u >= 0 && ((a.rows[p + ((uint32_t)u >> 3)] >> ((uint32_t)u & 7u)) & 1u)) val = a.V[r * a.nused + (uint32_t)u];
-                    const uint32_t ri = (uint32_t)(r - r0);
-                    if (!EMIT || sweep == 0) {
-                        const uint32_t len = col ? dec_field<false>(type, u >= 0, val, base, a.dict, a.dsize, nullptr) + 1u : 0u;      // + tab / newline
-                        const uint32_t total = wave_sum(len, lane);
-                        if (lane == ri) {
-                            if (EMIT) pre[ri * nbatch + b] = mylen;
-                            mylen += total;
-                        }
-                    } else {
-                        const uint32_t len = col ? dec_field<false>(type, u >= 0, val, base, a.dict, a.dsize, nullptr) + 1u : 0u;
-                        uint32_t total;
-                        const uint32_t off = wave_excl_sum(len, lane, total);
-                        if (col) {
-                            uint8_t *dst = a.out + a.rowoff[r] + pre[ri * nbatch + b] + off;
-                            (void)dec_field<true>(type, u >= 0, val, base, a.dict, a.dsize, dst);
-                            dst[len - 1u] = c + 1u == a.ncols ? '\n' : '\t';
-                        }
-                    }
+        for (uint32_t b = 0; b < nbatch; ++b) {
+            const uint32_t c = b * 64u + lane;
+            const bool col = c < a.ncols;
+            const int32_t u = col ? a.used_of[c] : -1;
+            const uint32_t type = col ? a.type[c] : 0u;
+            const uint64_t base = u >= 0 ? a.ubase[u] : 0ull;
+            const uint32_t sep = c + 1u == a.ncols ? '\n' : '\t';
+            uint64_t val = u >= 0 ? a.carry[tile * a.nused + (uint32_t)u] : 0ull;
+            for (uint64_t r = r0; r < r1; ++r) {
+                const uint64_t p = a.rstart[r];
+                if (u >= 0 && ((a.rows[p + ((uint32_t)u >> 3)] >> ((uint32_t)u & 7u)) & 1u)) val = a.V[r * a.nused + (uint32_t)u];
+                const uint32_t ri = (uint32_t)(r - r0);
+                const uint32_t len = col ? dec_field<false>(type, u >= 0, val, base, a.dict, a.dsize, nullptr, sep) : 0u;
+                uint32_t total;
+                const uint32_t off = wave_excl_sum(len, lane, total);
+                if (!EMIT) {
+                    if (lane == ri) { a.pre[r * nbatch + b] = mylen; mylen += total; }
+                } else if (col) {
+                    (void)dec_field<true>(type, u >= 0, val, base, a.dict, a.dsize, a.out + a.rowoff[r] + a.pre[r * nbatch + b] + off, sep);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
         }
         if (!EMIT && r0 + lane < r1) a.rowlen[r0 + lane] = mylen;
     }
 }
-
 
 // ------------------------------------------------------------------------------------------
 // host side: the zdw_dec_* C ABI
@@ -396,7 +487,7 @@ struct zdw_dec {
     std::vector<uint8_t> types;
     std::vector<uint16_t> charsizes;
     // the block
-    DBuf d_type, d_used_of, d_usize, d_ubase, d_tbl, entry, exit_true, counts, cum, scan_tmp, rstart, V, last, has, slast, shas, rowlen, rowoff, text, flag;
+    DBuf d_type, d_used_of, d_usize, d_ubase, d_tbl, entry, exit_true, counts, cum, scan_tmp, rstart, V, last, has, slast, shas, rowlen, rowoff, pre, text, flag;
     uint64_t text_bytes = 0;
     bool have_block = false;
     float stage_ms[5] = {0, 0, 0, 0, 0};
@@ -455,7 +546,7 @@ void zdw_dec_destroy(zdw_dec *d)
     (void)hipSetDevice(d->device);
     if (d->s) (void)hipStreamSynchronize(d->s);
     for (DBuf *b : {&d->img, &d->d_type, &d->d_used_of, &d->d_usize, &d->d_ubase, &d->d_tbl, &d->entry, &d->exit_true, &d->counts, &d->cum, &d->scan_tmp,
-                    &d->rstart, &d->V, &d->last, &d->has, &d->slast, &d->shas, &d->rowlen, &d->rowoff, &d->text, &d->flag})
+                    &d->rstart, &d->V, &d->last, &d->has, &d->slast, &d->shas, &d->rowlen, &d->rowoff, &d->pre, &d->text, &d->flag})
         b->release();
     for (int i = 0; i < 6; ++i) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
     for (int i = 0; i < 2; ++i) { if (d->piece[i]) (void)hipHostFree(d->piece[i]); if (d->piece_ev[i]) (void)hipEventDestroy(d->piece_ev[i]); }
@@ -628,7 +719,7 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
         DEC_TRY(d, d->scan_tmp.ensure(scan_tmp_bytes(nchunks + 1ull)));
         DEC_TRY(d, d->flag.ensure(64));
         const bool lds = (size_t)nflag * 512 <= 32768;
-        const size_t shm = lds ? (size_t)nflag * 512 : 0;
+        const size_t shm = lds ? (((size_t)nflag * 512 + 15) & ~(size_t)15) + 2 * 8192 : 0;
         const uint64_t warm = 1ull << chunk_shift;
         const uint16_t *t16 = d->d_tbl.as<uint16_t>();
         if (lds) hipLaunchKernelGGL((k_dec_walk<0, true>), dim3(nchunks), dim3(64), shm, s, rows, avail, nflag, t16, chunk_shift, nchunks, warm, nullptr,
@@ -698,13 +789,14 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
     const uint32_t cbatch = (ncols + 63) / 64;
     DEC_TRY(d, d->rowlen.ensure(4ull * ((uint64_t)nrows + 2)));
     DEC_TRY(d, d->rowoff.ensure(8ull * ((uint64_t)nrows + 2)));
+    DEC_TRY(d, d->pre.ensure(4ull * (uint64_t)nrows * cbatch + 64));
     DEC_TRY(d, d->scan_tmp.ensure(scan_tmp_bytes((uint64_t)nrows + 1)));
     DecText a{};
     a.rows = rows; a.rstart = d->rstart.as<uint64_t>(); a.nrows = nrows; a.ncols = ncols; a.nused = nused;
     a.type = d->d_type.as<uint8_t>(); a.used_of = d->d_used_of.as<int32_t>(); a.ubase = d->d_ubase.as<uint64_t>();
     a.V = d->V.as<uint64_t>(); a.carry = d->last.as<uint64_t>();
     a.dict = img + dict_off; a.dsize = dsize;
-    a.rowlen = d->rowlen.as<uint32_t>(); a.rowoff = d->rowoff.as<uint64_t>(); a.out = nullptr;
+    a.rowlen = d->rowlen.as<uint32_t>(); a.pre = d->pre.as<uint32_t>(); a.rowoff = d->rowoff.as<uint64_t>(); a.out = nullptr;
     uint64_t text_bytes = 0;
     if (nrows && ncols) {
         hipLaunchKernelGGL((k_dec_text<false>), dim3(grid_for(ntiles)), dim3(256), 0, s, a, ntiles, cbatch);
@@ -716,9 +808,7 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
     DEC_TRY(d, d->text.ensure(text_bytes + 64));
     if (text_bytes) {
         a.out = d->text.as<uint8_t>();
-        const size_t shm = (size_t)4 * DEC_TILE * cbatch * 4;
-        if (shm > 64 * 1024) return dfail(d, DEC_DEVICE, "schemas of more than %u columns are not supported by the text kernel yet", 64u * 64u);
-        hipLaunchKernelGGL((k_dec_text<true>), dim3(grid_for(ntiles)), dim3(256), shm, s, a, ntiles, cbatch);
+        hipLaunchKernelGGL((k_dec_text<true>), dim3(grid_for(ntiles)), dim3(256), 0, s, a, ntiles, cbatch);
     }
     DEC_TRY(d, hipEventRecord(d->ev[5], s));
     DEC_TRY(d, hipStreamSynchronize(s));
