@@ -121,3 +121,20 @@ def test_large_block_against_the_host_decoder(dec, sandbox, tmp_path):
         want += b"\t".join((x or b"0") if integer[i] else (x or b"0.000000000000") if table.types[i] == 11 else x for i, x in enumerate(fs)) + b"\n"
     assert text[:len(want)] == bytes(want)
     print("decode stages (ms):", dec.stage_ms(), "walk passes", blocks[0].walk_passes, "text bytes", len(text))
+
+
+def test_decoder_binary_gpu_mode(tmp_path):
+    """unconvertDWfile --gpu: the same bytes on stdout and in the files as the host mode, the same exit code for a stream cut short"""
+    from zdw_amd import build
+    exe = build.DECODER_EXE
+    for zdw, sql in (("test.zdw", "test.sql"), ("movie_tickets.zdw.xz", "movie_tickets.sql.xz")):
+        p = subprocess.run([exe, "--gpu", "-q", "-", pu.G + "/" + zdw], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr
+        assert p.stdout == pu.rd(sql), zdw
+    p = subprocess.run([exe, "--gpu", "-o", "-", pu.G + "/test.zdw"], stdout=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == pu.rd("test.desc.sql")
+    (tmp_path / "t.zdw").write_bytes(pu.rd("test.zdw"))
+    assert subprocess.run([exe, "--gpu", "-q", "-d", str(tmp_path), str(tmp_path / "t.zdw")]).returncode == 0
+    assert (tmp_path / "t.sql").read_bytes() == pu.rd("test.sql") and (tmp_path / "t.desc.sql").read_bytes() == pu.rd("test.desc.sql")
+    (tmp_path / "bad.zdw").write_bytes(pu.rd("test.zdw")[:-3])
+    assert subprocess.run([exe, "--gpu", "-q", "-t", str(tmp_path / "bad.zdw")], stderr=subprocess.PIPE).returncode == 6

@@ -9,13 +9,17 @@
 // prints "0"); an unused column prints its default ("" for text, "0" for integers, "0.000000000000"
 // for decimal: outputDefault, :1224-1267).  The reference's column selection (-c*), statistics, metadata
 // output and pre-v9 formats are not provided: this is the validation path, not a replacement of the
-// reference's decoder.  Plain C++, no GPU: decoding is SURVEY.md §8(f) row 1, outside this round's hot path.
+// reference's decoder.  Plain C++; with --gpu the blocks are decoded on the device instead, through the zdw_dec_* calls of
+// libzdw_hip.so (loaded from the directory of this binary when asked for: the host path needs no GPU library).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <dlfcn.h>
+#include <unistd.h>
 
 namespace {
 
@@ -243,6 +247,78 @@ int decode(const std::vector<unsigned char> &data, Out *rows_out, FILE *desc_out
     return OK;
 }
 
+// ---- --gpu: the same output through zdw_dec_* (include/zdw_hip.h) ----
+struct GpuApi {
+    void *lib = nullptr;
+    int (*create)(int, void **) = nullptr;
+    void (*destroy)(void *) = nullptr;
+    const char *(*last_error)(const void *) = nullptr;
+    int (*set_input_host)(void *, const unsigned char *, uint64_t) = nullptr;
+    int (*header)(const void *, uint32_t *, uint32_t *) = nullptr;
+    int (*column)(const void *, uint32_t, const char **, uint8_t *, uint16_t *) = nullptr;
+    int (*next_block)(void *, void *) = nullptr;
+    int (*text_write)(void *, int (*)(void *, const unsigned char *, uint64_t), void *, uint64_t *) = nullptr;
+};
+struct GpuBlock { uint32_t num_rows, longest_line, is_last_block, reserved; uint64_t text_bytes, zdw_bytes, dict_bytes, walk_passes; };      // zdw_dec_block
+
+bool load_gpu(GpuApi &g, const char *argv0)
+{
+    std::string dir;
+    char self[4096];
+    const ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+    if (n > 0) { self[n] = 0; dir = self; const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? "." : dir.substr(0, sl); }
+    else { dir = argv0; const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? "." : dir.substr(0, sl); }
+    g.lib = dlopen((dir + "/libzdw_hip.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!g.lib) g.lib = dlopen("libzdw_hip.so", RTLD_NOW | RTLD_LOCAL);
+    if (!g.lib) { fprintf(stderr, "--gpu: %s\n", dlerror()); return false; }
+    auto sym = [&](const char *name) { return dlsym(g.lib, name); };
+    g.create = reinterpret_cast<decltype(g.create)>(sym("zdw_dec_create"));
+    g.destroy = reinterpret_cast<decltype(g.destroy)>(sym("zdw_dec_destroy"));
+    g.last_error = reinterpret_cast<decltype(g.last_error)>(sym("zdw_dec_last_error"));
+    g.set_input_host = reinterpret_cast<decltype(g.set_input_host)>(sym("zdw_dec_set_input_host"));
+    g.header = reinterpret_cast<decltype(g.header)>(sym("zdw_dec_header"));
+    g.column = reinterpret_cast<decltype(g.column)>(sym("zdw_dec_column"));
+    g.next_block = reinterpret_cast<decltype(g.next_block)>(sym("zdw_dec_next_block"));
+    g.text_write = reinterpret_cast<decltype(g.text_write)>(sym("zdw_dec_text_write"));
+    return g.create && g.destroy && g.last_error && g.set_input_host && g.header && g.column && g.next_block && g.text_write;
+}
+
+int write_rows(void *user, const unsigned char *bytes, uint64_t len)
+{
+    Out *o = static_cast<Out *>(user);
+    o->flush();
+    return fwrite(bytes, 1, len, o->f) == len ? 0 : 1;
+}
+
+int decode_gpu(const GpuApi &g, const std::vector<unsigned char> &data, Out *rows_out, FILE *desc_out, uint64_t *rows_total)
+{
+    void *d = nullptr;
+    int rc = g.create(-1, &d);
+    if (rc) { fprintf(stderr, "--gpu: %s\n", g.last_error(nullptr)); return rc == 20 ? FILE_OPEN_ERR : rc; }
+    rc = g.set_input_host(d, data.data(), data.size());
+    uint32_t version = 0, ncols = 0;
+    if (!rc) rc = g.header(d, &version, &ncols);
+    for (uint32_t c = 0; !rc && c < ncols; ++c) {
+        const char *name = nullptr; uint8_t type = 0; uint16_t cs = 0;
+        g.column(d, c, &name, &type, &cs);
+        const std::string line = column_desc(name, type, cs);
+        if (line.empty()) rc = UNEXPECTED_DESC_TYPE;
+        else if (desc_out) fwrite(line.data(), 1, line.size(), desc_out);
+    }
+    uint64_t total = 0;
+    while (!rc && rows_out) {
+        GpuBlock b;
+        rc = g.next_block(d, &b);
+        if (rc) break;
+        if (b.num_rows) { rc = g.text_write(d, write_rows, rows_out, nullptr); total += b.num_rows; }
+        if (b.is_last_block) break;
+    }
+    if (rc) fprintf(stderr, "--gpu: %s\n", g.last_error(d));
+    if (rows_total) *rows_total = total;
+    g.destroy(d);
+    return rc == 20 ? CORRUPTED_DATA_ERROR : rc;
+}
+
 void usage(const char *exe)
 {
     printf("Usage: %s [-q] [-] [-o] [-t] [-w] [-d outputDirectory] file1 [file2...]\n"
@@ -252,6 +328,7 @@ void usage(const char *exe)
            "\t-q quiet\n"
            "\t-t test the integrity of the file only\n"
            "\t-w give outputted files no extension (default = .sql)\n"
+           "\t--gpu decode the blocks on the GPU (libzdw_hip.so next to this binary)\n"
            "\t(column selection, statistics and metadata output of the reference tool are not provided)\n", exe);
 }
 
@@ -259,7 +336,8 @@ void usage(const char *exe)
 
 int main(int argc, char **argv)
 {
-    bool to_stdout = false, quiet = false, desc_only = false, test_only = false, no_ext = false;
+    bool to_stdout = false, quiet = false, desc_only = false, test_only = false, no_ext = false, gpu = false;
+    GpuApi api;
     std::string dir;
     std::vector<std::string> files;
     for (int i = 1; i < argc; ++i) {
@@ -270,6 +348,7 @@ int main(int argc, char **argv)
         else if (a == "-t") test_only = true;
         else if (a == "-w") no_ext = true;
         else if (a == "-v") { }
+        else if (a == "--gpu") gpu = true;
         else if (a == "-d") { if (++i >= argc) { usage(argv[0]); return BAD_PARAMETER; } dir = argv[i]; }
         else if (a == "--help") { usage(argv[0]); return OK; }
         else if (a == "--version") { printf("unconvertDWfile (zdw-mi355x) for ZDW v9-v11\n"); return OK; }
@@ -277,6 +356,10 @@ int main(int argc, char **argv)
         else files.push_back(a);
     }
     if (files.empty()) { usage(argv[0]); return BAD_PARAMETER; }
+    if (gpu && !load_gpu(api, argv[0])) return FILE_OPEN_ERR;
+    auto run = [&](const std::vector<unsigned char> &data, Out *o, FILE *desc, uint64_t *rows) {
+        return gpu ? decode_gpu(api, data, o, desc, rows) : decode(data, o, desc, rows);
+    };
     int worst = OK;
     for (const std::string &path : files) {
         std::vector<unsigned char> data;
@@ -285,10 +368,10 @@ int main(int argc, char **argv)
         if (rc == OK) {
             if (test_only) {
                 struct Null : Out { Null() : Out(fopen("/dev/null", "wb")) {} ~Null() { if (f) fclose(f); } } sink;
-                rc = sink.f ? decode(data, &sink, nullptr, &rows) : FILE_CREATION_ERR;
+                rc = sink.f ? run(data, &sink, nullptr, &rows) : FILE_CREATION_ERR;
             } else if (to_stdout) {
                 Out o(stdout);
-                rc = decode(data, desc_only ? nullptr : &o, desc_only ? stdout : nullptr, &rows);
+                rc = run(data, desc_only ? nullptr : &o, desc_only ? stdout : nullptr, &rows);
                 o.flush();
                 fflush(stdout);
             } else {
@@ -302,7 +385,7 @@ int main(int argc, char **argv)
                 if (!fd || (!desc_only && !fr)) rc = FILE_CREATION_ERR;
                 else {
                     Out o(fr ? fr : stdout);
-                    rc = decode(data, fr ? &o : nullptr, fd, &rows);
+                    rc = run(data, fr ? &o : nullptr, fd, &rows);
                     o.flush();
                 }
                 if (fd) fclose(fd);
