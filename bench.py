@@ -189,10 +189,55 @@ def e2e_cli(torch, table, gb=2.0):
                 continue
             res[label + "_MBps"] = round(nbytes / 1e6 / dt, 1)
             res[label + "_s"] = round(dt, 2)
+            if label == "cat_shim":
+                # the other direction: that raw stream back to text on the device (zdw_dec_*), the second of two
+                # runs; checked against the file it came from on its first rows, by row count and by length
+                try:
+                    res["decode"] = decode_leg(table, open(outp, "rb").read(), os.path.join(d, "t.sql"), rows)
+                except Exception as e:  # noqa: BLE001
+                    res["decode"] = {"error": repr(e)[:200]}
             os.unlink(outp)
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return res
+
+
+def decode_leg(table, z, sql_path, rows):
+    from zdw_amd import capi
+    dec = capi.Decoder(0)
+    try:
+        out = None
+        for run in range(2):
+            assert dec.set_input(z) == 0, dec.error()
+            stages, text_bytes, nrows, first = {}, 0, 0, None
+            while True:
+                rc, blk = dec.next_block()
+                assert rc == 0, dec.error()
+                if blk.num_rows:
+                    nrows += blk.num_rows
+                    text_bytes += blk.text_bytes
+                    for k, v in dec.stage_ms().items():
+                        stages[k] = round(stages.get(k, 0.0) + v, 3)
+                    if first is None and run == 1:
+                        first = dec.text()[:8 << 20]
+                if blk.is_last_block:
+                    break
+            dev_ms = sum(stages.values())
+            out = {"zdw_bytes": len(z), "text_bytes": int(text_bytes), "device_ms": round(dev_ms, 2), "text_MBps": round(text_bytes / 1e3 / dev_ms, 1) if dev_ms else None,
+                   "stage_ms": stages}
+        integer = [t in (7, 8, 9, 10, 12, 13, 14, 15) for t in table.types]
+        first = first[:first.rfind(b"\n") + 1]
+        k = first.count(b"\n")
+        want = bytearray()
+        with open(sql_path, "rb") as f:
+            for _ in range(k):
+                fs = f.readline()[:-1].split(b"\t")
+                want += b"\t".join((x or b"0") if integer[i] else (x or b"0.000000000000") if table.types[i] == 11 else x for i, x in enumerate(fs)) + b"\n"
+        out["verified"] = bool(nrows == rows and bytes(want) == first)
+        out["checks"] = "row count; the first %d rows equal the input's (empty integer / decimal fields read 0 / 0.000000000000)" % k
+        return out
+    finally:
+        dec.close()
 
 
 def stream_copy_gbps(torch, src):
