@@ -50,6 +50,7 @@ constexpr uint32_t LUT_ROWS = 25;                 // byte masks "first L bytes" 
 // tables of mostly empty fields (a round of such data holds 1000+), whose boundaries are then emitted chunk by chunk
 // (~540 each).  What still does not fit is emitted in 16-lane pieces (<= 256 boundaries each), the ring drained in between.
 constexpr uint32_t QCAP_SMALL = 512, QCAP_LARGE = 1024;
+constexpr uint32_t DESC_POS = 0xffffffu;          // a descriptor's position bits (relative to the visit; the visit moves its base before they run out)
 
 // ------------------------------------------------------------------------------------------
 // per-lane byte classes of 16 bytes
@@ -335,6 +336,12 @@ struct WaveState {
     uint32_t ring_lo;            // smallest relative position the byte ring still holds
     uint32_t rel_se1;            // relative position of the span's last byte: the visit ends with the first line end at or past it
     uint32_t last_e;             // relative position of the last boundary that counted before the head descriptor (its field starts behind it)
+    uint32_t last_ord;           // ... and its ordinal among the visit's boundaries (mod 256)
+    uint32_t tok_ord;            // tokeniser: boundaries of the visit so far (descriptors carry it mod 256)
+    uint32_t tok_prevb;          // tokeniser: the byte before the next chunk is a boundary
+    bool tok_bs;                 // tokeniser: the chunk before held a backslash
+    bool far;                    // the boundary at last_e lies further back than a descriptor can say: far_abs is its position
+    uint64_t far_abs;
     bool first_pending;          // the head descriptor is the visit's sentinel: the line end before the first owned row
     bool ignoring;               // the visit began inside a row of the span before: everything up to that row's end is not ours
     bool prev_nl;                // the boundary before the head descriptor is a line end
@@ -348,17 +355,27 @@ struct WaveState {
 // entries were created.  DEFER: fields that need the general form are queued for k_pass1_deferred instead of
 // being handled here (the general form costs this kernel a fifth of its registers and a wave per SIMD).
 // TRIM: convertDWfile -t -- trailing blanks are cut off every field before anything else looks at it (ConvertToZDW.cpp:295-313).
-template <bool DEFER, bool TRIM, uint32_t QCAP>
+template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP>
 __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const DictTable &d, const P1Lds &L, WaveState &ws, uint32_t cnt,
                                             uint32_t lane)
 {
     constexpr uint32_t QM = QCAP * 4u - 1u;
     const bool live = lane < cnt;
     const uint32_t di = ws.q_head + lane;
-    const uint32_t e_pos = lds_u32(ws.desc | ((di << 2) & QM));
+    // a descriptor: position of the boundary (24 bits, relative to the visit) | its ordinal among the visit's boundaries (8 bits).
+    // Tabs that directly follow a boundary -- empty fields -- have no descriptor (the tokeniser drops them): the ordinals of two
+    // neighbours tell how many were skipped between them.
+    // (SKIP: the kernel for tables of mostly empty fields.  Without it a descriptor is the position alone, every boundary has one,
+    // and everything about ordinals below folds away.)
+    const uint32_t dsc = lds_u32(ws.desc | ((di << 2) & QM));
+    const uint32_t e_pos = SKIP ? dsc & DESC_POS : dsc;
     // the boundary before mine: my left neighbour's, lane 0: the last one of the batch before (one DPP move, no second LDS read)
-    uint32_t pe_pos = (uint32_t)__builtin_amdgcn_update_dpp((int)ws.last_e, (int)e_pos, DPP_WAVE_SHR1, 0xf, 0xf, false);
-    const uint32_t e_last = lane_value(e_pos, (int)cnt - 1);
+    uint32_t pdsc = (uint32_t)__builtin_amdgcn_update_dpp((int)(SKIP ? ws.last_e | (ws.last_ord << 24) : ws.last_e), (int)dsc, DPP_WAVE_SHR1, 0xf, 0xf, false);
+    uint32_t pe_pos = SKIP ? pdsc & DESC_POS : pdsc;
+    uint32_t n_prev = (SKIP && live) ? ((dsc >> 24) - (pdsc >> 24) - 1u) & 0xffu : 0u;      // empty fields skipped between that boundary and my field
+    bool far_me = SKIP && ws.far && lane == 0;                           // my field begins behind a boundary too far back for a descriptor
+    const uint32_t d_last = lane_value(dsc, (int)cnt - 1);
+    const uint32_t e_last = SKIP ? d_last & DESC_POS : d_last;
     // ---- what kind of boundary is mine?  The tokeniser only said "a tab or a newline": the byte itself and the one
     // ---- before it (a backslash?) come from the byte ring
     const uint32_t ea = ws.bytes + (e_pos & (BYTE_RING - 1u));
@@ -390,7 +407,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         // a visit that began inside a row of the span before: that row's end is the line end before our first row
         if (ws.ignoring) {
             const uint64_t nl0 = __ballot(e_nl);
-            if (!nl0) { ws.last_e = e_last; return 0; }                 // all of it foreign
+            if (!nl0) { ws.last_e = e_last; ws.last_ord = d_last >> 24; ws.far = false; return 0; }                 // all of it foreign
             sent_lane = (uint32_t)lowest_bit(nl0);
             if (lane < sent_lane) { dead = true; e_nl = false; }
             ws.ignoring = false;
@@ -403,7 +420,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         }
     }
     const uint64_t nlm = __ballot(e_nl);                               // line ends that count
-    uint32_t fs = pe_pos + 1u;                                          // a field begins one byte after the boundary before it
+    uint32_t fs = pe_pos + 1u + n_prev;                                 // a field begins one byte after the boundary before it and the tabs dropped behind that
     uint32_t raw_len, len, row, col;
     bool in_block, is_field;
     if (nlm == 0 && vm == 0 && !ws.first_pending) {
@@ -412,12 +429,19 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         // twenty of a table of mostly empty fields.)
         raw_len = len = e_pos - fs;
         row = ws.row_cur;
-        col = ws.col_cur + lane;
+        if (SKIP) {
+            const uint32_t incl = wave_incl_sum(dead ? 0u : n_prev + 1u);      // columns: one per field, skipped ones included
+            col = ws.col_cur + incl - 1u;
+            ws.col_cur += lane_value(incl, 63);
+        } else {
+            col = ws.col_cur + lane;
+            ws.col_cur += cnt;
+        }
         in_block = row < a.row_limit;
         is_field = !dead & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) & !(a.debug_skip & 1u);
-        ws.col_cur += cnt;
         ws.prev_nl = false;
-        ws.last_e = e_last;
+        ws.last_e = e_last; ws.last_ord = d_last >> 24;
+        ws.far = false;
     } else {
     const bool sentinel = lane == sent_lane;
     uint32_t pnl = wave_shr1(e_nl ? 1u : 0u);                           // the boundary before mine is a line end?
@@ -430,26 +454,45 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         if (!dead && before) {
             const int p = highest_bit(before);
             if ((uint32_t)p + 1u != lane) {
-                pe_pos = lds_u32(ws.desc | (((ws.q_head + (uint32_t)p) << 2) & QM));
-                fs = pe_pos + 1u;
+                pdsc = lds_u32(ws.desc | (((ws.q_head + (uint32_t)p) << 2) & QM));
+                pe_pos = SKIP ? pdsc & DESC_POS : pdsc;
+                // (the descriptors between that one and mine are escaped separators: kept, no fields)
+                if (SKIP) n_prev = ((dsc >> 24) - (pdsc >> 24) - 1u - (lane - (uint32_t)p - 1u)) & 0xffu;
+                fs = pe_pos + 1u + n_prev;
                 pnl = (uint32_t)(nlm >> p) & 1u;
+                far_me = false;
             }
         } else if (!dead && lane > 0) {                                 // none in this batch: the one before the batch
             pe_pos = ws.last_e;
-            fs = pe_pos + 1u;
+            if (SKIP) n_prev = ((dsc >> 24) - ws.last_ord - 1u - lane) & 0xffu;
+            fs = pe_pos + 1u + n_prev;
             pnl = ws.prev_nl ? 1u : 0u;
+            far_me = SKIP && ws.far;
         }
     }
+    if (sentinel) n_prev = 0u;
     raw_len = len = e_pos - fs;
-    const bool blank = e_nl & (pnl != 0) & (len == 0) & !sentinel;    // line end right after a line end: no row (getnextrow.cpp:38-43)
+    const bool blank = e_nl & (pnl != 0) & (len == 0) & (n_prev == 0u) & !sentinel;    // line end right after a line end: no row (getnextrow.cpp:38-43)
     const bool ends_row = e_nl & !blank & !sentinel;
-    row = ws.row_cur; col = ws.col_cur + lane;
+    // columns: every boundary that counts ends a field, and n_prev more (empty ones) lie in front of it; a line end starts over
+    uint32_t incl = 0, incl_all = 0, incl_at_last_nl = 0;
+    if (SKIP) {
+        incl = wave_incl_sum((dead | sentinel) ? 0u : n_prev + 1u);
+        incl_all = lane_value(incl, 63);
+    }
+    row = ws.row_cur; col = SKIP ? ws.col_cur + incl - 1u : ws.col_cur + lane;
     uint64_t rm = 0;
     if (nlm) {
         rm = __ballot(ends_row);
         row += mbcnt64(rm);
         const uint64_t prev = nlm & mask_lt((int)lane);
-        if (prev) col = lane - 1u - (uint32_t)highest_bit(prev);
+        if (SKIP) {
+            const uint32_t incl_prev_nl = (uint32_t)__shfl((int)incl, prev ? highest_bit(prev) : 0, 64);      // (every lane takes part in the exchange)
+            if (prev) col = incl - incl_prev_nl - 1u;
+            incl_at_last_nl = lane_value(incl, highest_bit(nlm));
+        } else if (prev) {
+            col = lane - 1u - (uint32_t)highest_bit(prev);
+        }
         // rows of 16383 bytes or more can grow the reference's line buffer (m_LongestLine): the host replays exactly those.
         // Only a batch whose last line end lies that far past the start of the open row can hold one.
         const int h = highest_bit(nlm);
@@ -465,7 +508,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         }
         ws.row_start = abs_h + 1;
     }
-    if (vm) {
+    if (!SKIP && vm) {
         // columns count the boundaries that count
         const uint64_t before = realm & mask_lt((int)lane), prev = nlm & mask_lt((int)lane);
         col = prev ? popc64(before & ~mask_le(highest_bit(prev))) : ws.col_cur + popc64(before);
@@ -481,28 +524,60 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                !(a.debug_skip & 1u);
     // state for the next call
     ws.row_cur += popc64(rm);
+    if (SKIP) ws.col_cur = nlm ? incl_all - incl_at_last_nl : ws.col_cur + incl_all;
+    else if (vm) ws.col_cur = nlm ? popc64(realm & ~mask_le(highest_bit(nlm))) : ws.col_cur + popc64(realm);
+    else ws.col_cur = nlm ? cnt - 1u - (uint32_t)highest_bit(nlm) : ws.col_cur + cnt;
     if (vm) {
-        ws.col_cur = nlm ? popc64(realm & ~mask_le(highest_bit(nlm))) : ws.col_cur + popc64(realm);
         if (realm) {                     // the next batch's first field begins behind the last boundary that counted
             const int h = highest_bit(realm);
             ws.prev_nl = ((nlm >> h) & 1ull) != 0;
-            ws.last_e = lane_value(e_pos, h);
+            ws.last_e = SKIP ? lane_value(dsc, h) & DESC_POS : lane_value(dsc, h);
+            ws.far = false;
         }
+        ws.last_ord = d_last >> 24;      // (escaped separators behind that boundary have descriptors and ordinals of their own: as if it were the last of them)
     } else {
-        ws.col_cur = nlm ? cnt - 1u - (uint32_t)highest_bit(nlm) : ws.col_cur + cnt;
         ws.prev_nl = ((nlm >> (cnt - 1u)) & 1ull) != 0;          // (lanes a foreign row or the end of the visit took out: nothing reads it then)
-        ws.last_e = e_last;
+        ws.last_e = e_last; ws.last_ord = d_last >> 24;
+        ws.far = false;
     }
     ws.first_pending = false;
     }
 
     // tables of mostly empty fields: the record matrix was zeroed beforehand (one streaming write instead of a scattered 4- or
     // 8-byte store per empty field), so an empty field -- no record but zero, no range, no string (ConvertToZDW.cpp:340-341) -- is done
+    // the empty fields in front of mine have no descriptor of their own: their records are zeroed here (unless the whole matrix was)
+    if (SKIP && !a.rec_zeroed) {
+        const bool mine = !dead & in_block & !(a.debug_skip & 5u);
+        uint32_t k = mine ? n_prev : 0u;
+        while (__ballot(k != 0u)) {
+            if (k) {
+                const uint32_t c = col - k;                                  // (col < k: a row with too many fields, reported at its end)
+                if (c < a.ncols) {
+                    uint32_t ck, co;
+                    if (t.cols_in_lds) { const uint32_t m = lds_u32(t.meta + 4u * c); ck = m & 3u; co = m >> 16; }
+                    else { ck = a.col_kind[c]; co = a.col_recoff[c]; }
+                    uint8_t *zp = a.rec + (uint64_t)row * a.rec_stride + co;
+                    if (ck == K_TEXT) *reinterpret_cast<uint32_t *>(zp) = 0u; else *reinterpret_cast<uint64_t *>(zp) = 0ull;
+                }
+                --k;
+            }
+        }
+    }
     if (a.rec_zeroed) is_field = is_field & (raw_len != 0);
+    // a field that begins further back than a descriptor can say (the visit moved its base past its start): the general form
+    uint64_t abs_start = ws.vbase + fs;
+    if (SKIP && __ballot(far_me)) {
+        if (far_me) {
+            abs_start = ws.far_abs + 1u + n_prev;
+            const uint64_t l64 = ws.vbase + e_pos - abs_start;
+            if (l64 >= (1ull << 30)) { a.st->nul_seen = 2; }                // a single field of 1 GiB or more
+            raw_len = len = (uint32_t)l64;
+        }
+    }
     uint32_t meta = 0;
     if (is_field && t.cols_in_lds) meta = lds_u32(t.meta + 4u * col);
     const uint32_t kind = meta & 3u;
-    bool slow = is_field && (!t.cols_in_lds || (!TRIM && a.trim != 0) || fs < ws.ring_lo);
+    bool slow = is_field && (!t.cols_in_lds || (!TRIM && a.trim != 0) || fs < ws.ring_lo || far_me);
     const uint32_t ra = ws.bytes + (fs & (BYTE_RING - 1u));
     if (TRIM) {
         if (is_field && !slow && len) {
@@ -558,7 +633,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 } else if (w.key == 0) {
                     if (nid >= a.id_cap) { a.st->overflow = 1; }
                     else {
-                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, ws.vbase + fs, len, a.uniq_pos, a.uniq_len, c0, c1, c2);
+                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, a.uniq_pos, a.uniq_len, c0, c1, c2);
                         if (old == 0) { is_new = true; id = nid + 1; } else slow = true;          // lost the race: general form
                     }
                     pending = false;
@@ -642,20 +717,20 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + qs) = cur + k;
             if (slow) {
                 if (qb < a.dq_cap) {
-                    a.dq[2ull * qb] = (ws.vbase + fs) | ((uint64_t)col << 40);
+                    a.dq[2ull * qb] = abs_start | ((uint64_t)col << 40);
                     a.dq[2ull * qb + 1] = (uint64_t)raw_len | ((uint64_t)row << 32);
                 } else {
                     a.st->deferred_lost = 1;
                 }
             }
         } else {
-            if (slow) process_field_general(a, t, d, ws.ids, ws.vbase + fs, raw_len, col, row, in_block, is_new);
+            if (slow) process_field_general(a, t, d, ws.ids, abs_start, raw_len, col, row, in_block, is_new);
             adopt_ids(ws.ids, sm);
         }
     }
     return popc64(__ballot(is_new));
 }
-template <bool DEFER, bool TRIM, uint32_t QCAP>
+template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP>
 __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass1Args a)
 {
     constexpr uint32_t QM = QCAP * 4u - 1u;
@@ -692,6 +767,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     ws.bytes = L.bytes + wv * RING_STRIDE + RING_HEAD;
     ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.rel_se1 = 0; ws.first_pending = false; ws.vbase = 0;
     ws.ignoring = false; ws.prev_nl = false; ws.done = false; ws.row_start = 0; ws.last_e = 0;
+    ws.last_ord = 255u; ws.tok_ord = 0; ws.tok_prevb = 0; ws.tok_bs = false; ws.far = false; ws.far_abs = 0;
     ws.ids.cur = ws.ids.end = 0;
     if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
@@ -727,9 +803,12 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         ws.prev_nl = false; ws.done = false;
         ws.row_start = ss;
         ws.last_e = (uint32_t)(ss - 1 - ws.vbase);
+        ws.last_ord = 255u;                  // (the first boundary of the visit has ordinal 0)
+        ws.tok_ord = 0; ws.tok_bs = false; ws.far = false; ws.far_abs = 0;
+        ws.tok_prevb = at_row_start ? 1u : 0u;      // the byte before the visit's first row is a line end: tabs right at its start are empty fields
         if (at_row_start) {
             // (every lane stores the same word: a branch on the lane number here would make q_count divergent for the compiler)
-            *reinterpret_cast<uint32_t *>(zdw_lds + ws.desc) = (uint32_t)(ss - 1 - ws.vbase);
+            *reinterpret_cast<uint32_t *>(zdw_lds + ws.desc) = (uint32_t)(ss - 1 - ws.vbase) | (SKIP ? 255u << 24 : 0u);
             ws.q_count = 1;
         }
 
@@ -743,12 +822,16 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         auto set_rels = [&]() { rel_ss = rel31(ss); ws.rel_se1 = rel31(se - 1); rel_hi = rel31(a.hi); };
         set_rels();
 
-        auto emit = [&](uint32_t bits, uint32_t pos, uint32_t first_slot) {     // this lane's boundaries `bits` (bit i = byte pos + i) from ring slot first_slot on
+        // this lane's kept boundaries `bits` (bit i = byte pos + i) from ring slot first_slot on; `all`: every boundary of the lane's
+        // 16 bytes, ord0: the ordinal of the first of them
+        auto emit = [&](uint32_t bits, uint32_t all, uint32_t ord0, uint32_t pos, uint32_t first_slot) {
             uint32_t qoff = first_slot << 2;
             while (bits) {
                 const uint32_t i = (uint32_t)__builtin_ctz(bits);
                 bits &= bits - 1;
-                *reinterpret_cast<uint32_t *>(zdw_lds + (ws.desc | (qoff & QM))) = pos + i;
+                uint32_t dv = pos + i;
+                if (SKIP) dv |= (ord0 + (uint32_t)__builtin_popcount(all & ((1u << i) - 1u))) << 24;
+                *reinterpret_cast<uint32_t *>(zdw_lds + (ws.desc | (qoff & QM))) = dv;
                 qoff += 4;
             }
         };
@@ -777,7 +860,9 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         //   step END    the image ended: whatever is pending
         enum : uint32_t { STEP_A = 0, STEP_B = 1, STEP_PIECE = 2, STEP_END = 3 };
         uint32_t step = relb < rel_hi ? STEP_A : STEP_END, piece = 0, piece_stop = 8;
-        uint32_t mA = 0, mB = 0, ex2 = 0, tot2 = 0;
+        uint32_t mA = 0, mB = 0, ex2 = 0, tot2 = 0;          // kept boundaries of the round's chunks; exclusive prefix / total of their counts (A | B << 16)
+        uint32_t bA = 0, bB = 0, exb2 = 0, totb2 = 0;        // all boundaries: the same
+        uint32_t ord_round = 0;                              // ordinal of the round's first boundary
         bool rebase = false, near_end = false;
         for (;;) {
             uint32_t keep = 0;                    // descriptors that may stay pending after this step
@@ -787,47 +872,79 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                 // a vmcnt(0) that waits for the chunk the moment it is requested)
                 const bool second = step == STEP_B;
                 const uint32_t at = (relb & (BYTE_RING - 1u)) + (second ? WROUND : 0u);     // 0, 1024, 2048 or 3072 (the base is a multiple of the ring)
-                uint32_t mN;
+                uint32_t mN, bN;
                 {
                     const uint4 v = P;
                     *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + at + 16u * lane) = v;
                     if (at == 0 && lane < RING_TAIL / 16u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes + BYTE_RING + 16u * lane) = v;
                     if (at == BYTE_RING - WROUND && lane == 63u) *reinterpret_cast<uint4 *>(zdw_lds + ws.bytes - RING_HEAD) = v;      // the ring's last 16 bytes, in front of it
-                    mN = boundaries16(v);
+                    // Every tab or newline is a boundary.  A tab that directly follows a boundary ends an EMPTY field: it gets no
+                    // descriptor (the fields that do carry the ordinal of their boundary, so the lane that handles one sees how many
+                    // were skipped in front of it) -- unless a backslash is near (this chunk or the one before): whether a boundary
+                    // is escaped is only decided by the lane that handles it, so there every boundary keeps its descriptor.  Every
+                    // 128th byte keeps its descriptor too: the ordinals of two neighbours then differ by less than 256.
+                    const uint32_t m0 = tab_or_nl7(v.x), m1 = tab_or_nl7(v.y), m2 = tab_or_nl7(v.z), m3 = tab_or_nl7(v.w);
+                    bN = pack16(m0, m1, m2, m3);
+                    mN = bN;
+                    if (SKIP) {      // (tables of mostly empty fields; for others the bookkeeping costs more than the lanes it saves)
+                        const uint32_t n0 = m0 & (v.x << 6), n1 = m1 & (v.y << 6), n2 = m2 & (v.z << 6), n3 = m3 & (v.w << 6);      // 0x0a, not 0x09: bit 1
+                        uint32_t nl16 = 0;
+                        if (n0 | n1 | n2 | n3) nl16 = pack16(n0, n1, n2, n3);
+                        const uint32_t x0 = v.x ^ 0x5c5c5c5cu, x1 = v.y ^ 0x5c5c5c5cu, x2 = v.z ^ 0x5c5c5c5cu, x3 = v.w ^ 0x5c5c5c5cu;
+                        const uint32_t hz = (((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1) | ((x2 - 0x01010101u) & ~x2) | ((x3 - 0x01010101u) & ~x3)) & 0x80808080u;
+                        const bool bs_here = __ballot(hz != 0u) != 0ull;
+                        const uint32_t prevbit = (uint32_t)__builtin_amdgcn_update_dpp((int)ws.tok_prevb, (int)(bN >> 15), DPP_WAVE_SHR1, 0xf, 0xf, false);
+                        uint32_t drop = bN & ~nl16 & ((bN << 1) | prevbit) & 0xffffu;
+                        if ((lane & 7u) == 0u) drop &= ~1u;
+                        if (bs_here | ws.tok_bs) drop = 0u;
+                        mN = bN & ~drop;
+                        ws.tok_bs = bs_here;
+                        ws.tok_prevb = lane_value(bN >> 15, 63);
+                    }
                 }
                 // (the chunk's registers are dead here: the next one is loaded into the same ones.  Requested while its
                 // predecessor is still looked at it would land in other registers and be copied over at the loop's end,
                 // behind a wait for it)
                 uint32_t ahead = second ? ROUND : WROUND;
-                asm volatile("" : "+v"(mN), "+v"(ahead));      // (an empty statement both values pass through: the boundaries are found before the address of the load exists)
+                asm volatile("" : "+v"(mN), "+v"(bN), "+v"(ahead));      // (an empty statement both values pass through: the boundaries are found before the address of the load exists)
                 P = load_chunk(lane_ptr + ahead);
                 constexpr bool DENSE = QCAP == QCAP_LARGE;      // boundaries of a chunk are emitted right away (two prefix sums per round)
                 if (!second) ws.ring_lo = relb + WROUND > BYTE_RING + first_rel ? relb + WROUND - BYTE_RING : first_rel;      // the ring holds [relb - 3072, relb + 1024)
                 else ws.ring_lo = relb > ROUND + first_rel ? relb - ROUND : first_rel;                                         // ... now [relb - 2048, relb + 2048)
                 if (!second && !DENSE) {
-                    mA = mN;
+                    mA = mN; bA = bN;
                     keep = 63;
                     step = STEP_B;
                 } else {
-                if (second) { mB = mN; if (DENSE) mA = 0; } else { mA = mN; mB = 0; }
+                if (second) { mB = mN; bB = bN; if (DENSE) { mA = 0; bA = 0; } } else { mA = mN; bA = bN; mB = 0; bB = 0; }
                 const uint32_t lrel = relb + 16u * lane;                                      // relative position of my first byte of chunk A
                 // positions that exist for this visit: [ss, hi)
                 if (relb < rel_ss || relb + ROUND > rel_hi) {
-                    mA &= valid16r(lrel, rel_ss, rel_hi);
-                    mB &= valid16r(lrel + WROUND, rel_ss, rel_hi);
+                    const uint32_t va = valid16r(lrel, rel_ss, rel_hi), vb = valid16r(lrel + WROUND, rel_ss, rel_hi);
+                    mA &= va; bA &= va;
+                    mB &= vb; bB &= vb;
                 }
                 // one prefix sum for both chunks; descriptors of A, then of B.  The ring always keeps the head's
                 // predecessor, so it can take QCAP - 1 - pending new descriptors.
                 static_assert(QCAP >= 256 + 2, "a drained ring must take one 16-lane piece");
                 const uint32_t cnts = (uint32_t)__builtin_popcount(mA) | ((uint32_t)__builtin_popcount(mB) << 16);
                 ex2 = wave_excl_sum(cnts, lane, tot2);
+                if (SKIP) {
+                    const uint32_t cntb = (uint32_t)__builtin_popcount(bA) | ((uint32_t)__builtin_popcount(bB) << 16);
+                    exb2 = wave_excl_sum(cntb, lane, totb2);
+                } else {
+                    exb2 = ex2; totb2 = tot2;          // every boundary has its descriptor
+                }
                 const uint32_t totA = tot2 & 0xffffu, nb_total = totA + (tot2 >> 16);
+                ord_round = ws.tok_ord;
+                const uint32_t ordA = ord_round + (exb2 & 0xffffu), ordB = ord_round + (totb2 & 0xffffu) + (exb2 >> 16);      // ordinals of this lane's first boundaries
+                ws.tok_ord += (totb2 & 0xffffu) + (totb2 >> 16);
                 near_end = relb + ROUND > ws.rel_se1 || relb + ROUND >= rel_hi;          // the span ends in this round or has ended: find the visit's end promptly
                 if (relb < a.rebase_at && ws.q_count + nb_total <= QCAP - 1) {
                     // the common round: everything fits
                     const uint32_t tail = ws.q_head + ws.q_count;
-                    emit(mA, lrel, tail + (ex2 & 0xffffu));
-                    emit(mB, lrel + WROUND, tail + totA + (ex2 >> 16));
+                    emit(mA, bA, ordA, lrel, tail + (ex2 & 0xffffu));
+                    emit(mB, bB, ordB, lrel + WROUND, tail + totA + (ex2 >> 16));
                     ws.q_count += nb_total;
                     keep = near_end ? 0u : 127u;
                     if (second) {
@@ -848,7 +965,12 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                     // nothing is pending: move the visit base up; the boundary before the head moves with it
                     const uint32_t delta = (relb - 2u * BYTE_RING) & ~(BYTE_RING - 1u);
                     if (!ws.first_pending) {
-                        if (ws.last_e < delta) { ws.last_e = delta; if (lane == 0) a.st->nul_seen = 2; }      // a single field of 1 GiB or more
+                        // (a field that began further back than the new base: its start is kept as an absolute position)
+                        if (ws.last_e < delta) {
+                            if (!SKIP) { if (lane == 0) a.st->nul_seen = 2; }             // a single field of 1 GiB or more
+                            else if (!ws.far) { ws.far = true; ws.far_abs = ws.vbase + ws.last_e; }
+                            ws.last_e = delta;
+                        }
                         ws.last_e -= delta;
                     }
                     ws.vbase += delta; ws.ring_lo -= delta; relb -= delta;
@@ -863,7 +985,8 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                 const uint32_t piece_end = first_lane == 48u ? tot : lane_value(ex, (int)first_lane + 16);
                 const bool active = (lane >> 4) == (piece & 3u);
                 const uint32_t lrel = relb + 16u * lane;
-                emit(active ? (inB ? mB : mA) : 0u, inB ? lrel + WROUND : lrel, ws.q_head + ws.q_count + ex - piece_base);
+                emit(active ? (inB ? mB : mA) : 0u, inB ? bB : bA, inB ? ord_round + (totb2 & 0xffffu) + (exb2 >> 16) : ord_round + (exb2 & 0xffffu),
+                     inB ? lrel + WROUND : lrel, ws.q_head + ws.q_count + ex - piece_base);
                 ws.q_count += piece_end - piece_base;
                 if (++piece == piece_stop) {
                     keep = near_end ? 0u : 127u;
@@ -881,7 +1004,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
             while (!ws.done && ws.q_count > keep) {
                 const uint32_t cnt = ws.q_count < 64u ? ws.q_count : 64u;
                 if (a.debug_skip & 32u) { if (near_end && ws.q_count <= 64u) ws.done = true; }      // profiling only: the tokeniser alone
-                else new_entries += consume<DEFER, TRIM, QCAP>(a, t, d, L, ws, cnt, lane);
+                else new_entries += consume<DEFER, TRIM, QCAP, SKIP>(a, t, d, L, ws, cnt, lane);
                 ws.q_head += cnt;
                 ws.q_count -= cnt;
             }
@@ -963,17 +1086,22 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     if (!a.nspans) return;
     const bool defer = a.dq != nullptr;
     const bool trim = a.trim != 0;
-    const bool large = a.dense_boundaries != 0;
-    const size_t lds = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, large ? QCAP_LARGE : QCAP_SMALL).total;
+    // three forms of the kernel: the ordinary one; a descriptor ring of 1024 for inputs with many boundaries per round; and, for
+    // tables of mostly empty fields, the one whose tokeniser gives the tabs of empty fields no descriptors (few are left: the small ring)
+    const uint32_t mode = a.skip_empty ? 2u : (a.dense_boundaries ? 1u : 0u);
+    const size_t lds = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, mode == 1u ? QCAP_LARGE : QCAP_SMALL).total;
     // Waves walk the spans with a grid stride, so every wave carries the same share of the block: the grid
     // must not exceed what is resident at once, or the surplus waves run alone after the others finish.
     int per_cu = 0, dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     typedef void (*P1Fn)(const Pass1Args);
-    static const P1Fn fns[2][2][2] = {{{k_pass1<false, false, QCAP_SMALL>, k_pass1<false, false, QCAP_LARGE>}, {k_pass1<false, true, QCAP_SMALL>, k_pass1<false, true, QCAP_LARGE>}},
-                                      {{k_pass1<true, false, QCAP_SMALL>, k_pass1<true, false, QCAP_LARGE>}, {k_pass1<true, true, QCAP_SMALL>, k_pass1<true, true, QCAP_LARGE>}}};
-    const P1Fn kfn = fns[defer][trim][large];
+    static const P1Fn fns[2][2][3] = {
+        {{k_pass1<false, false, QCAP_SMALL, false>, k_pass1<false, false, QCAP_LARGE, false>, k_pass1<false, false, QCAP_SMALL, true>},
+         {k_pass1<false, true, QCAP_SMALL, false>, k_pass1<false, true, QCAP_LARGE, false>, k_pass1<false, true, QCAP_SMALL, true>}},
+        {{k_pass1<true, false, QCAP_SMALL, false>, k_pass1<true, false, QCAP_LARGE, false>, k_pass1<true, false, QCAP_SMALL, true>},
+         {k_pass1<true, true, QCAP_SMALL, false>, k_pass1<true, true, QCAP_LARGE, false>, k_pass1<true, true, QCAP_SMALL, true>}}};
+    const P1Fn kfn = fns[defer][trim][mode];
     const void *fn = (const void *)kfn;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
     const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules

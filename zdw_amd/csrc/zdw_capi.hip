@@ -166,6 +166,7 @@ struct zdw_ctx {
         slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
     uint64_t nuniq = 0, dict_size = 0, extra_bytes = 0;
     uint64_t avg_row = 0;         // bytes per row, sampled at the start of the input
+    bool skip_empty = false;      // ... and: most of its fields are empty
     bool dense_boundaries = false; // ... and whether fields are so short that pass 1 takes its large descriptor ring
     uint32_t nids = 0;            // unique ids handed out in this block (holes included): entries of id_off
     uint32_t id_cap = 0;                   // capacity of uniq_pos / uniq_len (unique ids, holes included)
@@ -325,14 +326,20 @@ int sample_input(zdw_ctx *c)
 {
     c->avg_row = 0;
     c->dense_boundaries = false;
+    c->skip_empty = false;
     if (!c->n) return ZDW_OK;
     uint8_t sample[1 << 16];
     const uint64_t take = std::min<uint64_t>(sizeof sample, c->n);
     HIP_TRY(c, hipMemcpyAsync(sample, c->d_in, take, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    uint64_t lines = 0, tabs = 0;
-    for (uint64_t i = 0; i < take; ++i) { lines += sample[i] == '\n'; tabs += sample[i] == '\t'; }
+    uint64_t lines = 0, tabs = 0, empties = 0;
+    for (uint64_t i = 0; i < take; ++i) {
+        lines += sample[i] == '\n'; tabs += sample[i] == '\t';
+        empties += sample[i] == '\t' && i && (sample[i - 1] == '\t' || sample[i - 1] == '\n');
+    }
     c->avg_row = take / (lines ? lines : 1);
+    // more than half of the fields empty: pass 1 gives tabs that directly follow a boundary no descriptor (k_pass1.hip)
+    c->skip_empty = 2 * empties > lines + tabs;
     // field boundaries per 2 KiB round of pass 1: tables of mostly empty fields get the large descriptor ring
     c->dense_boundaries = take && (lines + tabs) * 2048 / take > 330;
     return ZDW_OK;
@@ -1344,12 +1351,14 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             a.uniq_pos = c->uniq_pos.as<uint64_t>(); a.uniq_len = c->uniq_len.as<uint32_t>(); a.id_cap = c->id_cap;
             a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 8 * 5, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
-            a.rebase_at = 1u << 30;
-            if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::max(16384u, (uint32_t)strtoul(e, nullptr, 10));   // tests
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             a.dense_boundaries = c->dense_boundaries ? 1u : 0u;
             if (const char *e = getenv("ZDW_P1_LARGE_RING")) a.dense_boundaries = atoi(e) != 0;      // tests
-            if (a.dense_boundaries && nrows) {
+            a.skip_empty = c->skip_empty ? 1u : 0u;
+            if (const char *e = getenv("ZDW_P1_SKIP_EMPTY")) a.skip_empty = atoi(e) != 0;      // tests
+            a.rebase_at = a.skip_empty ? 1u << 23 : 1u << 30;              // (descriptors of that form hold 24 bits of position)
+            if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::min(a.rebase_at, std::max(16384u, (uint32_t)strtoul(e, nullptr, 10)));   // tests
+            if ((a.dense_boundaries || a.skip_empty) && nrows) {
                 // mostly empty fields: zero the record matrix in one streaming write; pass 1 then skips every empty field
                 HIP_TRY(c, hipMemsetAsync(c->rec.p, 0, (uint64_t)nrows * c->rec_stride, s));
                 a.rec_zeroed = 1;
