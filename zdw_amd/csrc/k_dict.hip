@@ -700,7 +700,7 @@ void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, 
 {
     if (!count) return;
     DictTable d;
-    d.slots = slots; d.slot_mask = slot_mask; d.uniq_pos = uniq_pos; d.uniq_len = uniq_len; d.id_cap = id_cap; d.st = st;
+    d.slots = slots; d.slot_mask = slot_mask; d.uniq_pos = uniq_pos; d.uniq_len = uniq_len; d.id_cap = id_cap; d.st = st; d.track_first = 0;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

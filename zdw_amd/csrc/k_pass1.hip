@@ -630,10 +630,11 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 if (!pending) continue;
                 if (same) {
                     id = (uint32_t)w.key; pending = false;
+                    if (a.track_first) note_occurrence(a.uniq_pos, id - 1u, abs_start);
                 } else if (w.key == 0) {
                     if (nid >= a.id_cap) { a.st->overflow = 1; }
                     else {
-                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, a.uniq_pos, a.uniq_len, c0, c1, c2);
+                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, a.uniq_pos, a.uniq_len, c0, c1, c2, a.track_first != 0);
                         if (old == 0) { is_new = true; id = nid + 1; } else slow = true;          // lost the race: general form
                     }
                     pending = false;
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     ws.ids.cur = ws.ids.end = 0;
     if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
-    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st;
+    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st; d.track_first = a.track_first;
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
     for (uint32_t si = wave_id; si < a.nspans; si += wave_count) {
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_pass1_deferred(const Pass1Args a, uint3
     ColTables t;
     t.meta = t.mn = t.mx = t.seen = 0; t.cols_in_lds = false;
     DictTable d;
-    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st;
+    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st; d.track_first = a.track_first;
     IdAlloc al;
     al.cur = al.end = 0;
     uint32_t created = 0;

@@ -29,7 +29,26 @@ thread_local std::string g_create_error;
 struct Budget { size_t used = 0, cap = 0; };
 
 static double g_alloc_ms = 0.0;      // time inside hipMalloc / hipFree (ZDW_DEBUG_RETRY prints it)
+struct Lap {      // ZDW_DEBUG_LAPS=1: wall time between marks of one call, on stderr
+    const bool on = getenv("ZDW_DEBUG_LAPS") != nullptr;
+    double t0 = 0, last = 0;
+    std::string line;
+    void mark(const char *what);
+    void done(const char *name);
+};
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void Lap::mark(const char *what)
+{
+    if (!on) return;
+    const double t = now_ms();
+    if (t0 == 0) { t0 = last = t; return; }
+    char b[64];
+    snprintf(b, sizeof b, " %s=%.1f", what, t - last);
+    line += b;
+    last = t;
+}
+void Lap::done(const char *name) { if (on) fprintf(stderr, "[laps] %s:%s total=%.1f ms\n", name, line.c_str(), now_ms() - t0); }
 
 struct DevBuf {
     void *p = nullptr;
@@ -645,10 +664,8 @@ int ensure_dict(zdw_ctx *c)
 // vsize_MB = 2.6 + 64 x arenas + 64 B x strings / 2^20, checked whenever StringHeap takes a new 64 MiB arena; the strings
 // enter the arenas in the order pass 1 first meets them.  Pass 1 has just run over rows [0, nrows): *found = the limit
 // trips inside them, at field *fields - 1 of row *row (that row and everything after it belong to the next block).
-// The order of first occurrences is taken from uniq_pos, the occurrence that won the insertion: exact for strings that
-// occur once (the id-like columns that make dictionaries large); where an earlier occurrence of a string lost the race
-// to a later one the trip can move by that string's bytes -- the split is then not the reference's, the file still is
-// what the reference writes for that split (the re-run with the split hint decides every byte).
+// The order of first occurrences is taken from uniq_pos: while the model drives pass 1 every occurrence of a string takes part
+// in a minimum there (Pass1Args.track_first), so it is the first one whichever occurrence won the insertion.
 constexpr double MODEL_BASE_MB = 2.6, MODEL_NODE_BYTES = 64.0;
 constexpr uint64_t MODEL_ARENA = 64ull << 20;
 
@@ -1174,6 +1191,8 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     if (!c->have_input) return fail(c, ZDW_UNKNOWN_ERROR, "no input set");
     (void)hipSetDevice(c->device);
     hipStream_t s = c->stream;
+    Lap lap;
+    lap.mark("start");
     reset_block(c);
     if (c->oom_seen) {
         // The caller comes back with fewer rows after an allocation failed: buffers sized for the larger attempt would
@@ -1256,6 +1275,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     }
     c->next_lo = c->n;
     if (total_rows >= 0xFFFFFFFFull) return fail(c, ZDW_UNKNOWN_ERROR, "more than 2^32-2 rows in one block");
+    lap.mark("scan");
 
     uint32_t row_limit = 0xFFFFFFFFu, partial = 0;
     bool tripped = false;
@@ -1310,6 +1330,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             return fail(c, e == hipErrorOutOfMemory ? ZDW_OUT_OF_MEMORY : ZDW_UNKNOWN_ERROR, "record matrix of %llu bytes: %s",
                         (unsigned long long)nrows * c->rec_stride, hipGetErrorString(e));
     }
+    lap.mark("rec_alloc");
     const uint64_t blk_bytes = hi > lo ? hi - lo : 0;
     const uint32_t long_cap = (uint32_t)std::min<uint64_t>(blk_bytes / (FIRST_ROW_CAP - 1) + 2, 1u << 26);
     HIP_TRY(c, c->long_rows.ensure((uint64_t)long_cap * sizeof(LongRow)));
@@ -1334,6 +1355,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             if (e != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary table: %s", hipGetErrorString(e));
             c->id_cap = (uint32_t)cap;
         }
+        lap.mark("table_alloc");
         HIP_TRY(c, hipMemsetAsync(c->slots.p, 0, nslots * 32, s));
         HIP_TRY(c, hipMemsetAsync(c->col_min.p, 0xFF, c->ncols * 8 + 8, s));
         HIP_TRY(c, hipMemsetAsync(c->col_max.p, 0, c->ncols * 8 + 8, s));
@@ -1357,6 +1379,10 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 8 * 5, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
+            // the memory-limit model asks in which order the strings are first met: every occurrence takes part in a minimum
+            a.track_first = c->model_max_slots ? 1u : 0u;
+            if (const char *e = getenv("ZDW_P1_TRACK_FIRST")) a.track_first = atoi(e) != 0;      // tests
+            if (a.track_first) HIP_TRY(c, hipMemsetAsync(c->uniq_pos.p, 0xFF, (uint64_t)c->id_cap * 8, s));
             a.dense_boundaries = c->dense_boundaries ? 1u : 0u;
             if (const char *e = getenv("ZDW_P1_LARGE_RING")) a.dense_boundaries = atoi(e) != 0;      // tests
             a.skip_empty = c->skip_empty ? 1u : 0u;
@@ -1409,6 +1435,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
         }
         HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
+        lap.mark("pass1_kernels");
         hipError_t le = hipGetLastError();      // (allocation failures handled above have cleared theirs: DevBuf::ensure)
         if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));
         if (st.nul_seen == 2) return fail(c, ZDW_UNKNOWN_ERROR, "a single field of 1 GiB or more is not supported");
@@ -1468,6 +1495,8 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
         HIP_TRY(c, hipMemcpy(c->h_seen.data(), c->col_seen.p, c->ncols, hipMemcpyDeviceToHost));
     }
     c->p1_done = true;
+    lap.mark("tail");
+    lap.done("pass1_impl");
     if (tripped && nrows == 0) return fail(c, ZDW_OUT_OF_MEMORY, "block limit leaves no room for a single row");
     return ZDW_OK;
 }

@@ -158,11 +158,15 @@ __device__ __forceinline__ void retire_ids(const IdAlloc &al, uint32_t *uniq_len
 // (0 = claimed).  A lost race leaves the id a hole.
 template <bool FACTS_AT_AGENT_SCOPE>
 __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uint32_t id, uint64_t pos, uint32_t len, uint64_t *uniq_pos,
-                                               uint32_t *uniq_len, uint64_t c0, uint64_t c1, uint64_t c2)
+                                               uint32_t *uniq_len, uint64_t c0, uint64_t c1, uint64_t c2, bool track_first = false)
 {
     // Only strings of more than 24 bytes are ever compared against their first occurrence while the pass
     // runs; for the others the facts are read after the kernel, so ordinary (write-back) stores do.
-    if (FACTS_AT_AGENT_SCOPE) {
+    if (track_first) {
+        // (an earlier occurrence that another wave finds in the table a moment from now may get here first: a minimum, not a store)
+        atomicMin(reinterpret_cast<unsigned long long *>(uniq_pos + id), (unsigned long long)pos);
+        __hip_atomic_store(uniq_len + id, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (FACTS_AT_AGENT_SCOPE) {
         __hip_atomic_store(uniq_pos + id, pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(uniq_len + id, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -208,7 +212,16 @@ struct DictTable {
     uint64_t *slots; uint64_t slot_mask;
     uint64_t *uniq_pos; uint32_t *uniq_len; uint32_t id_cap;
     P1Status *st;
+    uint32_t track_first;      // uniq_pos[id] must end up as the string's FIRST occurrence in the image (the memory-limit model needs the
+                               // order in which the reference meets the strings): every occurrence takes part in a minimum.  The
+                               // array starts as all ones.
 };
+
+// an occurrence of unique id `id` (0-based) at image position pos: keep the smallest (ordinary read first: the value only falls)
+__device__ __forceinline__ void note_occurrence(uint64_t *uniq_pos, uint32_t id, uint64_t pos)
+{
+    if (pos < uniq_pos[id]) atomicMin(reinterpret_cast<unsigned long long *>(uniq_pos + id), (unsigned long long)pos);
+}
 
 // BULK: the string is read 96 bytes at a time with all twelve loads of a round in flight together, hashed and
 // compared from registers; the plain form reads 8 bytes at a time and waits for each (one memory latency per step:
@@ -260,7 +273,7 @@ __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, con
         if (!searching) continue;
         if (w.key == 0) {
             if (nid >= d.id_cap) { d.st->overflow = 1; searching = false; continue; }
-            const uint64_t old = claim_slot<true>(slot, make_slot_key(tag, len, nid), nid, pos, len, d.uniq_pos, d.uniq_len, c0, c1, c2);
+            const uint64_t old = claim_slot<true>(slot, make_slot_key(tag, len, nid), nid, pos, len, d.uniq_pos, d.uniq_len, c0, c1, c2, d.track_first != 0);
             if (old == 0) { is_new = true; result = nid + 1; searching = false; continue; }
             w.key = old; w.s0 = 0;                        // somebody else just claimed it
         }
@@ -271,7 +284,11 @@ __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, con
             if (w.s0 == 0) { d.st->overflow = 1; searching = false; continue; }      // cannot happen; never hang on it
             const uint32_t from = 24;                     // bytes [0, 24) are decided by the inline copy
             if (w.s0 == c0 && w.s1 == c1 && w.s2 == c2) {
-                if (from >= len) { result = (uint32_t)w.key; searching = false; continue; }   // len <= 24, equal length bytes: the slot decides
+                if (from >= len) {                                                             // len <= 24, equal length bytes: the slot decides
+                    result = (uint32_t)w.key; searching = false;
+                    if (d.track_first && pos < EXTRA_BASE) note_occurrence(d.uniq_pos, result - 1u, pos);
+                    continue;
+                }
                 // compare the rest against the stored occurrence; with a length byte < 255 both lengths are
                 // known to be equal, so only bytes are compared
                 const uint64_t sp = __hip_atomic_load(d.uniq_pos + ((uint32_t)w.key - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -303,7 +320,11 @@ __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, con
                             eq = stored_ends_here(in, sp, len, hi, trim, (nbs & 1u) != 0);
                         }
                     }
-                    if (eq) { result = (uint32_t)w.key; searching = false; continue; }
+                    if (eq) {
+                        result = (uint32_t)w.key; searching = false;
+                        if (d.track_first && pos < EXTRA_BASE) note_occurrence(d.uniq_pos, result - 1u, pos);
+                        continue;
+                    }
                 }
             }
         }

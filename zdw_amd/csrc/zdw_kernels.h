@@ -56,6 +56,7 @@ struct Pass1Args {
     uint64_t *col_min; uint64_t *col_max; uint8_t *col_seen;
     P1Status *st;
     LongRow *long_rows; uint32_t long_cap;
+    uint32_t track_first;                 // uniq_pos[id] = the string's first occurrence (a minimum over all of them; the array starts as all ones): the memory-limit model
     uint32_t skip_empty;                  // tabs that directly follow a boundary (empty fields) get no descriptor (tables of mostly empty fields)
     uint32_t rebase_at;                   // relative position at which a visit moves its base (2^23: a descriptor holds 24 bits of position; tests lower it)
     uint64_t *dq; uint32_t dq_cap;        // deferred fields (two words each: position | column << 40, length | row << 32); dq == nullptr: none, one kernel does everything
