@@ -293,7 +293,13 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("ZDW_BENCH_FORCE_DIST") == "1"      # measurements: the N > 1 driver with one rank (not a valid bench line)
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -330,7 +336,7 @@ def main():
         if world > 1 and args.independent_blocks:
             blocks = sharded.encode_independent_blocks_dist(enc, rank, world, fetch=False)
             return sum(b[0] for b in blocks), sum(b[1] for b in blocks), sum(b[2] for b in blocks)
-        if world > 1:
+        if world > 1 or force_dist:
             return sharded.encode_shard_dist(enc, rank, world, merge=merge)
         rc, p1 = enc.pass1()
         if rc:
@@ -465,7 +471,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 res["e2e_cli"] = {"error": repr(e)[:200]}
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     enc.close()

@@ -171,6 +171,85 @@ void launch_find_effective_end(const uint8_t *in, uint64_t n, uint64_t lo, uint6
 // Streaming kernel: 1 byte read per input byte; every lane counts the starts among its own bytes
 // and the wave adds up once per span.
 // ------------------------------------------------------------------------------------------
+// rows that start in [ss, se) (this wave's share of the count: the caller adds the lanes up); nul: some byte of it is NUL
+__device__ __forceinline__ uint32_t count_row_starts(const uint8_t *__restrict__ in, uint64_t n, uint64_t lo, uint64_t ss, uint64_t se, uint32_t lane,
+                                                     uint32_t &nul_out)
+{
+    uint32_t mine = 0, nul = 0;
+    if (ss < se) {
+        uint32_t prev_term = ((ss == lo) || is_row_terminator(in, lo, ss - 1)) ? 1u : 0u;
+        const uint64_t pos0 = ss & ~(uint64_t)(WROUND - 1);
+        uint32_t bs_carry = (pos0 > lo && in[pos0 - 1] == '\\') ? 1u : 0u;
+        // four rounds in flight, the next four requested before these are counted: a wave that counts inside pass 1 has only
+        // its own loads to wait for
+        auto round = [&](const uint64_t pos, const uint4 v) {
+            const uint64_t lp = pos + 16ull * lane;
+            if (pos >= ss && pos + WROUND <= se) {
+                // common case -- the round lies inside the span and no newline of it follows a backslash (so every
+                // newline is a row terminator): count in place on the bit-7 flags of the SWAR compares (no compaction
+                // to 16-bit sets)
+                const uint32_t H = 0x80808080u, L1 = 0x01010101u;
+                const uint32_t n0 = ~nz7b(v.x ^ 0x0a0a0a0au) & H, n1 = ~nz7b(v.y ^ 0x0a0a0a0au) & H, n2 = ~nz7b(v.z ^ 0x0a0a0a0au) & H,
+                               n3 = ~nz7b(v.w ^ 0x0a0a0a0au) & H;                           // bit 7 of a byte: it is a newline
+                const uint32_t b0 = v.x ^ 0x5c5c5c5cu, b1 = v.y ^ 0x5c5c5c5cu, b2 = v.z ^ 0x5c5c5c5cu, b3 = v.w ^ 0x5c5c5c5cu;
+                const uint32_t anybs = (((b0 - L1) & ~b0) | ((b1 - L1) & ~b1) | ((b2 - L1) & ~b2) | ((b3 - L1) & ~b3)) & H;     // exact for "some byte is a backslash"
+                bool plain = true;
+                uint32_t carry_next = 0;
+                if (__ballot(anybs != 0) | bs_carry) {
+                    // backslashes about: is one of them right before a newline?
+                    const uint32_t s0 = ~nz7b(b0) & H, s1 = ~nz7b(b1) & H, s2 = ~nz7b(b2) & H, s3 = ~nz7b(b3) & H;   // bit 7: the byte is a backslash
+                    uint32_t sbefore = wave_shr1(s3);
+                    if (lane == 0) sbefore = bs_carry ? 0x80000000u : 0u;
+                    const uint32_t hit = (n0 & __builtin_amdgcn_alignbit(s0, sbefore, 24)) | (n1 & __builtin_amdgcn_alignbit(s1, s0, 24)) |
+                                         (n2 & __builtin_amdgcn_alignbit(s2, s1, 24)) | (n3 & __builtin_amdgcn_alignbit(s3, s2, 24));
+                    plain = __ballot(hit != 0) == 0;
+                    carry_next = lane_value(s3 >> 31, 63);
+                }
+                if (plain) {
+                    uint32_t before = wave_shr1(n3);                                          // the byte before my first one
+                    if (lane == 0) before = prev_term ? 0x80000000u : 0u;
+                    // "the previous byte is a newline" for each of my bytes, then: a row starts where that holds and the byte is none
+                    mine += (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n0, before, 24) & ~n0)
+                          + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n1, n0, 24) & ~n1)
+                          + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n2, n1, 24) & ~n2)
+                          + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n3, n2, 24) & ~n3);
+                    nul |= (((v.x - L1) & ~v.x) | ((v.y - L1) & ~v.y) | ((v.z - L1) & ~v.z) | ((v.w - L1) & ~v.w)) & H;        // exact for "some byte is NUL"
+                    prev_term = lane_value(n3 >> 31, 63);
+                    bs_carry = carry_next;
+                    return;
+                }
+            }
+            Lane16 m;
+            classify16(in, lo, n, lp, v, lane, bs_carry, m, false);
+            uint32_t vm = 0xffffu;
+            if (pos < ss || pos + WROUND > se) vm = valid16(lp, ss, se);      // first / last round of the span
+            const uint32_t nl = m.nl & vm;
+            uint32_t pt = wave_shr1(nl >> 15) | ((nl << 1) & 0xffffu);
+            // the byte before the first position of the span (or before this round) terminated a row
+            if (prev_term) {
+                const uint64_t first = pos > ss ? pos : ss;
+                if (first >= lp && first < lp + 16) pt |= 1u << (uint32_t)(first - lp);
+            }
+            mine += (uint32_t)__builtin_popcount(pt & ~nl & vm);
+            nul |= eq16(v, 0u) & vm;
+            prev_term = lane_value(nl >> 15, 63);
+        };
+        uint4 q0 = load_round16(in, pos0, lane, n), q1 = load_round16(in, pos0 + WROUND, lane, n), q2 = load_round16(in, pos0 + 2 * WROUND, lane, n),
+              q3 = load_round16(in, pos0 + 3 * WROUND, lane, n);
+        for (uint64_t pos = pos0; pos < se; pos += 4 * WROUND) {
+            const uint4 c0 = q0, c1 = q1, c2 = q2, c3 = q3;
+            q0 = load_round16(in, pos + 4 * WROUND, lane, n); q1 = load_round16(in, pos + 5 * WROUND, lane, n);
+            q2 = load_round16(in, pos + 6 * WROUND, lane, n); q3 = load_round16(in, pos + 7 * WROUND, lane, n);
+            round(pos, c0);
+            if (pos + WROUND < se) round(pos + WROUND, c1);
+            if (pos + 2 * WROUND < se) round(pos + 2 * WROUND, c2);
+            if (pos + 3 * WROUND < se) round(pos + 3 * WROUND, c3);
+        }
+    }
+    nul_out = nul;
+    return mine;
+}
+
 __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restrict__ in, uint64_t n, uint64_t lo, uint64_t hi,
                                                           uint64_t span0, uint32_t nspans, uint32_t span_shift,
                                                           uint32_t *__restrict__ span_starts, P1Status *st)
@@ -181,67 +260,8 @@ __global__ __launch_bounds__(64) void k_count_row_starts(const uint8_t *__restri
         const uint64_t s0 = (span0 + si) << span_shift;
         const uint64_t ss = s0 > lo ? s0 : lo;
         const uint64_t se = s0 + SPAN_BYTES < hi ? s0 + SPAN_BYTES : hi;
-        uint32_t mine = 0, nul = 0;
-        if (ss < se) {
-            uint32_t prev_term = ((ss == lo) || is_row_terminator(in, lo, ss - 1)) ? 1u : 0u;
-            const uint64_t pos0 = ss & ~(uint64_t)(WROUND - 1);
-            uint32_t bs_carry = (pos0 > lo && in[pos0 - 1] == '\\') ? 1u : 0u;
-            uint4 nxt = load_round16(in, pos0, lane, n);
-            for (uint64_t pos = pos0; pos < se; pos += WROUND) {
-                const uint4 v = nxt;
-                nxt = load_round16(in, pos + WROUND, lane, n);            // next round in flight while this one is counted
-                const uint64_t lp = pos + 16ull * lane;
-                if (pos >= ss && pos + WROUND <= se) {
-                    // common case -- the round lies inside the span and no newline of it follows a backslash (so every
-                    // newline is a row terminator): count in place on the bit-7 flags of the SWAR compares (no compaction
-                    // to 16-bit sets)
-                    const uint32_t H = 0x80808080u, L1 = 0x01010101u;
-                    const uint32_t n0 = ~nz7b(v.x ^ 0x0a0a0a0au) & H, n1 = ~nz7b(v.y ^ 0x0a0a0a0au) & H, n2 = ~nz7b(v.z ^ 0x0a0a0a0au) & H,
-                                   n3 = ~nz7b(v.w ^ 0x0a0a0a0au) & H;                           // bit 7 of a byte: it is a newline
-                    const uint32_t b0 = v.x ^ 0x5c5c5c5cu, b1 = v.y ^ 0x5c5c5c5cu, b2 = v.z ^ 0x5c5c5c5cu, b3 = v.w ^ 0x5c5c5c5cu;
-                    const uint32_t anybs = (((b0 - L1) & ~b0) | ((b1 - L1) & ~b1) | ((b2 - L1) & ~b2) | ((b3 - L1) & ~b3)) & H;     // exact for "some byte is a backslash"
-                    bool plain = true;
-                    uint32_t carry_next = 0;
-                    if (__ballot(anybs != 0) | bs_carry) {
-                        // backslashes about: is one of them right before a newline?
-                        const uint32_t s0 = ~nz7b(b0) & H, s1 = ~nz7b(b1) & H, s2 = ~nz7b(b2) & H, s3 = ~nz7b(b3) & H;   // bit 7: the byte is a backslash
-                        uint32_t sbefore = wave_shr1(s3);
-                        if (lane == 0) sbefore = bs_carry ? 0x80000000u : 0u;
-                        const uint32_t hit = (n0 & __builtin_amdgcn_alignbit(s0, sbefore, 24)) | (n1 & __builtin_amdgcn_alignbit(s1, s0, 24)) |
-                                             (n2 & __builtin_amdgcn_alignbit(s2, s1, 24)) | (n3 & __builtin_amdgcn_alignbit(s3, s2, 24));
-                        plain = __ballot(hit != 0) == 0;
-                        carry_next = lane_value(s3 >> 31, 63);
-                    }
-                    if (plain) {
-                        uint32_t before = wave_shr1(n3);                                          // the byte before my first one
-                        if (lane == 0) before = prev_term ? 0x80000000u : 0u;
-                        // "the previous byte is a newline" for each of my bytes, then: a row starts where that holds and the byte is none
-                        mine += (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n0, before, 24) & ~n0)
-                              + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n1, n0, 24) & ~n1)
-                              + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n2, n1, 24) & ~n2)
-                              + (uint32_t)__builtin_popcount(__builtin_amdgcn_alignbit(n3, n2, 24) & ~n3);
-                        nul |= (((v.x - L1) & ~v.x) | ((v.y - L1) & ~v.y) | ((v.z - L1) & ~v.z) | ((v.w - L1) & ~v.w)) & H;        // exact for "some byte is NUL"
-                        prev_term = lane_value(n3 >> 31, 63);
-                        bs_carry = carry_next;
-                        continue;
-                    }
-                }
-                Lane16 m;
-                classify16(in, lo, n, lp, v, lane, bs_carry, m, false);
-                uint32_t vm = 0xffffu;
-                if (pos < ss || pos + WROUND > se) vm = valid16(lp, ss, se);      // first / last round of the span
-                const uint32_t nl = m.nl & vm;
-                uint32_t pt = wave_shr1(nl >> 15) | ((nl << 1) & 0xffffu);
-                // the byte before the first position of the span (or before this round) terminated a row
-                if (prev_term) {
-                    const uint64_t first = pos > ss ? pos : ss;
-                    if (first >= lp && first < lp + 16) pt |= 1u << (uint32_t)(first - lp);
-                }
-                mine += (uint32_t)__builtin_popcount(pt & ~nl & vm);
-                nul |= eq16(v, 0u) & vm;
-                prev_term = lane_value(nl >> 15, 63);
-            }
-        }
+        uint32_t nul = 0;
+        const uint32_t mine = count_row_starts(in, n, lo, ss, se, lane, nul);
         uint32_t total;
         wave_excl_sum(mine, lane, total);
         const uint64_t anynul = __ballot(nul != 0);
@@ -775,12 +795,8 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st; d.track_first = a.track_first;
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
-    for (uint32_t si = wave_id; si < a.nspans; si += wave_count) {
-        // (values loaded from memory count as divergent for the compiler even when the address is wave-uniform: a branch on
-        // one would put the rest of the loop body under an exec mask and its bookkeeping into vector registers)
-        const uint32_t rowbase = uniform32(a.span_rowbase[si]);
-        if (uniform32(a.span_rowbase[si + 1]) == rowbase) continue;          // no row starts in this span
-        if (rowbase > a.row_limit) break;                         // later spans hold rows of later blocks only
+    const bool fold = a.span_state != nullptr;      // no row scan has run: spans by ticket, their rows counted here
+    for (uint32_t si = wave_id;; si += wave_count) {
         if (uniform32(*reinterpret_cast<volatile const uint32_t *>(&a.st->overflow))) break;      // an ordinary (cached) read: a stale 0 only delays the exit
         if (new_entries >= 128) {        // publish this wave's inserts in bulk; stop everybody once the table is half full
             uint32_t seen_total = 0;
@@ -789,6 +805,62 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
             new_entries = 0;
             if (seen_total >= a.max_entries) { a.st->overflow = 1; break; }          // (every lane stores: a branch on the lane number next to a break makes the loop's exit divergent for the compiler)
         }
+        uint32_t rowbase, rows_here;
+        if (fold) {
+            // (nothing between taking a span and publishing its count may leave the loop: the spans behind it wait for that count)
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&a.st->next_span, 1u);
+            si = lane_value(t, 0);
+            if (si >= a.nspans) break;
+            const uint64_t f0 = (a.span0 + si) << a.span_shift;
+            const uint64_t fs0 = f0 > a.lo ? f0 : a.lo, fe0 = f0 + (1ull << a.span_shift) < a.hi ? f0 + (1ull << a.span_shift) : a.hi;
+            uint32_t nul = 0;
+            const uint32_t mine = count_row_starts(a.in, a.n, a.lo, fs0, fe0, lane, nul);
+            (void)wave_excl_sum(mine, lane, rows_here);
+            rows_here = uniform32(rows_here);
+            if (__ballot(nul != 0)) a.st->nul_seen = 1;
+            uint64_t before = 0;                             // rows that start in the spans before this one
+            if (si) {
+                __hip_atomic_store(a.span_state + si, (1ull << 62) | rows_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // look back: 64 spans at a time, the nearest in lane 0; up to the nearest one that knows its total
+                int64_t j = (int64_t)si - 1;
+                uint32_t spins = 0;
+                for (;;) {
+                    const int64_t idx = j - (int64_t)lane;
+                    uint64_t w = 2ull << 62;                  // (before span 0: a total of 0)
+                    if (idx >= 0) w = __hip_atomic_load(a.span_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t flag = (uint32_t)(w >> 62);
+                    const uint64_t known = __ballot(flag == 2u), pending = __ballot(flag == 0u);
+                    const int first = known ? lowest_bit(known) : 64;
+                    if (pending & mask_lt(first)) {           // a nearer span has not counted yet
+                        if (++spins > (1u << 22)) { a.st->fold_abort = 1; a.st->overflow = 1; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    uint32_t lo32 = (lane <= (uint32_t)first) ? (uint32_t)w : 0u, hi32 = (lane <= (uint32_t)first) ? (uint32_t)(w >> 32) & 0x3fffffffu : 0u;
+                    uint32_t tl, th;
+                    (void)wave_excl_sum(lo32 & 0xffffffu, lane, tl);                 // (sums of 64 values below 2^24 each stay below 2^32 ... piecewise)
+                    uint32_t tm;
+                    (void)wave_excl_sum(lo32 >> 24, lane, tm);
+                    (void)wave_excl_sum(hi32, lane, th);
+                    before += (uint64_t)uniform32(tl) + ((uint64_t)uniform32(tm) << 24) + ((uint64_t)uniform32(th) << 32);
+                    if (first < 64) break;
+                    j -= 64;
+                }
+            }
+            __hip_atomic_store(a.span_state + si, (2ull << 62) | (before + rows_here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (si + 1 == a.nspans) a.st->rows_total = before + rows_here + 1;
+            if (before >= 0xFFFFFFFFull) break;              // (reported by the host: more rows than a block may hold)
+            rowbase = (uint32_t)before;
+        } else {
+            if (si >= a.nspans) break;
+            // (values loaded from memory count as divergent for the compiler even when the address is wave-uniform: a branch on
+            // one would put the rest of the loop body under an exec mask and its bookkeeping into vector registers)
+            rowbase = uniform32(a.span_rowbase[si]);
+            rows_here = uniform32(a.span_rowbase[si + 1]) - rowbase;
+        }
+        if (rows_here == 0) continue;                             // no row starts in this span
+        if (rowbase > a.row_limit) break;                         // later spans hold rows of later blocks only
         const uint64_t s0 = (a.span0 + si) << a.span_shift, SPAN_BYTES = 1ull << a.span_shift;
         const uint64_t ss = s0 > a.lo ? s0 : a.lo;
         const uint64_t se = s0 + SPAN_BYTES < a.hi ? s0 + SPAN_BYTES : a.hi;

@@ -31,6 +31,10 @@ struct P1Status {
     uint8_t gap2[256 - 4];
     uint32_t deferred;      // fields queued for the general-form kernel
     uint8_t gap3[256 - 4];
+    uint32_t next_span;     // pass 1 counting its own rows (Pass1Args.span_state): the next span to hand out
+    uint32_t fold_abort;    // ... a wave gave up waiting for the spans before its own (cannot happen; never hang on it)
+    uint64_t rows_total;    // ... rows that start in the block, + 1 (0 = the last span was not reached)
+    uint8_t gap4[256 - 16];
 };
 
 struct LongRow { uint64_t start; uint64_t len; };   // len includes the terminating newline
@@ -41,6 +45,9 @@ struct Pass1Args {
     uint64_t span0; uint32_t nspans;      // spans [span0, span0 + nspans) cover [lo, hi)
     uint32_t span_shift;                  // a span = 2^span_shift bytes
     const uint32_t *span_rowbase;         // exclusive scan of per-span row starts
+    uint64_t *span_state;                 // not null: no row scan has run -- the waves take the spans in order (a ticket each), count the
+                                          // rows that start in theirs and learn their first row's number from the spans before (a word per
+                                          // span: 1 << 62 | count, then 2 << 62 | count of all spans up to it; zeroed before the launch)
     const uint8_t *extra;                 // imported strings (multi-GPU merge), NUL terminated
     uint32_t ncols;
     const uint8_t *col_kind;
