@@ -9,16 +9,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gb", type=float, default=1.0)
     ap.add_argument("--no-gzip", action="store_true")
+    ap.add_argument("--cols", type=int, default=200)
+    ap.add_argument("--id-every", type=int, default=0, help="every k-th column an id column (C5: --cols 1000 --id-every 20)")
+    ap.add_argument("--mem-limit", type=int, default=0, help="--mem-limit=<MB> for the runs (0: the tool's default)")
     args = ap.parse_args()
     import torch
     from zdw_amd import build, synth
-    table = synth.DeviceTable(ncols=200, device="cuda:0")
+    table = synth.DeviceTable(ncols=args.cols, device="cuda:0", id_every=args.id_every)
     rows = table.rows_for_bytes(args.gb * 1e9)
     buf, nbytes = table.generate(0, rows)
     d = tempfile.mkdtemp(prefix="zdwcli_")
     try:
         with open(os.path.join(d, "t.sql"), "wb") as f:
-            f.write(buf[:nbytes].cpu().numpy().tobytes())
+            for o in range(0, nbytes, 1 << 28):
+                f.write(buf[o:min(nbytes, o + (1 << 28))].cpu().numpy().tobytes())
         with open(os.path.join(d, "t.desc.sql"), "wb") as f:
             f.write(table.desc)
         del buf
@@ -28,14 +32,14 @@ def main():
         with open(p, "w") as f:
             f.write("#!/bin/sh\nexec cat\n")
         os.chmod(p, os.stat(p).st_mode | stat.S_IXUSR)
-        runs = [("cat", shim + os.pathsep + os.environ["PATH"], {}), ("cat, whole input first", shim + os.pathsep + os.environ["PATH"], {"ZDW_CLI_WHOLE_INPUT": "1"}),
+        runs = [("cat", shim + os.pathsep + os.environ["PATH"], {}), ("cat, file streamed in pieces", shim + os.pathsep + os.environ["PATH"], {"ZDW_CLI_STREAM_FILE": "1"}),
                 ("cat", shim + os.pathsep + os.environ["PATH"], {})]
         if not args.no_gzip:
             runs.append(("gzip", os.environ["PATH"], {}))
         for label, path, extra in runs:
             env = dict(os.environ, PATH=path, ZDW_CLI_TIMING="1", **extra)
             t0 = time.perf_counter()
-            r = subprocess.run([build.CLI_EXE, "-q", os.path.join(d, "t.sql")], env=env)
+            r = subprocess.run([build.CLI_EXE, "-q"] + (["--mem-limit=%d" % args.mem_limit] if args.mem_limit else []) + [os.path.join(d, "t.sql")], env=env)
             dt = time.perf_counter() - t0
             out = os.path.getsize(os.path.join(d, "t.zdw.gz"))
             print("%s: rc=%d  %.2f s  %.1f MB/s of input  (%d bytes in, %d out)" % (label, r.returncode, dt, nbytes / 1e6 / dt, nbytes, out))

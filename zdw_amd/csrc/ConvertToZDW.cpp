@@ -504,8 +504,11 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
                 if (!source.tee) return CANT_OPEN_TEMP_FILE;
             }
             rc = zdw_set_input_stream(ctx, readSource, &source, imageLen);
-        } else if (!hostImage && !getenv("ZDW_CLI_WHOLE_INPUT")) {
-            rc = zdw_set_input_host_async(ctx, image, imageLen);      // a mapped file: copied from the page cache while the blocks are encoded
+        } else if (!hostImage && getenv("ZDW_CLI_STREAM_FILE")) {
+            // a mapped file copied from the page cache piece by piece while its blocks are encoded.  Not the default: measured on a
+            // 16 GB file of five blocks, one copy of everything (50 GB/s) followed by the encode (0.13 s) was no slower than the
+            // pieces (33 GB/s, the blocks in between) -- the pipe to the compressor takes longer than both.
+            rc = zdw_set_input_host_async(ctx, image, imageLen);
         } else {
             rc = zdw_set_input_host(ctx, image, imageLen);
         }
@@ -745,8 +748,8 @@ ConvertToZDW::ERR_CODE ConvertToZDW::convertFile(const char *infile, const char 
             close(fd);
             return r;
         }
-        // a regular file: mapped; the library copies it to the device from the page cache piece by piece while the blocks are
-        // encoded (read() into a pinned buffer first costs a host copy: 12 GB/s against 44)
+        // a regular file: mapped and copied to the device from the page cache (read() into a pinned buffer first costs a host
+        // copy: 12 GB/s against 44-50)
         const char *map = NULL;
         if (len) {
             void *m = mmap(NULL, len, PROT_READ, MAP_PRIVATE, fd, 0);
