@@ -185,7 +185,8 @@ ConvertToZDW::ERR_CODE ConvertToZDW::validate(const char *zdwFile, const std::ve
     std::string dir(exeName);
     const size_t slash = dir.rfind('/');
     dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
-    std::string unconvert = dir + "unconvertDWfile -q - ";
+    // (ZDW_VALIDATE_GPU=1: the sibling decodes on the device -- unconvertDWfile --gpu -- instead of on one host core)
+    std::string unconvert = dir + (getenv("ZDW_VALIDATE_GPU") ? "unconvertDWfile --gpu -q - " : "unconvertDWfile -q - ");
     if (outputDir) { unconvert += "-d "; unconvert += outputDir; unconvert += " "; }
     unconvert += zdwFile;
     std::string cmd;
