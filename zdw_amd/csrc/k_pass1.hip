@@ -565,24 +565,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
 
     // tables of mostly empty fields: the record matrix was zeroed beforehand (one streaming write instead of a scattered 4- or
     // 8-byte store per empty field), so an empty field -- no record but zero, no range, no string (ConvertToZDW.cpp:340-341) -- is done
-    // the empty fields in front of mine have no descriptor of their own: their records are zeroed here (unless the whole matrix was)
-    if (SKIP && !a.rec_zeroed) {
-        const bool mine = !dead & in_block & !(a.debug_skip & 5u);
-        uint32_t k = mine ? n_prev : 0u;
-        while (__ballot(k != 0u)) {
-            if (k) {
-                const uint32_t c = col - k;                                  // (col < k: a row with too many fields, reported at its end)
-                if (c < a.ncols) {
-                    uint32_t ck, co;
-                    if (t.cols_in_lds) { const uint32_t m = lds_u32(t.meta + 4u * c); ck = m & 3u; co = m >> 16; }
-                    else { ck = a.col_kind[c]; co = a.col_recoff[c]; }
-                    uint8_t *zp = a.rec + (uint64_t)row * a.rec_stride + co;
-                    if (ck == K_TEXT) *reinterpret_cast<uint32_t *>(zp) = 0u; else *reinterpret_cast<uint64_t *>(zp) = 0ull;
-                }
-                --k;
-            }
-        }
-    }
+    // (SKIP: the empty fields in front of mine have no descriptor of their own; the record matrix was zeroed before the launch)
     if (a.rec_zeroed) is_field = is_field & (raw_len != 0);
     // a field that begins further back than a descriptor can say (the visit moved its base past its start): the general form
     uint64_t abs_start = ws.vbase + fs;
