@@ -174,9 +174,23 @@ __device__ __forceinline__ uint64_t load_le(const uint8_t *p, uint32_t size)
     return size >= 8 ? v : (v & ((1ull << (8u * size)) - 1ull));
 }
 
+__device__ __forceinline__ uint32_t dec_class(uint32_t t);
+__device__ __forceinline__ uint32_t dec_strlen(const uint8_t *__restrict__ s, uint64_t room);
+// A dictionary-backed value in the matrix: offset of the string (40 bits) | its length + 1 (24 bits; 0 = not measured).  The string
+// is measured ONCE, here, for the row that stores the value -- every row that repeats it, and both text kernels, read the length.
+constexpr uint64_t DEC_OFF_MASK = (1ull << 40) - 1ull;
+__device__ __forceinline__ uint64_t dec_pack_text(uint64_t off, const uint8_t *__restrict__ dict, uint64_t dsize)
+{
+    if (off == 0 || off >= dsize) return off;                 // empty; or beyond the dictionary (corrupt: printed as empty)
+    const uint32_t n = dec_strlen(dict + off, dsize - off);
+    return off | ((uint64_t)(n < 0xfffffeu ? n + 1u : 0u) << 40);
+}
+
 // wave = row: the values of its flagged columns into V[row][used column]
 __global__ __launch_bounds__(256) void k_dec_expand(const uint8_t *__restrict__ rows, const uint64_t *__restrict__ rstart, uint64_t nrows, uint32_t nflag,
-                                                    uint32_t nused, const uint8_t *__restrict__ usize, uint64_t *__restrict__ V)
+                                                    uint32_t nused, const uint8_t *__restrict__ usize, const uint8_t *__restrict__ utype,
+                                                    const uint64_t *__restrict__ ubase, const uint8_t *__restrict__ dict, uint64_t dsize,
+                                                    uint64_t *__restrict__ V)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -189,7 +203,11 @@ __global__ __launch_bounds__(256) void k_dec_expand(const uint8_t *__restrict__ 
             if (u < nused && ((rows[p + (u >> 3)] >> (u & 7u)) & 1u)) sz = usize[u];
             uint32_t total;
             const uint32_t off = wave_excl_sum(sz, lane, total);
-            if (sz) V[r * nused + u] = load_le(rows + p + run + off, sz);
+            if (sz) {
+                uint64_t v = load_le(rows + p + run + off, sz);
+                if (dec_class(utype[u]) <= 1u) v = v ? dec_pack_text(v + ubase[u], dict, dsize) : 0ull;
+                V[r * nused + u] = v;
+            }
             run += total;
         }
     }
@@ -367,9 +385,9 @@ __device__ __forceinline__ uint32_t dec_field(uint32_t type, bool used, uint64_t
     uint32_t n = 0;
     if (cls <= 1) {
         if (used && val) {
-            const uint64_t off = val + base;
+            const uint64_t off = val & DEC_OFF_MASK;                                 // (packed by k_dec_expand: absolute, with its length)
             if (off < dsize) {                                                       // (beyond it: corrupt data, printed as empty)
-                n = dec_strlen(dict + off, dsize - off);
+                n = (val >> 40) ? (uint32_t)(val >> 40) - 1u : dec_strlen(dict + off, dsize - off);
                 if (EMIT) dec_copy_sep(dst, dict + off, n, sep);
                 return n + 1u;
             }
@@ -461,8 +479,8 @@ __device__ __forceinline__ DecField dec_prepare(uint32_t type, bool used, uint64
     const uint32_t cls = dec_class(type);
     if (cls <= 1) {
         if (used && val) {
-            const uint64_t off = val + base;
-            if (off < dsize) { f.len = dec_strlen(dict + off, dsize - off); f.from_dict = true; f.src = dict + off; }
+            const uint64_t off = val & DEC_OFF_MASK;
+            if (off < dsize) { f.len = (val >> 40) ? (uint32_t)(val >> 40) - 1u : dec_strlen(dict + off, dsize - off); f.from_dict = true; f.src = dict + off; }
         } else if (cls == 1) {
             f.t.w0 = 0x303030302e30ull | (0x3030ull << 48); f.t.w1 = 0x303030303030ull; f.len = 14;
         }
@@ -599,7 +617,7 @@ struct zdw_dec {
     std::vector<uint8_t> types;
     std::vector<uint16_t> charsizes;
     // the block
-    DBuf d_type, d_used_of, d_usize, d_ubase, d_tbl, entry, exit_true, counts, cum, scan_tmp, rstart, V, last, has, slast, shas, rowlen, rowoff, pre, text, flag;
+    DBuf d_type, d_used_of, d_usize, d_utype, d_ubase, d_tbl, entry, exit_true, counts, cum, scan_tmp, rstart, V, last, has, slast, shas, rowlen, rowoff, pre, text, flag;
     uint64_t text_bytes = 0;
     bool have_block = false;
     float stage_ms[5] = {0, 0, 0, 0, 0};
@@ -657,7 +675,7 @@ void zdw_dec_destroy(zdw_dec *d)
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->s) (void)hipStreamSynchronize(d->s);
-    for (DBuf *b : {&d->img, &d->d_type, &d->d_used_of, &d->d_usize, &d->d_ubase, &d->d_tbl, &d->entry, &d->exit_true, &d->counts, &d->cum, &d->scan_tmp,
+    for (DBuf *b : {&d->img, &d->d_type, &d->d_used_of, &d->d_usize, &d->d_utype, &d->d_ubase, &d->d_tbl, &d->entry, &d->exit_true, &d->counts, &d->cum, &d->scan_tmp,
                     &d->rstart, &d->V, &d->last, &d->has, &d->slast, &d->shas, &d->rowlen, &d->rowoff, &d->pre, &d->text, &d->flag})
         b->release();
     for (int i = 0; i < 6; ++i) if (d->ev[i]) (void)hipEventDestroy(d->ev[i]);
@@ -781,10 +799,10 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
     if (ncols && !fetch(pos, size.data(), ncols)) return dfail(d, DEC_CORRUPT, "column sizes cut short");
     pos += ncols;
     std::vector<int32_t> used_of(ncols ? ncols : 1, -1);
-    std::vector<uint8_t> usize;
+    std::vector<uint8_t> usize, utype;
     for (uint32_t c = 0; c < ncols; ++c) {
         if (size[c] > 8) return dfail(d, DEC_CORRUPT, "column %u is %u bytes wide", c, (unsigned)size[c]);
-        if (size[c]) { used_of[c] = (int32_t)usize.size(); usize.push_back(size[c]); }
+        if (size[c]) { used_of[c] = (int32_t)usize.size(); usize.push_back(size[c]); utype.push_back(d->types[c]); }
     }
     const uint32_t nused = (uint32_t)usize.size();
     std::vector<uint64_t> ubase(nused ? nused : 1);
@@ -796,10 +814,12 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
 
     DEC_TRY(d, d->d_used_of.ensure(4ull * ncols + 8));
     DEC_TRY(d, d->d_usize.ensure(nused + 8));
+    DEC_TRY(d, d->d_utype.ensure(nused + 8));
     DEC_TRY(d, d->d_ubase.ensure(8ull * nused + 8));
     if (ncols) DEC_TRY(d, hipMemcpyAsync(d->d_used_of.p, used_of.data(), 4ull * ncols, hipMemcpyHostToDevice, s));
     if (nused) {
         DEC_TRY(d, hipMemcpyAsync(d->d_usize.p, usize.data(), nused, hipMemcpyHostToDevice, s));
+        DEC_TRY(d, hipMemcpyAsync(d->d_utype.p, utype.data(), nused, hipMemcpyHostToDevice, s));
         DEC_TRY(d, hipMemcpyAsync(d->d_ubase.p, ubase.data(), 8ull * nused, hipMemcpyHostToDevice, s));
     }
     DEC_TRY(d, d->rstart.ensure(8ull * ((uint64_t)nrows + 2)));
@@ -882,7 +902,7 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
     auto grid_for = [&](uint64_t waves) { const uint64_t wgs = (waves + 3) / 4; return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wgs, (uint64_t)cus * 8)); };
     if (nrows && nused) {
         hipLaunchKernelGGL(k_dec_expand, dim3(grid_for(nrows)), dim3(256), 0, s, rows, d->rstart.as<uint64_t>(), (uint64_t)nrows, nflag, nused,
-                           d->d_usize.as<uint8_t>(), d->V.as<uint64_t>());
+                           d->d_usize.as<uint8_t>(), d->d_utype.as<uint8_t>(), d->d_ubase.as<uint64_t>(), img + dict_off, dsize, d->V.as<uint64_t>());
     }
     DEC_TRY(d, hipEventRecord(d->ev[2], s));
     if (nrows && nused) {
