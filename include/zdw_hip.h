@@ -145,7 +145,8 @@ int zdw_set_input_host_async(zdw_ctx *ctx, const uint8_t *tsv, uint64_t len);
 /* parseInput(): consumes rows from the current position up to the end of input or the split hint
  * (NULL = no limit).  Returns 0, 15 (res->bad_row set), 7 (a block of zero rows was forced) or 20. */
 int zdw_block_pass1(zdw_ctx *ctx, const zdw_split_hint *hint, zdw_pass1_result *res);
-/* pass-1 kernel launches of this context so far (a block that the memory-limit model ends takes two, see zdw_opts.mem_limit_mb) */
+/* pass-1 kernel launches of this context so far (a block that the memory-limit model ends takes one over a window of rows a little larger
+ * than the block -- what lies beyond its end is taken back out of the records --, another one when the window was too short) */
 uint64_t zdw_ctx_pass1_launches(const zdw_ctx *ctx);
 /* leading fields of the row after the current block that its pass 1 visited (zdw_split_hint.partial_fields as taken: what the caller
  * passed, or what the memory-limit model found; 0 for a block that ends the input or that device memory ended) */

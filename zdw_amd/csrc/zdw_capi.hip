@@ -1127,9 +1127,9 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
 {
     if (!c || !res) return ZDW_UNKNOWN_ERROR;
     if (c->mem_limit_mb <= 0.0 || (hint && hint->max_rows != 0xFFFFFFFFu)) return pass1_impl(c, hint, res);      // (a caller's split overrides the model)
-    // The reference's block limit as a model (model_trip).  The block is parsed once over a window of rows and, when the limit
-    // trips inside the window, once more up to exactly that row and field: two pass-1 launches per block that the model ends, one
-    // for a last block, and the rows beyond a block are parsed by at most the window's excess.
+    // The reference's block limit as a model (model_trip).  The block is parsed once over a window of rows; when the limit trips
+    // inside the window, what the rows beyond that point added is taken back out of pass 1's results (trim_block): one pass-1
+    // launch per block, another one only when the window turns out too short.
     // The window, in rows.  After a block the model ended: the rows of that block plus a half -- plus a tenth when the two blocks
     // before were of one size (tables of id-like columns end their blocks every N rows).  For an input's first block: the rows
     // that four times the limit's bytes of input hold (C5: a row's id fields cost 0.44 bytes of the modelled process per input
