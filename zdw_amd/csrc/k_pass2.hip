@@ -434,10 +434,190 @@ __global__ __launch_bounds__(256, P2_R <= 8 ? 7 : 4) void k_pass2_emit_cols_pipe
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// rows of mostly empty fields: a wave per row, going by the map of non-zero records (Pass2Args.nz)
+// ------------------------------------------------------------------------------------------
+// Pass 1 left rec valid only where nz[row][column] is set.  A column can change between row r - 1 and row r only where one of
+// the two has a record: those columns (in column order) are gathered from the two rows of the map into LDS, and only they are
+// looked at -- tens of the thousands of columns such tables have.  Flags, stored values and their order are what the column
+// kernels above produce: flag = the raw values differ (first row: first_row_flag), value = stored_from_raw, in column order.
+constexpr uint32_t P2S_WAVES = 4;
+constexpr uint32_t P2S_ROWS = 8;
+constexpr uint32_t P2S_IMG = 1024;      // emit: a row's output of up to about this many bytes is put together in LDS and leaves in 16-byte stores
+__host__ __device__ inline uint32_t p2s_cand_bytes(uint32_t nused) { return (nused * 2u + 15u) & ~15u; }
+__host__ __device__ inline uint32_t p2s_img_bytes(uint32_t nused, bool emit) { return emit ? ((((nused + 7u) >> 3) + 15u) & ~15u) + 16u + P2S_IMG : 0u; }
+
+template <bool EMIT>
+__global__ __launch_bounds__(64 * P2S_WAVES) void k_pass2_rows_sparse(const Pass2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t p2s_lds[];
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t nflag = (a.nused + 7) >> 3;
+    // per wave: the candidates' columns (u16 each, at most nused), then (emit) the row's image: flag bytes, values
+    const uint32_t imgcap = p2s_img_bytes(a.nused, EMIT);
+    const uint32_t per_wave = p2s_cand_bytes(a.nused) + imgcap;
+    uint16_t *cand = reinterpret_cast<uint16_t *>(p2s_lds + (size_t)wv * per_wave);
+    uint8_t *fimg = p2s_lds + (size_t)wv * per_wave + p2s_cand_bytes(a.nused);
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    // (a wave takes P2S_ROWS rows in a row: the map row above is the one it has just read, its output is one run of bytes)
+    for (uint64_t it = wave * P2S_ROWS; it < (((uint64_t)a.nrows + P2S_ROWS - 1) / P2S_ROWS) * P2S_ROWS; it += (it % P2S_ROWS == P2S_ROWS - 1) ? (nwaves - 1) * P2S_ROWS + 1 : 1) {
+        const uint64_t row = it;
+        if (row >= a.nrows) continue;
+        const uint8_t *m1 = a.nz + row * a.nz_stride, *m0 = row ? m1 - a.nz_stride : nullptr;
+        const bool all = row == 0 && !a.prev_is_zero;      // a shard's first row is compared with the halo row: every used column
+        uint32_t cnt = 0;
+        if (all) {
+            for (uint32_t u = lane; u < a.nused; u += 64) cand[u] = (uint16_t)a.used_col[u];
+            cnt = a.nused;
+        } else {
+            // 16 columns of the two map rows per lane and load (the map's bytes are 0 or 1): all loads of a row are in flight together
+            for (uint32_t cb = 0; cb < a.nz_stride; cb += 1024u) {
+                const uint32_t c0 = cb + lane * 16u;
+                uint4 x = make_uint4(0, 0, 0, 0), y = x;
+                if (c0 < a.nz_stride) {
+                    x = *reinterpret_cast<const uint4 *>(m1 + c0);
+                    if (m0) y = *reinterpret_cast<const uint4 *>(m0 + c0);
+                }
+                const uint32_t M = 0x01020408u;      // bytes of 0 / 1 -> a bit each, in byte order
+                uint32_t bits = (((x.x | y.x) * M) >> 24 & 15u) | (((x.y | y.y) * M) >> 24 & 15u) << 4 | (((x.z | y.z) * M) >> 24 & 15u) << 8 |
+                                (((x.w | y.w) * M) >> 24 & 15u) << 12;
+                uint32_t total;
+                uint32_t at = cnt + wave_excl_sum((uint32_t)__popc(bits), lane, total);
+                while (bits) {
+                    const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
+                    bits &= bits - 1u;
+                    if (at < a.nused) cand[at] = (uint16_t)(c0 + b);
+                    ++at;
+                }
+                cnt += total;
+            }
+            cnt = cnt < a.nused ? cnt : a.nused;
+        }
+        const uint64_t out0 = EMIT ? a.row_off[row] : 0;
+        // emit: the image starts `shift` bytes into its buffer, so that 16-byte pieces of it are 16-byte pieces of the output;
+        // a row too long for the buffer has only its flag bytes there and its values written where they belong
+        uint32_t shift = 0;
+        bool img = false;
+        if (EMIT) {
+            const uint32_t L = (uint32_t)(a.row_off[row + 1] - out0);
+            shift = (uint32_t)((reinterpret_cast<uintptr_t>(a.out) + out0) & 15u);
+            img = shift + L <= imgcap;
+            if (!img) shift = 0;
+            for (uint32_t k = lane * 4u; k < shift + nflag; k += 256u) *reinterpret_cast<uint32_t *>(fimg + k) = 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t run = nflag;
+        // 128 candidates at a time; per candidate a chain of three loads: its column's facts and the two map bytes, the records,
+        // the dictionary offset of a string
+        for (uint32_t g = 0; g < cnt; g += 128) {
+            bool ok[2], text[2], flag[2];
+            uint32_t col[2], u[2], sz[2], n1[2], n0[2];
+            uint64_t meta[2], base[2], cur[2], prev[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ok[j] = g + 64u * j + lane < cnt;
+                col[j] = ok[j] ? cand[g + 64u * j + lane] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                meta[j] = ok[j] ? a.col_meta[col[j]] : 0xFFFFFFull;      // which used column (24 bits), kind (2), stored size (4), record offset (32)
+                base[j] = ok[j] ? a.col_meta[a.nz_cols + col[j]] : 0ull;   // the column's base value
+                n1[j] = ok[j] ? m1[col[j]] : 0u;
+                n0[j] = (ok[j] && m0) ? m0[col[j]] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u[j] = (uint32_t)meta[j] & 0xFFFFFFu;
+                ok[j] = ok[j] && u[j] != 0xFFFFFFu;
+                text[j] = ((uint32_t)meta[j] >> 24 & 3u) == K_TEXT;
+                const uint32_t off = (uint32_t)(meta[j] >> 32);
+                // a record is read only where it decides something: the map says it is not zero, so beside an empty field of the
+                // other row it is a change whatever it holds (the emit kernel wants the value itself)
+                cur[j] = (ok[j] && n1[j] && (EMIT || n0[j] || row == 0)) ? raw_value(a, (uint32_t)row, off, text[j]) : 0ull;
+                prev[j] = (ok[j] && n1[j] && n0[j]) ? raw_value(a, (uint32_t)row - 1u, off, text[j]) : 0ull;
+            }
+            uint64_t x[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                flag[j] = ok[j] && ((n1[j] != 0u) != (n0[j] != 0u) || cur[j] != prev[j]);
+                if (row == 0) flag[j] = ok[j] && first_row_flag(a, cur[j], u[j], text[j]);
+                sz[j] = flag[j] ? ((uint32_t)meta[j] >> 26 & 15u) : 0u;
+                x[j] = 0ull;
+                if (EMIT && flag[j] && cur[j]) x[j] = text[j] ? (uint64_t)a.id_off[(uint32_t)cur[j] - 1u] : cur[j] - base[j];
+            }
+            uint32_t t0, t1;
+            uint32_t at[2];
+            at[0] = wave_excl_sum(sz[0], lane, t0);
+            at[1] = t0 + wave_excl_sum(sz[1], lane, t1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (EMIT && flag[j]) {
+                    const uint32_t fb = shift + (u[j] >> 3);      // bit u of the flag bytes, through the aligned word that holds it
+                    atomicOr(reinterpret_cast<uint32_t *>(fimg + (fb & ~3u)), 1u << ((fb & 3u) * 8u + (u[j] & 7u)));
+                    uint64_t v = x[j];
+                    const uint32_t w = sz[j];
+                    if (img) {
+                        uint8_t *q = fimg + shift + run + at[j];
+                        if (w == 8) { reinterpret_cast<PackedW64 *>(q)->v = v; }
+                        else {
+                            if (w & 4u) { reinterpret_cast<PackedW32 *>(q)->v = (uint32_t)v; q += 4; v >>= 32; }
+                            if (w & 2u) { reinterpret_cast<PackedW16 *>(q)->v = (uint16_t)v; q += 2; v >>= 16; }
+                            if (w & 1u) *q = (uint8_t)v;
+                        }
+                    } else {
+                        uint8_t *q = a.out + out0 + run + at[j];
+                        if (w == 8) { reinterpret_cast<PackedW64 *>(q)->v = v; }
+                        else {
+                            if (w & 4u) { reinterpret_cast<PackedW32 *>(q)->v = (uint32_t)v; q += 4; v >>= 32; }
+                            if (w & 2u) { reinterpret_cast<PackedW16 *>(q)->v = (uint16_t)v; q += 2; v >>= 16; }
+                            if (w & 1u) *q = (uint8_t)v;
+                        }
+                    }
+                }
+            }
+            run += t0 + t1;
+        }
+        if (EMIT) {
+            __builtin_amdgcn_wave_barrier();
+            if (img) {
+                uint8_t *gdst = a.out + (out0 - shift);              // 16-byte aligned
+                const uint32_t endb = shift + run;
+                for (uint32_t o = lane * 16u; o < endb; o += 1024u) {
+                    if (o >= shift && o + 16u <= endb) {
+                        *reinterpret_cast<uint4 *>(gdst + o) = *reinterpret_cast<const uint4 *>(fimg + o);
+                    } else {
+                        const uint32_t lo = o > shift ? o : shift, hi = o + 16u < endb ? o + 16u : endb;
+                        for (uint32_t k = lo; k < hi; ++k) gdst[k] = fimg[k];
+                    }
+                }
+            } else {
+                for (uint32_t k = lane; k < nflag; k += 64) a.out[out0 + k] = fimg[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if (lane == 0) {
+            a.row_len[row] = run;
+        }
+    }
+}
+
+template <bool EMIT>
+static void launch_pass2_sparse(const Pass2Args &a, hipStream_t s)
+{
+    const size_t per_wave = (size_t)p2s_cand_bytes(a.nused) + p2s_img_bytes(a.nused, EMIT);
+    const size_t lds = per_wave * P2S_WAVES;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t want = ((uint64_t)a.nrows + P2S_WAVES * P2S_ROWS - 1) / (P2S_WAVES * P2S_ROWS);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * 8);
+    hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
+}
+
 template <bool EMIT>
 static void launch_pass2(const Pass2Args &a, hipStream_t s)
 {
     if (!a.nrows) return;
+    if (a.nz) { launch_pass2_sparse<EMIT>(a, s); return; }
     uint32_t g = 1;
     while (g < 64 && g < a.nused) g <<= 1;
     // Which kernels: the lane = column kernels need not be full to win.  Measured per 4 GB, G-lanes-per-row kernels vs column

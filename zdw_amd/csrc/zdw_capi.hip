@@ -187,6 +187,11 @@ struct zdw_ctx {
     uint64_t avg_row = 0;         // bytes per row, sampled at the start of the input
     bool skip_empty = false;      // ... and: most of its fields are empty
     double bytes_per_row = 0.0;   // of the last block pass 1 completed (how many rows the next one may hold)
+    DevBuf nz, d_used_col;        // tables of mostly empty fields: where pass 1 left a non-zero record (Pass1Args.nz)
+    bool nz_mode = false;         // ... this block's record matrix means something only there
+    bool rec_dense = true;        // ... until the rest has been zeroed for a reader that wants all of it (ensure_dense_rec)
+    uint32_t nz_stride = 0;       // bytes per row of the map (columns rounded up to 16)
+    uint32_t nrows_written = 0;   // rows of the matrix pass 1 may have written (the block may have been cut back since)
     bool no_fold = false;         // pass 1 counts its own rows unless that went wrong for this input
     DevBuf span_state;
     bool dense_boundaries = false; // ... and whether fields are so short that pass 1 takes its large descriptor ring
@@ -282,6 +287,7 @@ void reset_block(zdw_ctx *c)
     c->uniques_sorted = c->own_built = false;
     c->nrows = 0; c->nuniq = 0; c->nids = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
     c->have_prev = false;
+    c->nz_mode = false; c->rec_dense = true;
 }
 
 // Replays the reference's fgets() chunking on one logical row (getnextrow.cpp:26-84) to learn how
@@ -737,6 +743,8 @@ int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uin
     return ZDW_OK;
 }
 
+int ensure_dense_rec(zdw_ctx *c);
+
 // The block that pass 1 has just parsed ends earlier, at field `fields` of row `row` (which starts at input position row_start and
 // has a record: row < the rows pass 1 kept).  Instead of a second pass 1 up to there, what the rows beyond that point added is
 // taken back (k_trim_scan: launch_trim_block): strings only they hold become holes among the unique ids, ranges and used columns
@@ -744,6 +752,7 @@ int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uin
 int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res)
 {
     hipStream_t s = c->stream;
+    { int rcd = ensure_dense_rec(c); if (rcd) return rcd; }
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -821,6 +830,18 @@ int ensure_stats(zdw_ctx *c)
 }
 
 // uploads the per-used-column tables pass 2 reads and fills the kernel arguments
+// A reader that wants every record of the matrix (the column kernels of pass 2, the halo row of a shard, a block cut back to the
+// model's end): what pass 1 left unwritten under Pass1Args.nz is zeroed now.
+int ensure_dense_rec(zdw_ctx *c)
+{
+    if (!c->nz_mode || c->rec_dense) return ZDW_OK;
+    launch_rec_zero_fill(c->rec.as<uint8_t>(), c->rec_stride, c->nrows_written, c->ncols, c->d_kind.as<uint8_t>(), c->d_recoff.as<uint32_t>(),
+                         c->nz.as<uint8_t>(), c->nz_stride, c->stream);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->rec_dense = true;
+    return ZDW_OK;
+}
+
 int prepare_pass2(zdw_ctx *c, Pass2Args &a, hipStream_t s = nullptr)
 {
     int rc = ensure_stats(c);
@@ -852,6 +873,28 @@ int prepare_pass2(zdw_ctx *c, Pass2Args &a, hipStream_t s = nullptr)
     a.id_off = c->slot_off.as<uint32_t>(); a.nids = c->nids; a.prev0 = c->d_prev0.as<uint64_t>();
     a.prev_is_zero = c->have_prev ? 0u : 1u;
     a.last_stored = c->d_last.as<uint64_t>();
+    if (c->nz_mode && !c->rec_dense) {
+        // rows by the map of non-zero records (k_pass2_rows_sparse) when a row's candidates fit its LDS; else the whole matrix
+        const size_t per_wave = (((size_t)nu * 2 + 15) & ~(size_t)15) + ((((size_t)nu + 7) / 8 + 15) & ~(size_t)15) + 16 + 1024;      // (k_pass2.hip: p2s_*_bytes)
+        if (per_wave * 4 <= 60 * 1024 && c->ncols <= 65536 && !getenv("ZDW_P2_DENSE")) {
+            // per schema column: which used column it is and that column's facts; then per used column its schema column
+            std::vector<uint64_t> maps((size_t)c->ncols * 2 + (nu + 1) / 2, 0xFFFFFFull);
+            uint32_t *ucol = reinterpret_cast<uint32_t *>(maps.data() + (size_t)c->ncols * 2);
+            for (uint32_t u = 0; u < nu; ++u) {
+                maps[c->used[u]] = (uint64_t)u | (uint64_t)(uk[u] & 3u) << 24 | (uint64_t)(us[u] & 15u) << 26 | (uint64_t)uo[u] << 32;
+                maps[(size_t)c->ncols + c->used[u]] = ub[u];
+                ucol[u] = c->used[u];
+            }
+            HIP_TRY(c, c->d_used_col.ensure(maps.size() * 8));
+            HIP_TRY(c, hipMemcpyAsync(c->d_used_col.p, maps.data(), maps.size() * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            a.nz = c->nz.as<uint8_t>(); a.nz_stride = c->nz_stride;
+            a.col_meta = c->d_used_col.as<uint64_t>(); a.nz_cols = c->ncols; a.used_col = reinterpret_cast<const uint32_t *>(a.col_meta + (size_t)c->ncols * 2);
+        } else {
+            rc = ensure_dense_rec(c);
+            if (rc) return rc;
+        }
+    }
     return ZDW_OK;
 }
 
@@ -924,7 +967,7 @@ int run_pass2(zdw_ctx *c)
 
 std::vector<DevBuf *> all_device_buffers(zdw_ctx *c)
 {
-    return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->span_state, &c->scan_tmp, &c->scan_tmp2, &c->rec,
+    return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->span_state, &c->nz, &c->d_used_col, &c->scan_tmp, &c->scan_tmp2, &c->rec,
                       &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
                       &c->own_upos, &c->own_ulen, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
                       &c->own_out, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
@@ -1421,8 +1464,20 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             a.rebase_at = a.skip_empty ? 1u << 23 : 1u << 30;              // (descriptors of that form hold 24 bits of position)
             if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::min(a.rebase_at, std::max(16384u, (uint32_t)strtoul(e, nullptr, 10)));   // tests
             if ((a.dense_boundaries || a.skip_empty) && nrows) {
-                // mostly empty fields: zero the record matrix in one streaming write; pass 1 then skips every empty field
-                HIP_TRY(c, hipMemsetAsync(c->rec.p, 0, (uint64_t)nrows * c->rec_stride, s));
+                // mostly empty fields: pass 1 skips every empty field.  Either the record matrix is zeroed in one streaming write, or
+                // (the form for such tables, a map of a byte per field that fits) a map says where a record was written and pass 2
+                // looks nowhere else: a map of rows x columns bytes instead of rows x ~6 x columns bytes to clear.
+                c->nz_stride = (c->ncols + 15u) & ~15u;
+                const uint64_t map_bytes = (uint64_t)nrows * c->nz_stride;
+                bool use_map = a.skip_empty && map_bytes <= (16ull << 30) && !getenv("ZDW_P1_NO_NZ");
+                if (use_map && c->nz.ensure(map_bytes + 64) != hipSuccess) use_map = false;
+                if (use_map) {
+                    HIP_TRY(c, hipMemsetAsync(c->nz.p, 0, map_bytes, s));
+                    a.nz = c->nz.as<uint8_t>(); a.nz_stride = c->nz_stride;
+                } else {
+                    HIP_TRY(c, hipMemsetAsync(c->rec.p, 0, (uint64_t)nrows * c->rec_stride, s));
+                }
+                c->nz_mode = use_map; c->rec_dense = !use_map; c->nrows_written = nrows;
                 a.rec_zeroed = 1;
             }
             a.st = c->status.as<P1Status>(); a.long_rows = c->long_rows.as<LongRow>(); a.long_cap = long_cap;
@@ -1495,6 +1550,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     }
     if (getenv("ZDW_DEBUG_RETRY")) { fprintf(stderr, "[pass1] %u rows, table %llu slots, %u entries; hipMalloc/hipFree so far %.1f ms\n", nrows, (unsigned long long)nslots, st.entries, g_alloc_ms); }
     c->nrows = nrows;
+    if (c->nz_mode) c->nrows_written = nrows;      // (rows beyond the block's were not written)
     c->is_last = !tripped;
     c->partial_taken = tripped ? partial : 0;
     res->table_slots = nslots;
@@ -1805,6 +1861,8 @@ int zdw_shard_last_row(zdw_ctx *c, uint64_t *stored)
     if (!c || !stored) return ZDW_UNKNOWN_ERROR;
     (void)hipSetDevice(c->device);
     int rc = ensure_dict(c);                    // stored values of text columns are dictionary offsets
+    if (rc) return rc;
+    rc = ensure_dense_rec(c);                   // (the last row's records, whichever columns they are in)
     if (rc) return rc;
     Pass2Args a;
     rc = prepare_pass2(c, a);

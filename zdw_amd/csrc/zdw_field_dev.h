@@ -116,7 +116,10 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
         const uint64_t wm = __ballot(want);
         if (want) id = dict_insert<BULK>(p, a.in + a.n, a.in, a.n, a.extra, a.hi, d, al, ID_CHUNK, fs, len, a.trim != 0, is_new);
         adopt_ids(al, wm);
-        if (want && in_block) *reinterpret_cast<uint32_t *>(recp) = id;
+        if (want && in_block) {
+            *reinterpret_cast<uint32_t *>(recp) = id;
+            if (a.nz && id) a.nz[(uint64_t)row * a.nz_stride + col] = 1;
+        }
     }
     if (kind == K_TEXT) {
         if (!want && in_block) *reinterpret_cast<uint32_t *>(recp) = 0u;
@@ -135,7 +138,10 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
         }
         if (v_range > 0) range_update(a, t, col, numidx, v_range);
     }
-    if (in_block) *reinterpret_cast<uint64_t *>(recp) = v_rec;
+    if (in_block) {
+        *reinterpret_cast<uint64_t *>(recp) = v_rec;
+        if (a.nz && v_rec) a.nz[(uint64_t)row * a.nz_stride + col] = 1;
+    }
 }
 
 }  // namespace zdw
