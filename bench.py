@@ -177,8 +177,14 @@ def e2e_cli(torch, table, gb=2.0):
         with open(os.path.join(d, "t.sql"), "rb") as f:          # warm the page cache
             while f.read(64 << 20):
                 pass
-        for label, path in (("cat_shim", shim + os.pathsep + os.environ.get("PATH", "")), ("gzip", os.environ.get("PATH", ""))):
+        # cat_shim: the compressor child replaced by cat; gzip: the command line as shipped (deflate in the process on several
+        # threads); gzip_child: the reference's way, one `gzip` child (ZDW_GZIP_THREADS=0)
+        plain = os.environ.get("PATH", "")
+        for label, path, threads in (("cat_shim", shim + os.pathsep + plain, "0"), ("gzip", plain, None), ("gzip_child", plain, "0")):
             env = dict(os.environ, PATH=path)
+            env.pop("ZDW_GZIP_THREADS", None)
+            if threads is not None:
+                env["ZDW_GZIP_THREADS"] = threads
             t0 = time.perf_counter()
             r = subprocess.run([build.CLI_EXE, "-q", os.path.join(d, "t.sql")], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             dt = time.perf_counter() - t0
@@ -189,6 +195,10 @@ def e2e_cli(torch, table, gb=2.0):
                 continue
             res[label + "_MBps"] = round(nbytes / 1e6 / dt, 1)
             res[label + "_s"] = round(dt, 2)
+            if label == "gzip":
+                res["gzip_threads"] = min(os.cpu_count() or 1, 16)
+                res["gzip_bytes"] = os.path.getsize(outp)
+                res["gzip_reads_back"] = subprocess.run(["gzip", "-t", outp]).returncode == 0
             if label == "cat_shim":
                 # the other direction: that raw stream back to text on the device (zdw_dec_*), the second of two
                 # runs; checked against the file it came from on its first rows, by row count and by length

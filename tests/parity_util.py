@@ -49,7 +49,8 @@ def multiblock_tsv(c):
 
 class CliSandbox:
     """A scratch directory plus a PATH whose `gzip` is `cat`, so <x>.zdw.gz is the raw ZDW stream
-    (the same trick oracle/_ref uses for the reference binary)."""
+    (the same trick oracle/_ref uses for the reference binary); ZDW_GZIP_THREADS=0 makes the command line use that child, as the
+    reference does, instead of deflating in the process."""
 
     def __init__(self):
         self.dir = tempfile.mkdtemp(prefix="zdwgpu_")
@@ -61,10 +62,16 @@ class CliSandbox:
         os.chmod(p, os.stat(p).st_mode | stat.S_IXUSR | stat.S_IXGRP | stat.S_IXOTH)
         self.old_path = os.environ.get("PATH", "")
         os.environ["PATH"] = shim + os.pathsep + self.old_path
+        self.old_threads = os.environ.get("ZDW_GZIP_THREADS")
+        os.environ["ZDW_GZIP_THREADS"] = "0"          # the compressor is the child on PATH (the shim), not the writer in the process
         self.n = 0
 
     def close(self):
         os.environ["PATH"] = self.old_path
+        if self.old_threads is None:
+            os.environ.pop("ZDW_GZIP_THREADS", None)
+        else:
+            os.environ["ZDW_GZIP_THREADS"] = self.old_threads
         shutil.rmtree(self.dir, ignore_errors=True)
 
     def run(self, desc, tsv, args=(), meta_file=None, env=None):

@@ -32,10 +32,12 @@ def main():
         with open(p, "w") as f:
             f.write("#!/bin/sh\nexec cat\n")
         os.chmod(p, os.stat(p).st_mode | stat.S_IXUSR)
-        runs = [("cat", shim + os.pathsep + os.environ["PATH"], {}), ("cat, file streamed in pieces", shim + os.pathsep + os.environ["PATH"], {"ZDW_CLI_STREAM_FILE": "1"}),
-                ("cat", shim + os.pathsep + os.environ["PATH"], {})]
+        runs = [("cat", shim + os.pathsep + os.environ["PATH"], {"ZDW_GZIP_THREADS": "0"}),
+                ("cat, file streamed in pieces", shim + os.pathsep + os.environ["PATH"], {"ZDW_CLI_STREAM_FILE": "1", "ZDW_GZIP_THREADS": "0"}),
+                ("cat", shim + os.pathsep + os.environ["PATH"], {"ZDW_GZIP_THREADS": "0"})]
         if not args.no_gzip:
-            runs.append(("gzip", os.environ["PATH"], {}))
+            runs.append(("gzip in the process", os.environ["PATH"], {}))
+            runs.append(("gzip child", os.environ["PATH"], {"ZDW_GZIP_THREADS": "0"}))
         for label, path, extra in runs:
             env = dict(os.environ, PATH=path, ZDW_CLI_TIMING="1", **extra)
             t0 = time.perf_counter()

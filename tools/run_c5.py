@@ -36,7 +36,7 @@ def file_header(table, first_row):
         stem = os.path.join(d, "t")
         open(stem + ".sql", "wb").write(first_row)
         open(stem + ".desc.sql", "wb").write(table.desc)
-        env = dict(os.environ, PATH=shim + os.pathsep + os.environ.get("PATH", ""))
+        env = dict(os.environ, ZDW_GZIP_THREADS="0", PATH=shim + os.pathsep + os.environ.get("PATH", ""))
         r = subprocess.run([build.CLI_EXE, "-q", stem + ".sql"], env=env, capture_output=True)
         if r.returncode:
             raise RuntimeError("convertDWfile on the one-row file: rc %d %s" % (r.returncode, r.stderr[-300:]))

@@ -16,7 +16,7 @@ for fname in ("edge_cases.json", "fuzz_cases.json"):
         open(stem + ".sql", "wb").write(c["tsv"]); open(stem + ".desc.sql", "wb").write(c["desc"])
         if c["meta_file"] is not None:
             open(stem + ".metadata", "wb").write(c["meta_file"])
-        env = dict(os.environ); env["PATH"] = shim + os.pathsep + env["PATH"]
+        env = dict(os.environ); env["PATH"] = shim + os.pathsep + env["PATH"]; env["ZDW_GZIP_THREADS"] = "0"
         p = subprocess.run([build.CLI_EXE] + c["args"] + [stem + ".sql"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         out = open(stem + ".zdw.gz", "rb").read() if os.path.exists(stem + ".zdw.gz") else None
         ok = p.returncode == c["exit_code"] and (c["exit_code"] != 0 or out == c["zdw"])

@@ -12,6 +12,7 @@
 #include "ConvertToZDW.h"
 
 #include "zdw_hip.h"
+#include "parallel_gzip.h"
 
 #include <cerrno>
 #include <chrono>
@@ -21,6 +22,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <thread>
@@ -209,7 +211,8 @@ namespace {
 // writes.  So the next piece of a block leaves the device while the one before goes down the pipe, and the next block's pass 1
 // runs while the last pieces of this one drain (the reference writes and parses in turn).
 struct OutPipe {
-    FILE *f = nullptr;
+    FILE *f = nullptr;                                       // the compressor child's stdin, or (gz) the output file itself
+    std::unique_ptr<zdwhost::ParallelGzip> gz;               // gzip in this process, on several threads (parallel_gzip.h)
     static constexpr size_t QUEUE_LIMIT = 512u << 20;
     std::thread th;
     std::mutex m;
@@ -230,7 +233,8 @@ struct OutPipe {
                 piece.swap(q.front());
                 q.pop_front();
             }
-            const bool ok = failed || fwrite(piece.data(), 1, piece.size(), f) == piece.size();      // (after a failure: drain without writing)
+            const bool ok = failed || (gz ? gz->write(piece.data(), piece.size())                   // (after a failure: drain without writing)
+                                          : fwrite(piece.data(), 1, piece.size(), f) == piece.size());
             {
                 std::lock_guard<std::mutex> g(m);
                 queued -= piece.size();
@@ -279,8 +283,54 @@ struct OutPipe {
         }
         return !failed;
     }
-    ~OutPipe() { finish(); }
+    // Through `cmd` (a shell command that reads the stream on its stdin and writes the file), or with gzThreads > 0 deflated here into `path`
+    bool open(const std::string &cmd, const std::string &path, unsigned gzThreads, int gzLevel)
+    {
+        if (gzThreads) {
+            f = fopen(path.c_str(), "wb");
+            if (f) gz.reset(new zdwhost::ParallelGzip(f, gzThreads, gzLevel));
+        } else {
+            f = popen(cmd.c_str(), "w");
+        }
+        return f != nullptr;
+    }
+    // after finish(): the child's exit status (0: fine), or that of the writer in this process
+    int close()
+    {
+        if (!f) return 0;
+        int st;
+        if (gz) {
+            st = gz->close() ? 0 : 1;
+            gz.reset();
+            if (fclose(f) != 0) st = 1;
+        } else {
+            st = pclose(f);
+        }
+        f = nullptr;
+        return st;
+    }
+    ~OutPipe() { finish(); if (f) (void)close(); }
 };
+
+// gzip without arguments the child would need to see (or with a plain level): deflated in this process on several threads, unless
+// ZDW_GZIP_THREADS=0 asks for the reference's child process.  Returns the number of threads (0: the child), *level for them.
+static unsigned inProcessGzip(bool isGzip, const char *zArgs, int *level)
+{
+    *level = 6;
+    if (!isGzip) return 0;
+    if (zArgs && *zArgs) {
+        const std::string a = zArgs;
+        if (a.size() == 2 && a[0] == '-' && a[1] >= '1' && a[1] <= '9') *level = a[1] - '0';
+        else if (a == "--fast") *level = 1;
+        else if (a == "--best") *level = 9;
+        else return 0;
+    }
+    unsigned n = std::thread::hardware_concurrency();
+    if (n > 16) n = 16;                                      // (a GPU's share of the host's cores)
+    if (n < 1) n = 1;
+    if (const char *e = getenv("ZDW_GZIP_THREADS")) n = (unsigned)atoi(e);
+    return n > 64 ? 64 : n;
+}
 
 // The input read from a descriptor by the library's feeder thread (zdw_set_input_stream); with -i -v the bytes are also teed into
 // the temporary file the validation compares against (ConvertToZDW.cpp:786-803: the reference tees stdin the same way).
@@ -410,8 +460,9 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         cmd += " > ";
         cmd += tempName;
         OutPipe out;
-        out.f = popen(cmd.c_str(), "w");
-        if (!out.f) {
+        int gzLevel = 6;
+        const unsigned gzThreads = inProcessGzip(compressor == GZIP, zArgs, &gzLevel);
+        if (!out.open(cmd, tempName, gzThreads, gzLevel)) {
             statusOutput(ERROR, "Could not open the process '%s' for writing!\n", cmd.c_str());
             return FILE_CREATION_ERR;
         }
@@ -449,8 +500,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
             }
         }
         ok = out.finish() && ok;
-        const int childStatus = pclose(out.f);
-        out.f = NULL;
+        const int childStatus = out.close();
         if (res == OK && (!ok || childStatus != 0)) {
             statusOutput(ERROR, "Writing through '%s' failed\n", cmd.c_str());
             res = FILE_CREATION_ERR;
@@ -526,8 +576,9 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
     cmd += " > ";
     cmd += tempName;
     OutPipe out;
-    out.f = popen(cmd.c_str(), "w");
-    if (!out.f) {
+    int gzLevel = 6;
+    const unsigned gzThreads = inProcessGzip(compressor == GZIP, zArgs, &gzLevel);
+    if (!out.open(cmd, tempName, gzThreads, gzLevel)) {
         statusOutput(ERROR, "Could not open the process '%s' for writing!\n", cmd.c_str());
         return FILE_CREATION_ERR;
     }
@@ -633,8 +684,7 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
     }
 
     ok = out.finish() && ok;
-    const int childStatus = pclose(out.f);
-    out.f = NULL;
+    const int childStatus = out.close();
     clock.mark("compressor_drain");
     if (res == OK && (!ok || childStatus != 0)) {
         statusOutput(ERROR, "Writing through '%s' failed\n", cmd.c_str());

@@ -3,6 +3,7 @@
 // pass, then every non-flag argument is converted in order; any per-file failure turns the exit
 // code into CONVERSION_FAILED (2) while the detailed code is printed to stderr.
 #include "ConvertToZDW.h"
+#include "parallel_gzip.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -203,6 +204,24 @@ static int runCommandLine(int argc, char *argv[])
         }
     }
     return exitCode;
+}
+
+// The writer behind `.zdw.gz` on its own (parallel_gzip.h): `n` bytes handed over in pieces of `piece` bytes, deflated on `threads`
+// threads into `path`.  0: written.  (tests: the file must read back as the bytes, with gzip -d and with zlib)
+extern "C" int zdw_cli_gzip_bytes(const unsigned char *data, unsigned long long n, const char *path, unsigned threads, int level, unsigned long long piece)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return 2;
+    int rc = 0;
+    {
+        zdwhost::ParallelGzip gz(f, threads, level);
+        if (!piece) piece = n ? n : 1;
+        for (unsigned long long o = 0; o < n && rc == 0; o += piece)
+            if (!gz.write(data + o, (size_t)(n - o < piece ? n - o : piece))) rc = 1;
+        if (!gz.close()) rc = 1;
+    }
+    if (fclose(f) != 0) rc = 1;
+    return rc;
 }
 
 extern "C" int zdw_convertDWfile_main(int argc, char *argv[])
