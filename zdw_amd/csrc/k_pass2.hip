@@ -447,49 +447,87 @@ constexpr uint32_t P2S_IMG = 1024;      // emit: a row's output of up to about t
 __host__ __device__ inline uint32_t p2s_cand_bytes(uint32_t nused) { return (nused * 2u + 15u) & ~15u; }
 __host__ __device__ inline uint32_t p2s_img_bytes(uint32_t nused, bool emit) { return emit ? ((((nused + 7u) >> 3) + 15u) & ~15u) + 16u + P2S_IMG : 0u; }
 
-template <bool EMIT>
+// bytes of 0 / 1 -> a bit each, in byte order (16 columns of a map row)
+__device__ __forceinline__ uint32_t p2s_bits(const uint4 &x)
+{
+    const uint32_t M = 0x01020408u;
+    return ((x.x * M) >> 24 & 15u) | ((x.y * M) >> 24 & 15u) << 4 | ((x.z * M) >> 24 & 15u) << 8 | ((x.w * M) >> 24 & 15u) << 12;
+}
+constexpr uint32_t P2S_PIECES = 4;      // PRE: map rows of up to 4096 columns are read one row ahead (16 columns per lane and piece)
+
+template <bool EMIT, bool PRE>
 __global__ __launch_bounds__(64 * P2S_WAVES) void k_pass2_rows_sparse(const Pass2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t p2s_lds[];
     const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nflag = (a.nused + 7) >> 3;
-    // per wave: the candidates' columns (u16 each, at most nused), then (emit) the row's image: flag bytes, values
+    // per wave: the candidates (u16 each, at most nused: column | record in this row << 14 | in the row above << 15), then (emit)
+    // the row's image: flag bytes, values
     const uint32_t imgcap = p2s_img_bytes(a.nused, EMIT);
     const uint32_t per_wave = p2s_cand_bytes(a.nused) + imgcap;
     uint16_t *cand = reinterpret_cast<uint16_t *>(p2s_lds + (size_t)wv * per_wave);
     uint8_t *fimg = p2s_lds + (size_t)wv * per_wave + p2s_cand_bytes(a.nused);
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    // PRE: the map row is read while the row before it is worked on; its 16 bits per piece stay in a register and are
+    // "the row above" of the next row
+    auto load_row = [&](uint64_t r, uint4 (&v)[P2S_PIECES]) {
+        const uint8_t *m = a.nz + r * a.nz_stride;
+#pragma unroll
+        for (uint32_t k = 0; k < P2S_PIECES; ++k) {
+            const uint32_t c0 = k * 1024u + lane * 16u;
+            v[k] = c0 < a.nz_stride ? *reinterpret_cast<const uint4 *>(m + c0) : make_uint4(0, 0, 0, 0);
+        }
+    };
     // (a wave takes P2S_ROWS rows in a row: the map row above is the one it has just read, its output is one run of bytes)
-    for (uint64_t it = wave * P2S_ROWS; it < (((uint64_t)a.nrows + P2S_ROWS - 1) / P2S_ROWS) * P2S_ROWS; it += (it % P2S_ROWS == P2S_ROWS - 1) ? (nwaves - 1) * P2S_ROWS + 1 : 1) {
-        const uint64_t row = it;
-        if (row >= a.nrows) continue;
+    for (uint64_t g0 = wave * P2S_ROWS; g0 < a.nrows; g0 += nwaves * P2S_ROWS) {
+    uint32_t bcur[P2S_PIECES] = {0, 0, 0, 0}, bprev[P2S_PIECES] = {0, 0, 0, 0};
+    uint4 xn[P2S_PIECES];
+    if (PRE) {
+        uint4 yv[P2S_PIECES];
+        load_row(g0, xn);
+        if (g0) load_row(g0 - 1, yv);
+#pragma unroll
+        for (uint32_t k = 0; k < P2S_PIECES; ++k) { bcur[k] = p2s_bits(xn[k]); bprev[k] = g0 ? p2s_bits(yv[k]) : 0u; }
+    }
+    for (uint32_t r = 0; r < P2S_ROWS && g0 + r < a.nrows; ++r) {
+        const uint64_t row = g0 + r;
+        const bool more = r + 1 < P2S_ROWS && row + 1 < a.nrows;
+        if (PRE && more) load_row(row + 1, xn);
         const uint8_t *m1 = a.nz + row * a.nz_stride, *m0 = row ? m1 - a.nz_stride : nullptr;
         const bool all = row == 0 && !a.prev_is_zero;      // a shard's first row is compared with the halo row: every used column
         uint32_t cnt = 0;
         if (all) {
-            for (uint32_t u = lane; u < a.nused; u += 64) cand[u] = (uint16_t)a.used_col[u];
+            for (uint32_t u = lane; u < a.nused; u += 64) { const uint32_t c = a.used_col[u]; cand[u] = (uint16_t)(c | (m1[c] ? 0x4000u : 0u)); }
             cnt = a.nused;
         } else {
-            // 16 columns of the two map rows per lane and load (the map's bytes are 0 or 1): all loads of a row are in flight together
-            for (uint32_t cb = 0; cb < a.nz_stride; cb += 1024u) {
-                const uint32_t c0 = cb + lane * 16u;
-                uint4 x = make_uint4(0, 0, 0, 0), y = x;
-                if (c0 < a.nz_stride) {
-                    x = *reinterpret_cast<const uint4 *>(m1 + c0);
-                    if (m0) y = *reinterpret_cast<const uint4 *>(m0 + c0);
-                }
-                const uint32_t M = 0x01020408u;      // bytes of 0 / 1 -> a bit each, in byte order
-                uint32_t bits = (((x.x | y.x) * M) >> 24 & 15u) | (((x.y | y.y) * M) >> 24 & 15u) << 4 | (((x.z | y.z) * M) >> 24 & 15u) << 8 |
-                                (((x.w | y.w) * M) >> 24 & 15u) << 12;
+            // 16 columns of the two map rows per lane and piece (the map's bytes are 0 or 1)
+            auto compact = [&](uint32_t c0, uint32_t b1, uint32_t b0) {
+                uint32_t bits = b1 | b0;
                 uint32_t total;
                 uint32_t at = cnt + wave_excl_sum((uint32_t)__popc(bits), lane, total);
                 while (bits) {
                     const uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
                     bits &= bits - 1u;
-                    if (at < a.nused) cand[at] = (uint16_t)(c0 + b);
+                    // (the column, and which of the two rows has a record there: bits 14 and 15)
+                    if (at < a.nused) cand[at] = (uint16_t)((c0 + b) | ((b1 >> b & 1u) << 14) | ((b0 >> b & 1u) << 15));
                     ++at;
                 }
                 cnt += total;
+            };
+            if (PRE) {
+#pragma unroll
+                for (uint32_t k = 0; k < P2S_PIECES; ++k)
+                    if (k * 1024u < a.nz_stride) compact(k * 1024u + lane * 16u, bcur[k], bprev[k]);
+            } else {
+                for (uint32_t cb = 0; cb < a.nz_stride; cb += 1024u) {
+                    const uint32_t c0 = cb + lane * 16u;
+                    uint4 x = make_uint4(0, 0, 0, 0), y = x;
+                    if (c0 < a.nz_stride) {
+                        x = *reinterpret_cast<const uint4 *>(m1 + c0);
+                        if (m0) y = *reinterpret_cast<const uint4 *>(m0 + c0);
+                    }
+                    compact(c0, p2s_bits(x), p2s_bits(y));
+                }
             }
             cnt = cnt < a.nused ? cnt : a.nused;
         }
@@ -516,14 +554,13 @@ __global__ __launch_bounds__(64 * P2S_WAVES) void k_pass2_rows_sparse(const Pass
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 ok[j] = g + 64u * j + lane < cnt;
-                col[j] = ok[j] ? cand[g + 64u * j + lane] : 0u;
+                const uint32_t e = ok[j] ? cand[g + 64u * j + lane] : 0u;
+                col[j] = e & 0x3fffu; n1[j] = e >> 14 & 1u; n0[j] = e >> 15;
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 meta[j] = ok[j] ? a.col_meta[col[j]] : 0xFFFFFFull;      // which used column (24 bits), kind (2), stored size (4), record offset (32)
                 base[j] = ok[j] ? a.col_meta[a.nz_cols + col[j]] : 0ull;   // the column's base value
-                n1[j] = ok[j] ? m1[col[j]] : 0u;
-                n0[j] = (ok[j] && m0) ? m0[col[j]] : 0u;
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -597,6 +634,11 @@ __global__ __launch_bounds__(64 * P2S_WAVES) void k_pass2_rows_sparse(const Pass
         } else if (lane == 0) {
             a.row_len[row] = run;
         }
+        if (PRE) {
+#pragma unroll
+            for (uint32_t k = 0; k < P2S_PIECES; ++k) { bprev[k] = bcur[k]; if (more) bcur[k] = p2s_bits(xn[k]); }
+        }
+    }
     }
 }
 
@@ -610,7 +652,8 @@ static void launch_pass2_sparse(const Pass2Args &a, hipStream_t s)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t want = ((uint64_t)a.nrows + P2S_WAVES * P2S_ROWS - 1) / (P2S_WAVES * P2S_ROWS);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * 8);
-    hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
+    if (a.nz_stride <= 1024u * P2S_PIECES && !getenv("ZDW_P2S_NO_PRE")) hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT, true>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
+    else hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT, false>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
 }
 
 template <bool EMIT>

@@ -876,7 +876,7 @@ int prepare_pass2(zdw_ctx *c, Pass2Args &a, hipStream_t s = nullptr)
     if (c->nz_mode && !c->rec_dense) {
         // rows by the map of non-zero records (k_pass2_rows_sparse) when a row's candidates fit its LDS; else the whole matrix
         const size_t per_wave = (((size_t)nu * 2 + 15) & ~(size_t)15) + ((((size_t)nu + 7) / 8 + 15) & ~(size_t)15) + 16 + 1024;      // (k_pass2.hip: p2s_*_bytes)
-        if (per_wave * 4 <= 60 * 1024 && c->ncols <= 65536 && !getenv("ZDW_P2_DENSE")) {
+        if (per_wave * 4 <= 60 * 1024 && c->ncols <= 16384 && !getenv("ZDW_P2_DENSE")) {
             // per schema column: which used column it is and that column's facts; then per used column its schema column
             std::vector<uint64_t> maps((size_t)c->ncols * 2 + (nu + 1) / 2, 0xFFFFFFull);
             uint32_t *ucol = reinterpret_cast<uint32_t *>(maps.data() + (size_t)c->ncols * 2);
