@@ -1862,8 +1862,10 @@ int zdw_shard_last_row(zdw_ctx *c, uint64_t *stored)
     (void)hipSetDevice(c->device);
     int rc = ensure_dict(c);                    // stored values of text columns are dictionary offsets
     if (rc) return rc;
-    rc = ensure_dense_rec(c);                   // (the last row's records, whichever columns they are in)
-    if (rc) return rc;
+    if (c->nz_mode && !c->rec_dense && c->nrows) {      // the last row's records, whichever columns they are in: that row is completed from the map
+        launch_rec_zero_fill(c->rec.as<uint8_t>() + (uint64_t)(c->nrows - 1) * c->rec_stride, c->rec_stride, 1, c->ncols, c->d_kind.as<uint8_t>(),
+                             c->d_recoff.as<uint32_t>(), c->nz.as<uint8_t>() + (uint64_t)(c->nrows - 1) * c->nz_stride, c->nz_stride, c->stream);
+    }
     Pass2Args a;
     rc = prepare_pass2(c, a);
     if (rc) return rc;
