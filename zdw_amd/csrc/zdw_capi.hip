@@ -752,7 +752,7 @@ int ensure_dense_rec(zdw_ctx *c);
 int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res)
 {
     hipStream_t s = c->stream;
-    { int rcd = ensure_dense_rec(c); if (rcd) return rcd; }
+    const bool sparse = c->nz_mode && !c->rec_dense;      // (the matrix means something only where the map says so: the scan goes by the map too)
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -768,7 +768,7 @@ int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zd
         StageScope ts(c, ZDW_STAGE_PASS1);
         launch_trim_block(c->rec.as<uint8_t>(), c->rec_stride, c->ncols, c->d_kind.as<uint8_t>(), c->d_recoff.as<uint32_t>(), row, fields,
                           c->lenp1.as<uint8_t>(), c->col_min.as<uint64_t>(), c->col_max.as<uint64_t>(), c->col_seen.as<uint8_t>(),
-                          c->uniq_len.as<uint32_t>(), u, d_entries, s);
+                          c->uniq_len.as<uint32_t>(), u, d_entries, sparse ? c->nz.as<uint8_t>() : nullptr, c->nz_stride, s);
     }
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));

@@ -148,7 +148,7 @@ void launch_model_trip(const uint64_t *excl, uint32_t nreal, double base_mb, dou
 void launch_locate_field(const uint8_t *in, uint64_t lo, uint64_t p, uint64_t *out, hipStream_t s);
 void launch_trim_block(const uint8_t *rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff, uint32_t rows,
                        uint32_t partial, uint8_t *live, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids,
-                       uint32_t *entries, hipStream_t s);
+                       uint32_t *entries, const uint8_t *nz, uint32_t nz_stride, hipStream_t s);
 // range-partitioned dictionary (multi-GPU)
 void launch_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                      const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys, hipStream_t s);
