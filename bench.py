@@ -463,16 +463,16 @@ def main():
         copy_gbps = stream_copy_gbps(torch, buf)
         res["roofline"]["stream_copy"] = {"measured": round(copy_gbps, 1), "unit": "GB/s (read + write)",
                                           "frac_of_it": round(achieved / copy_gbps, 4) if copy_gbps else None}
-        if not args.no_cpu:
-            # bounded sample: whole rows from the head of rank 0's table
+        if not args.no_cpu and world == 1:
+            # bounded sample: whole rows from the head of rank 0's table (N = 1 only: the other ranks would sit in the barrier)
             want = int(min(args.cpu_mb * 1e6, nbytes))
             head = buf[:want].cpu().numpy().tobytes()
             cut = head.rfind(b"\n") + 1
             res["cpu_baseline"] = cpu_baseline(table.desc, head[:cut])
             res["cpu_baseline"]["host_cores"] = os.cpu_count()
         else:
-            res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 1, "kind": "port", "sample": "skipped (--no-cpu)"}
-        if not args.no_e2e and not args.pass1_only:
+            res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 1, "kind": "reference", "sample": "skipped (--no-cpu, or N > 1: measured at N = 1)"}
+        if not args.no_e2e and not args.pass1_only and world == 1:
             enc.close()
             del buf
             torch.cuda.empty_cache()
