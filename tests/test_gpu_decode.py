@@ -75,6 +75,25 @@ def test_multi_block_stream_and_errors(dec, sandbox):
     assert rc == 5
 
 
+@pytest.mark.parametrize("ncols,group", [(70, ""), (130, ""), (190, "1"), (190, "2"), (300, ""), (500, ""), (500, "8"), (513, "")])
+def test_column_groups_of_the_row_kernel(dec, sandbox, ncols, group, monkeypatch):
+    """Schemas of 2 .. 8 batches of 64 columns (and one just beyond, which takes the direct kernel): a wave puts together a group of
+    batches of a row, groups of one row meet at the offsets the lengths kernel left.  Against the Python test decoder."""
+    from tests import zdw_decode
+    from tests.test_decode_cpu import _render
+    from zdw_amd import synth
+    if group:
+        monkeypatch.setenv("ZDW_DEC_GROUP", group)
+    desc, types, tsv = synth.make_table(seed=200 + ncols, ncols=ncols, nrows=700)
+    rc, z = sandbox.run(desc, tsv, args=["-q"])
+    assert rc == 0
+    rc, text, blocks = dec.decode_all(z)
+    assert rc == 0, dec.error()
+    zz, rows = zdw_decode.decode(z)
+    want = _render(zz, rows)
+    assert text == want, next(i for i in range(min(len(text), len(want))) if text[i] != want[i]) if len(text) == len(want) else (len(text), len(want))
+
+
 def test_rows_that_all_repeat_the_row_above(dec, sandbox):
     """A table whose rows are all the same: after the first, every row is nothing but zero flag bytes, and on such data row chains
     of different phase never meet -- the guesses of the parallel walk are wrong and are corrected pass by pass.  The text is still

@@ -346,20 +346,62 @@ __device__ __forceinline__ void store_exact(uint8_t *dst, const Text24 &t, uint3
     if (r & 2u) { const uint16_t x = (uint16_t)w; __builtin_memcpy(dst + o, &x, 2); w >>= 16; o += 2; }
     if (r & 1u) dst[o] = (uint8_t)w;
 }
-// decimal digits of v in front of what t holds (nd of them: dec_digits(v))
-__device__ __forceinline__ void t24_digits(Text24 &t, uint64_t v)
+// Decimal digits without a loop: four digits at a time by multiplications that are exact on the ranges they see (24-bit ones: the
+// full-rate multiplier), eight ASCII digits per 64-bit word with the most significant in byte 0, i.e. in text order.
+__device__ __forceinline__ uint32_t dec_ascii4(uint32_t v)          // v < 10000: "dddd" (leading zeros kept)
 {
-    if (v >> 32) {                                   // nine digits at a time while the value needs 64-bit arithmetic
-        do {
-            const uint64_t q = v / 1000000000ull;
-            uint32_t lo = (uint32_t)(v - q * 1000000000ull);
-            for (int i = 0; i < 9; ++i) { const uint32_t d = lo / 10u; t24_push_front(t, '0' + (lo - d * 10u)); lo = d; }
-            v = q;
-        } while (v >> 32);
-        if (v == 0) return;
+    const uint32_t q100 = __umul24(v, 10486u) >> 20;                 // v / 100 (exact below 43668)
+    const uint32_t r100 = v - __umul24(q100, 100u);
+    const uint32_t w = q100 | (r100 << 16);                          // two numbers below 100 in 16-bit halves
+    const uint32_t q10 = (__umul24(w, 103u) >> 10) & 0x000f000fu;    // each / 10 (exact below 179; the halves do not meet)
+    const uint32_t r10 = w - __umul24(q10, 10u);
+    return (q10 | (r10 << 8)) + 0x30303030u;
+}
+__device__ __forceinline__ uint64_t dec_ascii8(uint32_t v)          // v < 10^8
+{
+    const uint32_t hi = __umulhi(v, 0xD1B71759u) >> 13;              // v / 10000
+    const uint32_t lo = v - hi * 10000u;
+    return (uint64_t)dec_ascii4(hi) | ((uint64_t)dec_ascii4(lo) << 32);
+}
+// t |= the 8 bytes of d at byte position pos (0..16)
+__device__ __forceinline__ void t24_or_at(Text24 &t, uint32_t pos, uint64_t d)
+{
+    const uint32_t sh = 8u * (pos & 7u);
+    const uint64_t lo = d << sh, hi = sh ? d >> (64u - sh) : 0ull;
+    const uint32_t idx = pos >> 3;                      // (selects, not branches: an indexed struct would live in scratch memory)
+    t.w0 |= idx == 0u ? lo : 0ull;
+    t.w1 |= idx == 0u ? hi : (idx == 1u ? lo : 0ull);
+    t.w2 |= idx == 1u ? hi : (idx == 2u ? lo : 0ull);
+}
+// the nd = dec_digits(v) decimal digits of v at the front of t (which is empty)
+__device__ __forceinline__ void t24_digits(Text24 &t, uint64_t v, uint32_t nd)
+{
+    if (v < 100000000ull) {                                          // nd <= 8
+        t.w0 = dec_ascii8((uint32_t)v) >> (8u * (8u - nd));
+        return;
     }
-    uint32_t x = (uint32_t)v;
-    do { const uint32_t d = x / 10u; t24_push_front(t, '0' + (x - d * 10u)); x = d; } while (x);
+    if (!(v >> 32)) {                                                // 9 or 10 digits: all in 32-bit arithmetic
+        const uint32_t x = (uint32_t)v;
+        const uint32_t qh = __umulhi(x >> 8, 0xABCC7712u) >> 18;     // x / 10^8 (10^8 = 2^8 * 390625; exact below 2^32), at most 42
+        const uint32_t k = nd - 8u;
+        t.w0 = (uint64_t)(dec_ascii4(qh) >> (8u * (4u - k)));
+        t24_or_at(t, k, dec_ascii8(x - qh * 100000000u));
+        return;
+    }
+    const uint64_t q = v / 100000000ull;
+    const uint64_t d_low = dec_ascii8((uint32_t)(v - q * 100000000ull));
+    if (q < 100000000ull) {                                          // up to 16 digits: k of them in front of the low eight
+        const uint32_t k = nd - 8u;
+        t.w0 = dec_ascii8((uint32_t)q) >> (8u * (8u - k));
+        t24_or_at(t, k, d_low);
+        return;
+    }
+    const uint32_t q2 = (uint32_t)(q / 100000000ull);                // 17..20 digits: below 10^4
+    const uint64_t d_mid = dec_ascii8((uint32_t)(q - (uint64_t)q2 * 100000000ull));
+    const uint32_t k = nd - 16u;
+    t.w0 = (uint64_t)(dec_ascii4(q2) >> (8u * (4u - k)));
+    t24_or_at(t, k, d_mid);
+    t24_or_at(t, k + 8u, d_low);
 }
 // n bytes from src, then the separator
 __device__ inline void dec_copy_sep(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t sep)
@@ -407,8 +449,9 @@ __device__ __forceinline__ uint32_t dec_field(uint32_t type, bool used, uint64_t
         uint64_t x = (used && val) ? val + base : 0;
         uint32_t neg = 0;
         if (cls == 4 && (int64_t)x < 0) { neg = 1; x = 0ull - x; }
-        n = neg + dec_digits(x);
-        if (EMIT) { t24_digits(t, x); if (neg) t24_push_front(t, '-'); }
+        const uint32_t nd = dec_digits(x);
+        n = neg + nd;
+        if (EMIT) { t24_digits(t, x, nd); if (neg) t24_push_front(t, '-'); }
     }
     if (EMIT) { t24_set(t, n, sep); store_exact(dst, t, n + 1u); }
     return n + 1u;
@@ -495,8 +538,9 @@ __device__ __forceinline__ DecField dec_prepare(uint32_t type, bool used, uint64
         uint64_t x = (used && val) ? val + base : 0;
         uint32_t neg = 0;
         if (cls == 4 && (int64_t)x < 0) { neg = 1; x = 0ull - x; }
-        f.len = neg + dec_digits(x);
-        t24_digits(f.t, x);
+        const uint32_t nd = dec_digits(x);
+        f.len = neg + nd;
+        t24_digits(f.t, x, nd);
         if (neg) t24_push_front(f.t, '-');
     }
     return f;
@@ -520,58 +564,83 @@ __device__ __forceinline__ void dec_put_lds(uint32_t at, DecField &f, uint32_t s
     }
 }
 
+// A wave's unit of work: a tile of 64 rows x a group of NB batches of 64 columns (the whole row when the schema has no more).  A
+// group's piece of a row begins where the lengths kernel said (pre).
 template <uint32_t NB>
-__global__ __launch_bounds__(256) void k_dec_rows(const DecText a, uint64_t ntiles)
+__global__ __launch_bounds__(256) void k_dec_rows(const DecText a, uint64_t ntiles, uint32_t nbatch, uint32_t ngroups)
 {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t buf = wv * DEC_ROWBUF;                       // this wave's row buffer in LDS
-    // the wave's columns: the same in every tile
-    bool col[NB]; int32_t u[NB]; uint32_t type[NB], sep[NB]; uint64_t base[NB];
+    for (uint64_t unit = wave; unit < ntiles * ngroups; unit += nwaves) {
+        const uint64_t tile = unit / ngroups;
+        const uint32_t b0 = (uint32_t)(unit - tile * ngroups) * NB;          // the group's first batch
+        const bool last_group = b0 + NB >= nbatch;
+        // the wave's columns
+        bool col[NB]; int32_t u[NB]; uint32_t type[NB], sep[NB]; uint64_t base[NB];
 #pragma unroll
-    for (uint32_t b = 0; b < NB; ++b) {
-        const uint32_t c = b * 64u + lane;
-        col[b] = c < a.ncols;
-        u[b] = col[b] ? a.used_of[c] : -1;
-        type[b] = col[b] ? a.type[c] : 0u;
-        base[b] = u[b] >= 0 ? a.ubase[u[b]] : 0ull;
-        sep[b] = c + 1u == a.ncols ? '\n' : '\t';
-    }
-    for (uint64_t tile = wave; tile < ntiles; tile += nwaves) {
+        for (uint32_t b = 0; b < NB; ++b) {
+            const uint32_t c = (b0 + b) * 64u + lane;
+            col[b] = c < a.ncols;
+            u[b] = col[b] ? a.used_of[c] : -1;
+            type[b] = col[b] ? a.type[c] : 0u;
+            base[b] = u[b] >= 0 ? a.ubase[u[b]] : 0ull;
+            sep[b] = c + 1u == a.ncols ? '\n' : '\t';
+        }
         const uint64_t r0 = tile * DEC_TILE, r1 = r0 + DEC_TILE < a.nrows ? r0 + DEC_TILE : a.nrows;
         uint64_t val[NB];
 #pragma unroll
         for (uint32_t b = 0; b < NB; ++b) val[b] = u[b] >= 0 ? a.carry[tile * a.nused + (uint32_t)u[b]] : 0ull;
+        // a row's flag bytes and values are requested one row ahead (a value is read whether its flag is set or not: V has a cell
+        // for every used column of every row)
+        uint32_t fb[NB], fb_next[NB];
+        uint64_t vv[NB], vv_next[NB];
+        auto request = [&](uint64_t r, uint32_t (&f)[NB], uint64_t (&v)[NB]) {
+            const uint64_t p = a.rstart[r];
+#pragma unroll
+            for (uint32_t b = 0; b < NB; ++b) {
+                f[b] = u[b] >= 0 ? a.rows[p + ((uint32_t)u[b] >> 3)] : 0u;
+                v[b] = u[b] >= 0 ? a.V[r * a.nused + (uint32_t)u[b]] : 0ull;
+            }
+        };
+        request(r0, fb, vv);
         for (uint64_t r = r0; r < r1; ++r) {
-            const uint64_t p = a.rstart[r], o0 = a.rowoff[r];
-            const uint32_t rowlen = (uint32_t)(a.rowoff[r + 1] - o0);
-            const bool in_lds = rowlen <= DEC_ROWBUF;
+            // this group's piece of the row: [o0, o0 + seglen) of the text
+            const uint64_t row0 = a.rowoff[r];
+            const uint32_t at0 = a.pre[r * nbatch + b0];
+            const uint32_t at1 = last_group ? (uint32_t)(a.rowoff[r + 1] - row0) : a.pre[r * nbatch + b0 + NB];
+            const uint64_t o0 = row0 + at0;
+            const uint32_t seglen = at1 - at0;
+            const bool in_lds = seglen <= DEC_ROWBUF;
+            if (r + 1 < r1) request(r + 1, fb_next, vv_next);
             uint32_t run = 0;
 #pragma unroll
             for (uint32_t b = 0; b < NB; ++b) {
-                if (u[b] >= 0 && ((a.rows[p + ((uint32_t)u[b] >> 3)] >> ((uint32_t)u[b] & 7u)) & 1u)) val[b] = a.V[r * a.nused + (uint32_t)u[b]];
+                if (u[b] >= 0 && ((fb[b] >> ((uint32_t)u[b] & 7u)) & 1u)) val[b] = vv[b];
                 DecField f = dec_prepare(type[b], u[b] >= 0, val[b], base[b], a.dict, a.dsize);
                 const uint32_t len = col[b] ? f.len + 1u : 0u;
                 uint32_t total;
                 const uint32_t off = wave_excl_sum(len, lane, total);
                 if (col[b]) {
                     if (in_lds) dec_put_lds(buf + run + off, f, sep[b]);
-                    else (void)dec_field<true>(type[b], u[b] >= 0, val[b], base[b], a.dict, a.dsize, a.out + o0 + run + off, sep[b]);      // a row longer than the buffer
+                    else (void)dec_field<true>(type[b], u[b] >= 0, val[b], base[b], a.dict, a.dsize, a.out + o0 + run + off, sep[b]);      // a piece longer than the buffer
                 }
                 run += total;
             }
             if (in_lds) {
                 __builtin_amdgcn_wave_barrier();
-                // out[o0, o0 + rowlen) <- buffer: whole 16-byte pieces, then what is left byte by byte
+                // out[o0, o0 + seglen) <- buffer: whole 16-byte pieces, then what is left byte by byte
                 uint8_t *dst = a.out + o0;
-                const uint32_t whole = rowlen & ~15u;
+                const uint32_t whole = seglen & ~15u;
                 for (uint32_t k = lane * 16u; k < whole; k += 64u * 16u) {
                     const uint4 w = *reinterpret_cast<const uint4 *>(zdw_lds + buf + k);
                     __builtin_memcpy(dst + k, &w, 16);
                 }
-                if (lane < (rowlen & 15u)) dst[whole + lane] = zdw_lds[buf + whole + lane];
+                if (lane < (seglen & 15u)) dst[whole + lane] = zdw_lds[buf + whole + lane];
                 __builtin_amdgcn_wave_barrier();
             }
+#pragma unroll
+            for (uint32_t b = 0; b < NB; ++b) { fb[b] = fb_next[b]; vv[b] = vv_next[b]; }
         }
     }
 }
@@ -942,11 +1011,17 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
         a.out = d->text.as<uint8_t>();
         const size_t shm = 4 * DEC_ROWBUF;
         if (cbatch <= 8 && !getenv("ZDW_DEC_DIRECT")) {
-            const uint32_t g = grid_for(ntiles);
-            if (cbatch <= 1) hipLaunchKernelGGL((k_dec_rows<1>), dim3(g), dim3(256), shm, s, a, ntiles);
-            else if (cbatch <= 2) hipLaunchKernelGGL((k_dec_rows<2>), dim3(g), dim3(256), shm, s, a, ntiles);
-            else if (cbatch <= 4) hipLaunchKernelGGL((k_dec_rows<4>), dim3(g), dim3(256), shm, s, a, ntiles);
-            else hipLaunchKernelGGL((k_dec_rows<8>), dim3(g), dim3(256), shm, s, a, ntiles);
+            // batches per wave: 10 GB x 200 columns, 1 / 2 / 4 per wave: 21.8 / 21.4 / 20.9 ms (the walk is not short of waves);
+            // schemas of 5..8 batches take two groups of 4 (8 in one wave: 207 registers, 2 waves per SIMD)
+            uint32_t nb = cbatch <= 1 ? 1u : cbatch <= 2 ? 2u : 4u;
+            if (const char *e = getenv("ZDW_DEC_GROUP")) { const int v = atoi(e); nb = v >= 8 ? 8u : v >= 4 ? 4u : v >= 2 ? 2u : 1u; }      // (A/B measurements)
+            while (nb > 1 && nb / 2 >= cbatch) nb /= 2;
+            const uint32_t ngroups = (cbatch + nb - 1) / nb;
+            const uint32_t g = grid_for(ntiles * ngroups);
+            if (nb == 1) hipLaunchKernelGGL((k_dec_rows<1>), dim3(g), dim3(256), shm, s, a, ntiles, cbatch, ngroups);
+            else if (nb == 2) hipLaunchKernelGGL((k_dec_rows<2>), dim3(g), dim3(256), shm, s, a, ntiles, cbatch, ngroups);
+            else if (nb == 4) hipLaunchKernelGGL((k_dec_rows<4>), dim3(g), dim3(256), shm, s, a, ntiles, cbatch, ngroups);
+            else hipLaunchKernelGGL((k_dec_rows<8>), dim3(g), dim3(256), shm, s, a, ntiles, cbatch, ngroups);
         } else {
             hipLaunchKernelGGL((k_dec_text<true>), dim3(grid_for(ntiles)), dim3(256), 0, s, a, ntiles, cbatch);
         }
