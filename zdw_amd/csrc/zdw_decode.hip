@@ -489,9 +489,13 @@ __global__ __launch_bounds__(256) void k_dec_text(const DecText a, uint64_t ntil
             const uint64_t base = u >= 0 ? a.ubase[u] : 0ull;
             const uint32_t sep = c + 1u == a.ncols ? '\n' : '\t';
             uint64_t val = u >= 0 ? a.carry[tile * a.nused + (uint32_t)u] : 0ull;
+            // (the next row's flag byte and value are requested while this one is worked on; a value is read whether flagged or not)
+            uint32_t fcur = u >= 0 ? a.rows[a.rstart[r0] + ((uint32_t)u >> 3)] : 0u, fnext = 0;
+            uint64_t vcur = u >= 0 ? a.V[r0 * a.nused + (uint32_t)u] : 0ull, vnext = 0;
             for (uint64_t r = r0; r < r1; ++r) {
-                const uint64_t p = a.rstart[r];
-                if (u >= 0 && ((a.rows[p + ((uint32_t)u >> 3)] >> ((uint32_t)u & 7u)) & 1u)) val = a.V[r * a.nused + (uint32_t)u];
+                if (u >= 0 && r + 1 < r1) { fnext = a.rows[a.rstart[r + 1] + ((uint32_t)u >> 3)]; vnext = a.V[(r + 1) * a.nused + (uint32_t)u]; }
+                if (u >= 0 && ((fcur >> ((uint32_t)u & 7u)) & 1u)) val = vcur;
+                fcur = fnext; vcur = vnext;
                 const uint32_t ri = (uint32_t)(r - r0);
                 const uint32_t len = col ? dec_field<false>(type, u >= 0, val, base, a.dict, a.dsize, nullptr, sep) : 0u;
                 uint32_t total;
