@@ -609,7 +609,7 @@ void launch_locate_field(const uint8_t *in, uint64_t lo, uint64_t p, uint64_t *o
 __global__ __launch_bounds__(256) void k_trim_scan(const uint8_t *__restrict__ rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *__restrict__ col_kind,
                                                    const uint32_t *__restrict__ col_recoff, uint32_t rows, uint32_t partial, uint8_t *__restrict__ live,
                                                    uint64_t *__restrict__ col_min, uint64_t *__restrict__ col_max, uint8_t *__restrict__ col_seen,
-                                                   const uint8_t *__restrict__ nz, uint32_t nz_stride)
+                                                   const uint32_t *__restrict__ nz, uint32_t nz_stride)
 {
     constexpr uint32_t TILE = 32;
     const uint64_t r0 = (uint64_t)blockIdx.x * TILE;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void k_trim_scan(const uint8_t *__restrict__ r
         uint64_t mn = ~0ull, mx = 0;
         bool seen = false;
         for (uint64_t r = r0; r < stop; ++r) {
-            if (nz && !nz[r * nz_stride + col]) continue;               // (a matrix written through the map of non-zero records: zero elsewhere)
+            if (nz && !((nz[r * nz_stride + (col >> 5)] >> (col & 31u)) & 1u)) continue;               // (a matrix written through the map of non-zero records: zero elsewhere)
             const uint8_t *p = rec + r * rec_stride + off;
             if (kind == K_TEXT) {
                 const uint32_t id1 = *reinterpret_cast<const uint32_t *>(p);
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void k_trim_ids(const uint8_t *__restrict__ li
 }
 void launch_trim_block(const uint8_t *rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff, uint32_t rows,
                        uint32_t partial, uint8_t *live, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids,
-                       uint32_t *entries, const uint8_t *nz, uint32_t nz_stride, hipStream_t s)
+                       uint32_t *entries, const uint32_t *nz, uint32_t nz_stride, hipStream_t s)
 {
     const uint64_t last = (uint64_t)rows + (partial ? 1u : 0u);
     if (last) hipLaunchKernelGGL(k_trim_scan, dim3((uint32_t)((last + 31) / 32)), dim3(256), 0, s, rec, rec_stride, ncols, col_kind, col_recoff, rows, partial,

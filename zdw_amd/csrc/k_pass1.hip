@@ -650,7 +650,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (pending) slow = true;
             if (!slow && in_block && !(a.debug_skip & 4u)) {
                 *reinterpret_cast<uint32_t *>(recp) = id;
-                if (SKIP && a.nz && id) a.nz[(uint64_t)row * a.nz_stride + col] = 1;
+                if (SKIP && a.nz && id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
             }
         }
         adopt_ids(ws.ids, ftm);
@@ -698,7 +698,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 if (v_range > 0) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
                 if (in_block && !(a.debug_skip & 4u)) {
                     *reinterpret_cast<uint64_t *>(recp) = v_rec;
-                    if (SKIP && a.nz && v_rec) a.nz[(uint64_t)row * a.nz_stride + col] = 1;
+                    if (SKIP && a.nz && v_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
                 }
             }
         }
@@ -1137,23 +1137,23 @@ __global__ __launch_bounds__(256) void k_pass1_deferred(const Pass1Args a, uint3
     }
 }
 
-// rec[row][column] := 0 wherever nz[row][column] is clear
+// rec[row][column] := 0 wherever bit `column` of the map's row is clear
 __global__ __launch_bounds__(256) void k_rec_zero_fill(uint8_t *__restrict__ rec, uint32_t rec_stride, uint32_t nrows, uint32_t ncols,
                                                        const uint8_t *__restrict__ col_kind, const uint32_t *__restrict__ col_recoff,
-                                                       const uint8_t *__restrict__ nz, uint32_t nz_stride)
+                                                       const uint32_t *__restrict__ nz, uint32_t nz_stride)
 {
     for (uint32_t row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const uint8_t *m = nz + (uint64_t)row * nz_stride;
+        const uint32_t *m = nz + (uint64_t)row * nz_stride;
         uint8_t *r = rec + (uint64_t)row * rec_stride;
         for (uint32_t c = threadIdx.x; c < ncols; c += blockDim.x) {
-            if (m[c]) continue;
+            if ((m[c >> 5] >> (c & 31u)) & 1u) continue;
             if (col_kind[c] == K_TEXT) *reinterpret_cast<uint32_t *>(r + col_recoff[c]) = 0u;
             else *reinterpret_cast<uint64_t *>(r + col_recoff[c]) = 0ull;
         }
     }
 }
 void launch_rec_zero_fill(uint8_t *rec, uint32_t rec_stride, uint32_t nrows, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff,
-                          const uint8_t *nz, uint32_t nz_stride, hipStream_t s)
+                          const uint32_t *nz, uint32_t nz_stride, hipStream_t s)
 {
     if (!nrows || !ncols) return;
     hipLaunchKernelGGL(k_rec_zero_fill, dim3(nrows < 65536u ? nrows : 65536u), dim3(256), 0, s, rec, rec_stride, nrows, ncols, col_kind, col_recoff, nz, nz_stride);

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, P2_R <= 8 ? 7 : 4) void k_pass2_emit_cols_pipe
 // ------------------------------------------------------------------------------------------
 // rows of mostly empty fields: a wave per row, going by the map of non-zero records (Pass2Args.nz)
 // ------------------------------------------------------------------------------------------
-// Pass 1 left rec valid only where nz[row][column] is set.  A column can change between row r - 1 and row r only where one of
+// Pass 1 left rec valid only where the map (a bit per field) is set.  A column can change between row r - 1 and row r only where one of
 // the two has a record: those columns (in column order) are gathered from the two rows of the map into LDS, and only they are
 // looked at -- tens of the thousands of columns such tables have.  Flags, stored values and their order are what the column
 // kernels above produce: flag = the raw values differ (first row: first_row_flag), value = stored_from_raw, in column order.
@@ -459,13 +459,7 @@ constexpr uint32_t P2S_IMG = 1024;      // emit: a row's output of up to about t
 __host__ __device__ inline uint32_t p2s_cand_bytes(uint32_t nused) { return (nused * 2u + 15u) & ~15u; }
 __host__ __device__ inline uint32_t p2s_img_bytes(uint32_t nused, bool emit) { return emit ? ((((nused + 7u) >> 3) + 15u) & ~15u) + 16u + P2S_IMG : 0u; }
 
-// bytes of 0 / 1 -> a bit each, in byte order (16 columns of a map row)
-__device__ __forceinline__ uint32_t p2s_bits(const uint4 &x)
-{
-    const uint32_t M = 0x01020408u;
-    return ((x.x * M) >> 24 & 15u) | ((x.y * M) >> 24 & 15u) << 4 | ((x.z * M) >> 24 & 15u) << 8 | ((x.w * M) >> 24 & 15u) << 12;
-}
-constexpr uint32_t P2S_PIECES = 4;      // PRE: map rows of up to 4096 columns are read one row ahead (16 columns per lane and piece)
+constexpr uint32_t P2S_PIECES = 2;      // PRE: map rows of up to 4096 columns are read one row ahead (a word of 32 columns per lane and piece)
 
 template <bool EMIT, bool PRE>
 __global__ __launch_bounds__(64 * P2S_WAVES) void k_pass2_rows_sparse(const Pass2Args a)
@@ -480,39 +474,35 @@ __global__ __launch_bounds__(64 * P2S_WAVES) void k_pass2_rows_sparse(const Pass
     uint16_t *cand = reinterpret_cast<uint16_t *>(p2s_lds + (size_t)wv * per_wave);
     uint8_t *fimg = p2s_lds + (size_t)wv * per_wave + p2s_cand_bytes(a.nused);
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    // PRE: the map row is read while the row before it is worked on; its 16 bits per piece stay in a register and are
-    // "the row above" of the next row
-    auto load_row = [&](uint64_t r, uint4 (&v)[P2S_PIECES]) {
-        const uint8_t *m = a.nz + r * a.nz_stride;
+    // PRE: the map row is read while the row before it is worked on; its word per piece stays in a register and is "the row
+    // above" of the next row
+    auto load_row = [&](uint64_t r, uint32_t (&v)[P2S_PIECES]) {
+        const uint32_t *m = a.nz + r * a.nz_stride;
 #pragma unroll
         for (uint32_t k = 0; k < P2S_PIECES; ++k) {
-            const uint32_t c0 = k * 1024u + lane * 16u;
-            v[k] = c0 < a.nz_stride ? *reinterpret_cast<const uint4 *>(m + c0) : make_uint4(0, 0, 0, 0);
+            const uint32_t w = k * 64u + lane;
+            v[k] = w < a.nz_stride ? m[w] : 0u;
         }
     };
     // (a wave takes P2S_ROWS rows in a row: the map row above is the one it has just read, its output is one run of bytes)
     for (uint64_t g0 = wave * P2S_ROWS; g0 < a.nrows; g0 += nwaves * P2S_ROWS) {
-    uint32_t bcur[P2S_PIECES] = {0, 0, 0, 0}, bprev[P2S_PIECES] = {0, 0, 0, 0};
-    uint4 xn[P2S_PIECES];
+    uint32_t bcur[P2S_PIECES] = {}, bprev[P2S_PIECES] = {}, xn[P2S_PIECES] = {};
     if (PRE) {
-        uint4 yv[P2S_PIECES];
-        load_row(g0, xn);
-        if (g0) load_row(g0 - 1, yv);
-#pragma unroll
-        for (uint32_t k = 0; k < P2S_PIECES; ++k) { bcur[k] = p2s_bits(xn[k]); bprev[k] = g0 ? p2s_bits(yv[k]) : 0u; }
+        load_row(g0, bcur);
+        if (g0) load_row(g0 - 1, bprev);
     }
     for (uint32_t r = 0; r < P2S_ROWS && g0 + r < a.nrows; ++r) {
         const uint64_t row = g0 + r;
         const bool more = r + 1 < P2S_ROWS && row + 1 < a.nrows;
         if (PRE && more) load_row(row + 1, xn);
-        const uint8_t *m1 = a.nz + row * a.nz_stride, *m0 = row ? m1 - a.nz_stride : nullptr;
+        const uint32_t *m1 = a.nz + row * a.nz_stride, *m0 = row ? m1 - a.nz_stride : nullptr;
         const bool all = row == 0 && !a.prev_is_zero;      // a shard's first row is compared with the halo row: every used column
         uint32_t cnt = 0;
         if (all) {
-            for (uint32_t u = lane; u < a.nused; u += 64) { const uint32_t c = a.used_col[u]; cand[u] = (uint16_t)(c | (m1[c] ? 0x4000u : 0u)); }
+            for (uint32_t u = lane; u < a.nused; u += 64) { const uint32_t c = a.used_col[u]; cand[u] = (uint16_t)(c | (((m1[c >> 5] >> (c & 31u)) & 1u) << 14)); }
             cnt = a.nused;
         } else {
-            // 16 columns of the two map rows per lane and piece (the map's bytes are 0 or 1)
+            // 32 columns of the two map rows per lane and piece
             auto compact = [&](uint32_t c0, uint32_t b1, uint32_t b0) {
                 uint32_t bits = b1 | b0;
                 uint32_t total;
@@ -529,16 +519,16 @@ __global__ __launch_bounds__(64 * P2S_WAVES) void k_pass2_rows_sparse(const Pass
             if (PRE) {
 #pragma unroll
                 for (uint32_t k = 0; k < P2S_PIECES; ++k)
-                    if (k * 1024u < a.nz_stride) compact(k * 1024u + lane * 16u, bcur[k], bprev[k]);
+                    if (k * 64u < a.nz_stride) compact((k * 64u + lane) * 32u, bcur[k], bprev[k]);
             } else {
-                for (uint32_t cb = 0; cb < a.nz_stride; cb += 1024u) {
-                    const uint32_t c0 = cb + lane * 16u;
-                    uint4 x = make_uint4(0, 0, 0, 0), y = x;
-                    if (c0 < a.nz_stride) {
-                        x = *reinterpret_cast<const uint4 *>(m1 + c0);
-                        if (m0) y = *reinterpret_cast<const uint4 *>(m0 + c0);
+                for (uint32_t wb = 0; wb < a.nz_stride; wb += 64u) {
+                    const uint32_t w = wb + lane;
+                    uint32_t x = 0, y = 0;
+                    if (w < a.nz_stride) {
+                        x = m1[w];
+                        if (m0) y = m0[w];
                     }
-                    compact(c0, p2s_bits(x), p2s_bits(y));
+                    compact(w * 32u, x, y);
                 }
             }
             cnt = cnt < a.nused ? cnt : a.nused;
@@ -648,7 +638,7 @@ __global__ __launch_bounds__(64 * P2S_WAVES) void k_pass2_rows_sparse(const Pass
         }
         if (PRE) {
 #pragma unroll
-            for (uint32_t k = 0; k < P2S_PIECES; ++k) { bprev[k] = bcur[k]; if (more) bcur[k] = p2s_bits(xn[k]); }
+            for (uint32_t k = 0; k < P2S_PIECES; ++k) { bprev[k] = bcur[k]; if (more) bcur[k] = xn[k]; }
         }
     }
     }
@@ -664,7 +654,7 @@ static void launch_pass2_sparse(const Pass2Args &a, hipStream_t s)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t want = ((uint64_t)a.nrows + P2S_WAVES * P2S_ROWS - 1) / (P2S_WAVES * P2S_ROWS);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * 8);
-    if (a.nz_stride <= 1024u * P2S_PIECES && !getenv("ZDW_P2S_NO_PRE")) hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT, true>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
+    if (a.nz_stride <= 64u * P2S_PIECES && !getenv("ZDW_P2S_NO_PRE")) hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT, true>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
     else hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT, false>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
 }
 

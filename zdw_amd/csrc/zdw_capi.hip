@@ -190,7 +190,7 @@ struct zdw_ctx {
     DevBuf nz, d_used_col;        // tables of mostly empty fields: where pass 1 left a non-zero record (Pass1Args.nz)
     bool nz_mode = false;         // ... this block's record matrix means something only there
     bool rec_dense = true;        // ... until the rest has been zeroed for a reader that wants all of it (ensure_dense_rec)
-    uint32_t nz_stride = 0;       // bytes per row of the map (columns rounded up to 16)
+    uint32_t nz_stride = 0;       // 32-bit words per row of the map (a bit per column; a multiple of 4 words)
     uint32_t nrows_written = 0;   // rows of the matrix pass 1 may have written (the block may have been cut back since)
     bool no_fold = false;         // pass 1 counts its own rows unless that went wrong for this input
     DevBuf span_state;
@@ -768,7 +768,7 @@ int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zd
         StageScope ts(c, ZDW_STAGE_PASS1);
         launch_trim_block(c->rec.as<uint8_t>(), c->rec_stride, c->ncols, c->d_kind.as<uint8_t>(), c->d_recoff.as<uint32_t>(), row, fields,
                           c->lenp1.as<uint8_t>(), c->col_min.as<uint64_t>(), c->col_max.as<uint64_t>(), c->col_seen.as<uint8_t>(),
-                          c->uniq_len.as<uint32_t>(), u, d_entries, sparse ? c->nz.as<uint8_t>() : nullptr, c->nz_stride, s);
+                          c->uniq_len.as<uint32_t>(), u, d_entries, sparse ? c->nz.as<uint32_t>() : nullptr, c->nz_stride, s);
     }
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -836,7 +836,7 @@ int ensure_dense_rec(zdw_ctx *c)
 {
     if (!c->nz_mode || c->rec_dense) return ZDW_OK;
     launch_rec_zero_fill(c->rec.as<uint8_t>(), c->rec_stride, c->nrows_written, c->ncols, c->d_kind.as<uint8_t>(), c->d_recoff.as<uint32_t>(),
-                         c->nz.as<uint8_t>(), c->nz_stride, c->stream);
+                         c->nz.as<uint32_t>(), c->nz_stride, c->stream);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->rec_dense = true;
     return ZDW_OK;
@@ -888,7 +888,7 @@ int prepare_pass2(zdw_ctx *c, Pass2Args &a, hipStream_t s = nullptr)
             HIP_TRY(c, c->d_used_col.ensure(maps.size() * 8));
             HIP_TRY(c, hipMemcpyAsync(c->d_used_col.p, maps.data(), maps.size() * 8, hipMemcpyHostToDevice, s));
             HIP_TRY(c, hipStreamSynchronize(s));
-            a.nz = c->nz.as<uint8_t>(); a.nz_stride = c->nz_stride;
+            a.nz = c->nz.as<uint32_t>(); a.nz_stride = c->nz_stride;
             a.col_meta = c->d_used_col.as<uint64_t>(); a.nz_cols = c->ncols; a.used_col = reinterpret_cast<const uint32_t *>(a.col_meta + (size_t)c->ncols * 2);
         } else {
             rc = ensure_dense_rec(c);
@@ -1465,15 +1465,15 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::min(a.rebase_at, std::max(16384u, (uint32_t)strtoul(e, nullptr, 10)));   // tests
             if ((a.dense_boundaries || a.skip_empty) && nrows) {
                 // mostly empty fields: pass 1 skips every empty field.  Either the record matrix is zeroed in one streaming write, or
-                // (the form for such tables, a map of a byte per field that fits) a map says where a record was written and pass 2
-                // looks nowhere else: a map of rows x columns bytes instead of rows x ~6 x columns bytes to clear.
-                c->nz_stride = (c->ncols + 15u) & ~15u;
-                const uint64_t map_bytes = (uint64_t)nrows * c->nz_stride;
+                // (the form for such tables) a map of a bit per field says where a record was written and pass 2 looks nowhere
+                // else: rows x columns / 8 bytes to clear instead of rows x ~6 x columns.
+                c->nz_stride = ((c->ncols + 31u) / 32u + 3u) & ~3u;
+                const uint64_t map_bytes = (uint64_t)nrows * c->nz_stride * 4u;
                 bool use_map = a.skip_empty && map_bytes <= (16ull << 30) && !getenv("ZDW_P1_NO_NZ");
                 if (use_map && c->nz.ensure(map_bytes + 64) != hipSuccess) use_map = false;
                 if (use_map) {
                     HIP_TRY(c, hipMemsetAsync(c->nz.p, 0, map_bytes, s));
-                    a.nz = c->nz.as<uint8_t>(); a.nz_stride = c->nz_stride;
+                    a.nz = c->nz.as<uint32_t>(); a.nz_stride = c->nz_stride;
                 } else {
                     HIP_TRY(c, hipMemsetAsync(c->rec.p, 0, (uint64_t)nrows * c->rec_stride, s));
                 }
@@ -1864,7 +1864,7 @@ int zdw_shard_last_row(zdw_ctx *c, uint64_t *stored)
     if (rc) return rc;
     if (c->nz_mode && !c->rec_dense && c->nrows) {      // the last row's records, whichever columns they are in: that row is completed from the map
         launch_rec_zero_fill(c->rec.as<uint8_t>() + (uint64_t)(c->nrows - 1) * c->rec_stride, c->rec_stride, 1, c->ncols, c->d_kind.as<uint8_t>(),
-                             c->d_recoff.as<uint32_t>(), c->nz.as<uint8_t>() + (uint64_t)(c->nrows - 1) * c->nz_stride, c->nz_stride, c->stream);
+                             c->d_recoff.as<uint32_t>(), c->nz.as<uint32_t>() + (uint64_t)(c->nrows - 1) * c->nz_stride, c->nz_stride, c->stream);
     }
     Pass2Args a;
     rc = prepare_pass2(c, a);

@@ -118,7 +118,7 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
         adopt_ids(al, wm);
         if (want && in_block) {
             *reinterpret_cast<uint32_t *>(recp) = id;
-            if (a.nz && id) a.nz[(uint64_t)row * a.nz_stride + col] = 1;
+            if (a.nz && id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }
     if (kind == K_TEXT) {
@@ -140,7 +140,7 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
     }
     if (in_block) {
         *reinterpret_cast<uint64_t *>(recp) = v_rec;
-        if (a.nz && v_rec) a.nz[(uint64_t)row * a.nz_stride + col] = 1;
+        if (a.nz && v_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
     }
 }
 

@@ -69,7 +69,7 @@ struct Pass1Args {
     uint64_t *dq; uint32_t dq_cap;        // deferred fields (two words each: position | column << 40, length | row << 32); dq == nullptr: none, one kernel does everything
     uint32_t debug_skip;                  // profiling only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary
     uint32_t rec_zeroed;                  // 1: rec was zeroed before the launch: empty fields leave nothing to do
-    uint8_t *nz; uint32_t nz_stride;      // not null (with rec_zeroed, instead of a zeroed rec): nz[row * nz_stride + column] = 1 (stride: a multiple of 16) where a non-zero record was
+    uint32_t *nz; uint32_t nz_stride;     // not null (with rec_zeroed, instead of a zeroed rec): a bit per field, bit (column & 31) of word nz[row * nz_stride + column / 32], set where a non-zero record was
                                           // written; what rec holds elsewhere means nothing (tables of mostly empty fields: pass 2 goes by this map)
     uint32_t dense_boundaries;            // 1: the input averages more boundaries per round than the small descriptor ring takes (tables of mostly empty fields): large ring
 };
@@ -93,7 +93,7 @@ struct Pass2Args {
     uint8_t *out;
     uint64_t *last_stored;         // k_last_row only: stored values of the last row (per used column)
     uint32_t background;           // size kernel: it runs beside the dictionary sort (second stream): a smaller grid
-    const uint8_t *nz; uint32_t nz_stride;      // not null: rec is valid only where nz[row][column] is set (Pass1Args.nz): the kernels for sparse rows
+    const uint32_t *nz; uint32_t nz_stride;     // not null: rec is valid only where the map's bit is set (Pass1Args.nz; nz_stride words per row): the kernels for sparse rows
     const uint32_t *used_col;      // ... per used column: its column in the schema
     const uint64_t *col_meta;      // ... per column of the schema: used column (bits 0-23, 0xFFFFFF: none), kind (24-25), stored size (26-29), record offset (32-63)
     uint32_t nz_cols;              // ... columns of the schema; col_meta[nz_cols + column] = the column's base value
@@ -104,9 +104,9 @@ void launch_find_effective_end(const uint8_t *in, uint64_t n, uint64_t lo, uint6
 void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t hi, uint64_t span0, uint32_t nspans, uint32_t span_shift,
                              uint32_t *span_starts, P1Status *st, hipStream_t s);
 void launch_pass1(const Pass1Args &a, hipStream_t s);
-// rec[row][column] := 0 wherever nz[row][column] is clear (a record matrix that was written through Pass1Args.nz, for readers that want all of it)
+// rec[row][column] := 0 wherever the map's bit is clear (a record matrix that was written through Pass1Args.nz, for readers that want all of it)
 void launch_rec_zero_fill(uint8_t *rec, uint32_t rec_stride, uint32_t nrows, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff,
-                          const uint8_t *nz, uint32_t nz_stride, hipStream_t s);
+                          const uint32_t *nz, uint32_t nz_stride, hipStream_t s);
 void launch_pass1_deferred(const Pass1Args &a, uint32_t count, hipStream_t s);
 size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds);
 
@@ -148,7 +148,7 @@ void launch_model_trip(const uint64_t *excl, uint32_t nreal, double base_mb, dou
 void launch_locate_field(const uint8_t *in, uint64_t lo, uint64_t p, uint64_t *out, hipStream_t s);
 void launch_trim_block(const uint8_t *rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff, uint32_t rows,
                        uint32_t partial, uint8_t *live, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids,
-                       uint32_t *entries, const uint8_t *nz, uint32_t nz_stride, hipStream_t s);
+                       uint32_t *entries, const uint32_t *nz, uint32_t nz_stride, hipStream_t s);
 // range-partitioned dictionary (multi-GPU)
 void launch_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                      const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys, hipStream_t s);
