@@ -285,18 +285,18 @@ __device__ __forceinline__ void emit_batch(const Pass2Args &a, uint8_t *img, uin
         const uint32_t at = lane_value(my_at, r), pre = lane_value(my_pre, r);
         if (lane < 8 && 64 * b + 8 * lane < a.nused) img[at + 8 * b + lane] = (uint8_t)(bal >> (8 * lane));
         if (flag) {
-            // The value's bytes go into the (zeroed) image as ORs into the aligned dwords they touch, at most three.  A plain store
-            // at a byte offset is replayed by the LDS at ~64 cycles per wave-instruction whenever one lane's address is off its
-            // natural alignment, which here is nearly always: those replays were most of this kernel's LDS time.
-            const uint32_t A = at + nflag + pre + (inc - mine);
-            const uint32_t sz = f.sz, ph = A & 3u, sh = 8u * ph;
+            // little-endian truncating store in at most three pieces (4 + 2 + 1 bytes; LDS stores are unaligned-capable).  (Measured
+            // and dropped: ORs into the aligned dwords of a zeroed image -- no unaligned LDS stalls any more, the kernel 1 % faster,
+            // but 5 GB more fetched from beyond L2 per 10 GB: DESIGN.md 4.3.)
+            uint8_t *q = img + at + nflag + pre + (inc - mine);
+            const uint32_t sz = f.sz;
             uint64_t x = v[r + 1];
-            if (sz < 8u) x &= (1ull << (8u * sz)) - 1ull;
-            uint32_t *d = reinterpret_cast<uint32_t *>(img + (A & ~3u));
-            const uint64_t xs = x << sh;
-            atomicOr(d, (uint32_t)xs);
-            if (ph + sz > 4u) atomicOr(d + 1, (uint32_t)(xs >> 32));
-            if (ph + sz > 8u) atomicOr(d + 2, (uint32_t)(x >> (64u - sh)));          // (ph > 0 here)
+            if (sz == 8) { reinterpret_cast<PackedL64 *>(q)->v = x; }
+            else {
+                if (sz & 4u) { reinterpret_cast<PackedL32 *>(q)->v = (uint32_t)x; q += 4; x >>= 32; }
+                if (sz & 2u) { reinterpret_cast<PackedL16 *>(q)->v = (uint16_t)x; q += 2; x >>= 16; }
+                if (sz & 1u) *q = (uint8_t)x;
+            }
         }
     }
 }
@@ -313,14 +313,7 @@ __device__ __forceinline__ void copy_image_out(const Pass2Args &a, const uint8_t
             const uint32_t lo = o > shift ? o : shift, hi = o + 16u < endb ? o + 16u : endb;
             for (uint32_t k = lo; k < hi; ++k) gdst[k] = img[k];
         }
-        // the image is all zero between chunks (emit_batch ORs into it): the thread that has read a piece clears it
-        *reinterpret_cast<uint4 *>(const_cast<uint8_t *>(img) + o) = make_uint4(0, 0, 0, 0);
     }
-}
-// before the first chunk: the whole image zero
-__device__ __forceinline__ void zero_image(uint8_t *img, uint32_t bytes)
-{
-    for (uint32_t o = threadIdx.x * 16u; o < bytes; o += 256u * 16u) *reinterpret_cast<uint4 *>(img + o) = make_uint4(0, 0, 0, 0);
 }
 
 // emit: the workgroup assembles P2_R consecutive rows in LDS (at the byte offset that makes LDS and global
@@ -335,8 +328,6 @@ __global__ __launch_bounds__(256) void k_pass2_emit_cols(const Pass2Args a)
     const uint32_t nflag = (a.nused + 7) >> 3;
     const uint32_t nbatch = (a.nused + 63) >> 6;
     const uint32_t nchunks = (a.nrows + P2_R - 1) / P2_R;
-    zero_image(p2_lds, (P2_R * a.out_row_max + 32u + 15u) & ~15u);
-    __syncthreads();
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t row0 = chunk * P2_R;
         const uint32_t rows = a.nrows - row0 < P2_R ? a.nrows - row0 : P2_R;
@@ -400,7 +391,6 @@ __global__ __launch_bounds__(256, P2_R <= 8 ? 7 : 4) void k_pass2_emit_cols_pipe
     uint32_t pre;
     {
         const uint32_t crow0 = blockIdx.x * CR, crows = chunk_rows(crow0), rows = wave_rows(crows);
-        zero_image(p2_lds, (CR * a.out_row_max + 32u + 15u) & ~15u);
         at0 = stage_chunk(a, stage, crow0, crows);
         ro = load_ro(crow0, crows, rows);
         pre = (have && lane < rows) ? a.batch_pre[(uint64_t)(crow0 + r0 + lane) * nbatch + b] : 0u;
