@@ -284,6 +284,7 @@ def main():
                          "SURVEY 8f-3) instead of one block row-sharded over the ranks")
     ap.add_argument("--p-empty", type=float, default=0.25, help="fraction of empty fields (0.25 = BASELINE's table; other values: not a valid bench line)")
     ap.add_argument("--dead-cols", type=float, default=0.0, help="fraction of columns empty in every row (0 = BASELINE's table)")
+    ap.add_argument("--id-every", type=int, default=0, help="every k-th column holds practically unique 24-character ids (C5's table: --cols 1000 --id-every 20; 0 = BASELINE's table)")
     ap.add_argument("--pass1-only", action="store_true", help="profiling: time pass 1 alone (not a valid bench line)")
     ap.add_argument("--no-verify", action="store_true", help="skip the property checks of the outputs after the timed region")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end timing of the convertDWfile binary after the timed region")
@@ -316,7 +317,7 @@ def main():
             dist.init_process_group(args.backend)
 
     # ---- synthetic table, generated in HBM; rank r holds rows [r*R, (r+1)*R) ----
-    table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local, word_maxlen=args.word_maxlen, p_empty=args.p_empty, dead_cols=args.dead_cols)
+    table = synth.DeviceTable(ncols=args.cols, device="cuda:%d" % local, word_maxlen=args.word_maxlen, p_empty=args.p_empty, dead_cols=args.dead_cols, id_every=args.id_every)
     rows_total = table.rows_for_bytes(args.gb * 1e9)
 
     def rank_rows(mode):

@@ -1173,7 +1173,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     // The reference's block limit as a model (model_trip).  The block is parsed once over a window of rows; when the limit trips
     // inside the window, what the rows beyond that point added is taken back out of pass 1's results (trim_block): one pass-1
     // launch per block, another one only when the window turns out too short.
-    // The window, in rows.  After a block the model ended: the rows of that block plus a half -- plus a tenth when the two blocks
+    // The window, in rows.  After a block the model ended: the rows of that block plus a quarter -- plus a tenth when the two blocks
     // before were of one size (tables of id-like columns end their blocks every N rows).  For an input's first block: the rows
     // that four times the limit's bytes of input hold (C5: a row's id fields cost 0.44 bytes of the modelled process per input
     // byte); when the limit does not trip inside a window, the next one is sized from the process size the model saw at its end.
@@ -1186,7 +1186,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     if (c->model_rows_prev) {
         const uint64_t a = c->model_rows_prev, b = c->model_rows_prev2;
         const bool steady = b && (a > b ? a - b : b - a) <= a / 32;
-        window = a + (steady ? a / 10 : a / 2) + 1000;
+        window = a + (steady ? a / 10 : a / 4) + 1000;
     } else {
         const double bytes = 4.0 * c->mem_limit_mb * 1048576.0;
         window = (uint64_t)(bytes / (double)(c->avg_row ? c->avg_row : 1)) + 1000;
@@ -1385,7 +1385,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     uint64_t nslots = first_table(nrows);
     HIP_TRY(c, c->col_min.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_max.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_seen.ensure(c->ncols + 8));
     if (c->model_max_slots && !c->model_rows_prev && tripped) {
-        // The first window of an input whose blocks the memory-limit model ends: the next block's window is half as large again.
+        // The first window of an input whose blocks the memory-limit model ends: the next block's window is a quarter larger (room for that and some more).
         // Room for that now saves freeing and allocating tens of GB between the first two blocks (seen to take half a second).
         (void)c->rec.ensure((uint64_t)nrows * c->rec_stride / 5 * 8 + 64);
     }
