@@ -1371,7 +1371,11 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             ns = 1ull << 14;
             // (the block's share of the remaining input, by rows)
             const uint64_t bytes = total_rows ? (uint64_t)((double)(hi > lo ? hi - lo : 0) * rows_in_block / (double)total_rows) : 0;
-            while (ns < bytes / 32 && ns < (1ull << 25)) ns <<= 1;
+            // (a window of the memory-limit model that holds 2 GB of slots' worth of input: a table of 2^26 -- blocks of id-like
+            // columns reach the limit at tens of millions of strings, and a table that overflows is a second pass 1 over the window;
+            // the larger table costs the benchmark's table 0.1 ms: tools/ab_slots.sh)
+            const uint64_t cap = (c->model_max_slots && bytes / 32 >= (1ull << 26)) ? (1ull << 26) : (1ull << 25);
+            while (ns < bytes / 32 && ns < cap) ns <<= 1;
             if (c->slots_learned > ns && rows_in_block >= c->rows_learned) ns = c->slots_learned;
             // what the rows of this input have held so far, per row (load limit 5/8, 15 % to spare)
             const double est = (double)rows_in_block * c->entries_per_row * 1.6 * 1.15;
