@@ -13,8 +13,10 @@ After the timed region (never inside it) rank 0 also: verifies the last step's o
 dictionary header + strict strcmp order of every entry, a walk of the first rows, and byte equality of the
 dictionary / column stats / row section with the same table encoded as THREE row shards, whose positions all stay
 below 2^32); times the reference encoder on the host ("cpu_baseline"); and times the shipped convertDWfile
-binary as a child process on a page-cache-warm 2 GB file ("e2e_cli": compressor child replaced by cat, and the
-default gzip) -- SURVEY.md 8d protocol (b); neither rate is ever `value`.
+binary as a child process on a page-cache-warm 2 GB file ("e2e_cli": compressor child replaced by cat; as shipped, gzip
+deflated in the process on several threads; and the reference's way, one gzip child) -- SURVEY.md 8d protocol (b); none of
+these rates is ever `value`.  Other table shapes (--cols, --p-empty, --dead-cols, --id-every) are for measurements, not
+valid bench lines.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--gb G] [--cols C] [--no-cpu] [--no-verify] [--no-e2e] [--scaling weak|strong]
 """
