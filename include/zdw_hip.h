@@ -71,7 +71,13 @@ typedef struct zdw_opts {
                                       beyond this virtual size (stringheap.cpp:74-86, memory.cpp:76-81).  Reproduced as a
                                       deterministic model of that size (fitted to the reference build on this image):
                                       2.6 + 64 x arenas + 64 B x dictionary entries.  A zdw_split_hint overrides it. */
-    uint64_t reserved[1];
+    uint64_t track_first_occurrence; /* 1: for every unique string of a block pass 1 keeps the position of its FIRST occurrence in this context's
+                                      image (a minimum over all of them), whichever occurrence won the insertion: what the block-limit model needs
+                                      when the block is row-sharded over several contexts (zdw_shard_model_walk); implied by mem_limit_mb */
+    uint64_t defer_bad_row;        /* 1: a row with a wrong field count does not fail zdw_block_pass1 (15): the call returns 0 with
+                                      zdw_pass1_result.bad_row set and the caller decides -- a row-sharded block under a memory limit may end
+                                      before that row, which then belongs to a later block (ConvertToZDW.cpp:336-338: the reference meets
+                                      rows in order and stops at whichever comes first) */
 } zdw_opts;
 
 /* Where a block must end when it cannot hold the whole remaining input (reference: memory-driven,
@@ -223,6 +229,45 @@ int zdw_shard_partition(zdw_ctx *ctx, uint32_t nparts, const uint64_t *splitters
 int zdw_owner_build(zdw_ctx *ctx, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes, uint64_t *slice_bytes);
 int zdw_owner_offsets(zdw_ctx *ctx, uint64_t base /* dictionary offset of the range's first string */, const void **d_offsets);
 int zdw_shard_set_offsets(zdw_ctx *ctx, const void *d_offsets, uint64_t count, uint64_t dict_size, int first_range);
+/* the owner's half of zdw_shard_set_offsets alone, for a context that owns a key range of the block's dictionary but holds none of
+ * its rows (a shard whose rows all lie in earlier or later blocks): zdw_block_dict[_device|_write] then returns its piece */
+int zdw_owner_section(zdw_ctx *ctx, uint64_t dict_size, int first_range);
+
+/* ---- where the reference's memory limit ends a row-sharded block (SURVEY.md §8e "Invariance requirement", Q9) ------------------
+ * The reference ends a block when its StringHeap takes a new arena while the process is at or beyond --mem-limit
+ * (stringheap.cpp:74-86, memory.cpp:76-81, ConvertToZDW.cpp:338,404): a function of the order in which the block's strings are FIRST
+ * met.  Over row shards that order is: shard 0's strings in the order of their first occurrence, then those of shard 1 that shard 0
+ * does not hold, and so on -- so the decision is taken on the node-wide dictionary, never per shard:
+ *   contexts are created with zdw_opts.track_first_occurrence (and mem_limit_mb = 0: no shard ends a block on its own);
+ *   zdw_shard_model_counts   entries / bytes / longest string of this shard: with zdw_model_upper_bound_mb the caller sees cheaply
+ *                            that a limit cannot trip (all shards' counts added up as if no string were shared);
+ *   zdw_shard_positions      after zdw_shard_partition: the position of every exported string's first occurrence, `base` (where this
+ *                            shard's image begins in the whole input) added -- travels to the owners with the strings;
+ *   zdw_owner_import         (owner) the first half of zdw_owner_build: the arriving strings deduplicated, the smallest position kept;
+ *   zdw_owner_first_flags    (owner) per arrival: 1 = this is the string's first occurrence node-wide -> back to the requesters;
+ *   zdw_shard_model_walk     (requester, shards in row order, the state handed from one to the next) the reference's arenas walked over
+ *                            this shard's node-wide-first strings in the order of their positions: *found = the limit trips in this shard,
+ *                            at field *fields - 1 (0-based) of its row *row, which starts at *row_start; *trip_pos = where that field lies;
+ *   zdw_shard_trim           the shard that holds the end: its block is cut back to `row` rows and the first `fields` fields of the next
+ *                            row (they stay in the block's dictionary and ranges as in the reference); the shards behind it take no part
+ *                            in this block; zdw_block_next then moves the shard on to row_start;
+ *   zdw_owner_finish         (owner) the second half of zdw_owner_build: strings first met beyond base + trip_pos are dropped
+ *                            (last_pos; ~0 = keep all), the rest sorted and laid out.
+ * zdw_owner_build = zdw_owner_import without positions + zdw_owner_finish(~0). */
+typedef struct zdw_model_state {
+    uint64_t arenas;       /* arenas the block's strings have taken so far */
+    uint64_t entries;      /* dictionary entries so far */
+    uint64_t arena_free;   /* bytes left in the arena that is open */
+} zdw_model_state;
+double zdw_model_upper_bound_mb(uint64_t entries, uint64_t bytes, uint32_t max_len);
+int zdw_shard_model_counts(zdw_ctx *ctx, uint64_t *entries, uint64_t *bytes, uint32_t *max_len);
+int zdw_shard_positions(zdw_ctx *ctx, uint64_t base, const void **d_pos);
+int zdw_owner_import(zdw_ctx *ctx, const void *d_lens, const void *d_bytes, const void *d_pos /* NULL: no positions */, uint64_t count, uint64_t nbytes);
+int zdw_owner_first_flags(zdw_ctx *ctx, const void **d_flags);
+int zdw_owner_finish(zdw_ctx *ctx, uint64_t last_pos, uint64_t *slice_bytes);
+int zdw_shard_model_walk(zdw_ctx *ctx, const void *d_flags, uint64_t count, double limit_mb, zdw_model_state *state, uint32_t *found,
+                         uint32_t *row, uint32_t *fields, uint64_t *row_start, uint64_t *trip_pos);
+int zdw_shard_trim(zdw_ctx *ctx, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res);
 
 /* ---- the same exchange inside the library: one process, several GPUs of one node -----------------
  * One ZDW block row-sharded over `ndev` devices: a zdw_ctx and a host thread per device, column ranges by
@@ -230,7 +275,8 @@ int zdw_shard_set_offsets(zdw_ctx *ctx, const void *d_offsets, uint64_t count, u
  * ncclCommInitAll: no second process, nothing re-executed), the row halo by the host.  The bytes are the ones a single
  * context writes for the whole input, whatever ndev is.  A device may be listed more than once (tests on a one-GPU
  * box): the exchange then runs as device-to-device copies.  convertDWfile --gpus=N (not in the reference tool) uses it.
- * The whole input is ONE block: a dictionary beyond 2^32 bytes, or a shard that does not fit its device, returns 7. */
+ * Without zdw_opts.mem_limit_mb the whole input is ONE block (a dictionary beyond 2^32 bytes returns 7); a shard that does not fit its
+ * device returns 7. */
 typedef struct zdw_multi zdw_multi;
 typedef struct zdw_multi_block {
     uint32_t num_rows;        /* block header fields 1-3 (ConvertToZDW.cpp:839-842) */
@@ -244,7 +290,12 @@ void zdw_multi_destroy(zdw_multi *m);
 const char *zdw_multi_last_error(const zdw_multi *m);   /* m may be NULL: last zdw_multi_create error */
 /* cuts the image into ndev pieces at row boundaries and copies piece i to device i; tsv must stay valid until zdw_multi_encode returns */
 int zdw_multi_set_input_host(zdw_multi *m, const uint8_t *tsv, uint64_t len);
+/* the next block of the input.  With zdw_opts.mem_limit_mb the input's blocks end where the reference's end (the model of its memory
+ * limit walked over the node-wide dictionary, see zdw_shard_model_walk); is_last_block = 0 then says that zdw_multi_next + another
+ * zdw_multi_encode give the block behind it.  num_rows = 0 with is_last_block = 1: the input holds no (more) rows. */
 int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk);
+/* uniques.clear() for the whole set of shards: on to the block behind the one zdw_multi_encode returned */
+int zdw_multi_next(zdw_multi *m);
 int zdw_multi_stats(zdw_multi *m, uint8_t *col_size, uint64_t *col_base, uint32_t *used);
 /* dictionary section / rows of the block, shard after shard, through the writer (see zdw_block_dict_write) */
 int zdw_multi_dict_write(zdw_multi *m, zdw_write_fn write, void *user, uint64_t *section_len);

@@ -12,7 +12,7 @@ STAGE_NAMES = ["scan_rows", "pass1", "dict_compact", "dict_sort", "dict_emit", "
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("trim_trailing_spaces", C.c_uint32),
-                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("max_dict_bytes", C.c_uint64), ("max_device_bytes", C.c_uint64), ("mem_limit_mb", C.c_uint64), ("reserved", C.c_uint64 * 1)]
+                ("first_row_capacity", C.c_uint32), ("dict_slots", C.c_uint64), ("max_dict_bytes", C.c_uint64), ("max_device_bytes", C.c_uint64), ("mem_limit_mb", C.c_uint64), ("track_first_occurrence", C.c_uint64), ("defer_bad_row", C.c_uint64)]
 
 
 class SplitHint(C.Structure):
@@ -26,6 +26,10 @@ class Pass1Result(C.Structure):
 
 class StageTimes(C.Structure):
     _fields_ = [("ms", C.c_float * NUM_STAGES), ("launches", C.c_uint32 * NUM_STAGES)]
+
+
+class ModelState(C.Structure):
+    _fields_ = [("arenas", C.c_uint64), ("entries", C.c_uint64), ("arena_free", C.c_uint64)]
 
 
 class MultiBlock(C.Structure):
@@ -49,6 +53,11 @@ class ZdwError(RuntimeError):
 
 
 _lib = None
+
+
+def model_upper_bound_mb(entries, nbytes, max_len):
+    """the most the reference's process can have grown to with a dictionary of that many entries / bytes (the model)"""
+    return float(lib().zdw_model_upper_bound_mb(entries, nbytes, max_len))
 
 
 def lib():
@@ -92,6 +101,17 @@ def lib():
         L.zdw_owner_build.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, u64p]
         L.zdw_owner_offsets.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
         L.zdw_shard_set_offsets.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int]
+        L.zdw_owner_section.argtypes = [vp, C.c_uint64, C.c_int]
+        L.zdw_model_upper_bound_mb.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        L.zdw_model_upper_bound_mb.restype = C.c_double
+        L.zdw_shard_model_counts.argtypes = [vp, u64p, u64p, u32p]
+        L.zdw_shard_positions.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+        L.zdw_owner_import.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64]
+        L.zdw_owner_first_flags.argtypes = [vp, C.POINTER(vp)]
+        L.zdw_owner_finish.argtypes = [vp, C.c_uint64, u64p]
+        L.zdw_shard_model_walk.argtypes = [vp, vp, C.c_uint64, C.c_double, C.POINTER(ModelState), u32p, u32p, u32p, u64p, u64p]
+        L.zdw_shard_trim.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Pass1Result)]
+        L.zdw_multi_next.argtypes = [vp]
         L.zdw_shard_last_row.argtypes = [vp, u64p]
         L.zdw_shard_set_prev_row.argtypes = [vp, u64p]
         L.zdw_shard_line_caps.argtypes = [vp, u32p]
@@ -122,21 +142,24 @@ def lib():
 
 
 class MultiEncoder:
-    """zdw_multi_*: one block row-sharded over several devices inside the library (RCCL between distinct devices)."""
+    """zdw_multi_*: the blocks of an input, each row-sharded over several devices inside the library (RCCL between distinct devices).
+    mem_limit_mb: where the reference's --mem-limit ends the blocks (0 = the whole input is one block)."""
 
-    def __init__(self, col_types, devices, trim=False):
+    def __init__(self, col_types, devices, trim=False, mem_limit_mb=0):
         self.L = lib()
         self.ncols = len(col_types)
         types = (C.c_uint8 * max(1, self.ncols))(*col_types)
         o = Opts()
         o.struct_size = C.sizeof(Opts)
         o.trim_trailing_spaces = 1 if trim else 0
+        o.mem_limit_mb = mem_limit_mb
         devs = (C.c_int32 * len(devices))(*devices)
         h = C.c_void_p()
         rc = self.L.zdw_multi_create(types, self.ncols, C.byref(o), devs, len(devices), C.byref(h))
         if rc:
             raise ZdwError(rc, self.L.zdw_multi_last_error(None).decode())
         self.h = h
+        self._keep = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -145,23 +168,44 @@ class MultiEncoder:
 
     __del__ = close
 
-    def encode(self, data):
-        """data: bytes.  Returns (rc, block bytes as the file holds them -- block header, dictionary, stats, rows -- or None, MultiBlock)."""
-        import struct
-        buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else None
-        rc = self.L.zdw_multi_set_input_host(self.h, C.cast(buf, C.c_void_p) if buf is not None else None, len(data))
+    def error(self):
+        return self.L.zdw_multi_last_error(self.h).decode()
+
+    def set_input(self, data):
+        """bytes / bytearray / C-contiguous uint8 numpy array (kept alive until the next input)"""
+        if isinstance(data, (bytes, bytearray)):
+            buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else None
+            self._keep = buf
+            rc = self.L.zdw_multi_set_input_host(self.h, C.cast(buf, C.c_void_p) if buf is not None else None, len(data))
+        else:
+            self._keep = data
+            rc = self.L.zdw_multi_set_input_host(self.h, C.c_void_p(data.ctypes.data), data.size)
         if rc:
-            raise ZdwError(rc, self.L.zdw_multi_last_error(self.h).decode())
+            raise ZdwError(rc, self.error())
+
+    def next_block(self, sink=None):
+        """Encodes the block behind the last one.  Returns (rc, block bytes as the file holds them -- block header, dictionary, stats,
+        rows -- or None, MultiBlock); with `sink` (a callable taking bytes) the pieces go there and the second value is their length."""
+        import struct
         blk = MultiBlock()
         rc = self.L.zdw_multi_encode(self.h, C.byref(blk))
         if rc or blk.num_rows == 0:
             return rc, None, blk
-        out = bytearray(struct.pack("<IIB", blk.num_rows, blk.longest_line, 1))
+        out = bytearray()
+        total = [0]
 
-        def sink(_user, p, n):
-            out.extend(C.string_at(p, n))
+        def put(b):
+            total[0] += len(b)
+            if sink is None:
+                out.extend(b)
+            else:
+                sink(b)
+
+        def cb_fn(_user, p, n):
+            put(C.string_at(p, n))
             return 0
-        cb = WRITE_FN(sink)
+        put(struct.pack("<IIB", blk.num_rows, blk.longest_line, 1 if blk.is_last_block else 0))
+        cb = WRITE_FN(cb_fn)
         rc = self.L.zdw_multi_dict_write(self.h, cb, None, None)
         cs = (C.c_uint8 * max(1, self.ncols))()
         cbs = (C.c_uint64 * max(1, self.ncols))()
@@ -169,12 +213,38 @@ class MultiEncoder:
         if rc == 0:
             rc = self.L.zdw_multi_stats(self.h, cs, cbs, C.byref(used))
         if rc == 0:
-            out.extend(bytes(cs)[:self.ncols])
-            out.extend(struct.pack("<%dQ" % used.value, *list(cbs)[:used.value]))
+            put(bytes(cs)[:self.ncols])
+            put(struct.pack("<%dQ" % used.value, *list(cbs)[:used.value]))
             rc = self.L.zdw_multi_rows_write(self.h, cb, None, None)
+        if rc == 0:
+            rc = self.L.zdw_multi_next(self.h)
         if rc:
-            raise ZdwError(rc, self.L.zdw_multi_last_error(self.h).decode())
-        return 0, bytes(out), blk
+            raise ZdwError(rc, self.error())
+        return 0, (bytes(out) if sink is None else total[0]), blk
+
+    def encode(self, data):
+        """The input's first block (all of it without a memory limit): (rc, block bytes or None, MultiBlock)."""
+        self.set_input(data)
+        return self.next_block()
+
+    def encode_all(self, data, sink=None):
+        """All blocks of `data`: (rc, concatenated block bytes (or their length with `sink`), [MultiBlock])."""
+        self.set_input(data)
+        out, blocks, total = bytearray(), [], 0
+        while True:
+            rc, b, blk = self.next_block(sink)
+            if rc:
+                return rc, (bytes(out) if sink is None else total), blocks + [blk]
+            if b is None:
+                break
+            if sink is None:
+                out.extend(b)
+            else:
+                total += b
+            blocks.append(blk)
+            if blk.is_last_block:
+                break
+        return 0, (bytes(out) if sink is None else total), blocks
 
 
 class Decoder:
@@ -273,7 +343,8 @@ class Block:
 class Encoder:
     """One zdw_ctx: the per-block seam of ConvertToZDW::processFile (cplusplus/ConvertToZDW.cpp:805-872)."""
 
-    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0, max_dict_bytes=0, max_device_bytes=0, mem_limit_mb=0):
+    def __init__(self, col_types, trim=False, device=-1, dict_slots=0, first_row_capacity=0, max_dict_bytes=0, max_device_bytes=0, mem_limit_mb=0,
+                 track_first_occurrence=False, defer_bad_row=False):
         self.L = lib()
         self.ncols = len(col_types)
         types = (C.c_uint8 * max(1, self.ncols))(*col_types)
@@ -286,6 +357,8 @@ class Encoder:
         o.max_dict_bytes = max_dict_bytes
         o.max_device_bytes = max_device_bytes
         o.mem_limit_mb = mem_limit_mb
+        o.track_first_occurrence = 1 if track_first_occurrence else 0
+        o.defer_bad_row = 1 if defer_bad_row else 0
         h = C.c_void_p()
         rc = self.L.zdw_ctx_create(types, self.ncols, C.byref(o), C.byref(h))
         if rc:
@@ -338,12 +411,16 @@ class Encoder:
                 data = reader(int(cap))
             except Exception:  # noqa: BLE001
                 return -1
+            if len(data) > cap:
+                return -1                     # a reader that hands over more than it was asked for: a failed read, never an overflow
             if data:
                 C.memmove(buf, data, len(data))
             return len(data)
-        self._reader = READ_FN(cb)
+        reader_cb = READ_FN(cb)
         self._keep = None
-        self._chk(self.L.zdw_set_input_stream(self.h, self._reader, None, size_hint))
+        # (the thunk of the input before stays alive until the library has joined the thread that may still be calling it)
+        self._chk(self.L.zdw_set_input_stream(self.h, reader_cb, None, size_hint))
+        self._reader = reader_cb
 
     def pass1(self, max_rows=None, partial_fields=0):
         res = Pass1Result()
@@ -443,6 +520,48 @@ class Encoder:
         out = C.c_uint64()
         self._chk(self.L.zdw_owner_build(self.h, C.c_void_p(d_lens), C.c_void_p(d_bytes), count, nbytes, C.byref(out)))
         return out.value
+
+    def owner_import(self, d_lens, d_bytes, d_pos, count, nbytes):
+        self._chk(self.L.zdw_owner_import(self.h, C.c_void_p(d_lens), C.c_void_p(d_bytes), C.c_void_p(d_pos) if d_pos else None, count, nbytes))
+
+    def owner_first_flags(self):
+        p = C.c_void_p()
+        self._chk(self.L.zdw_owner_first_flags(self.h, C.byref(p)))
+        return p.value
+
+    def owner_finish(self, last_pos=None):
+        out = C.c_uint64()
+        self._chk(self.L.zdw_owner_finish(self.h, (1 << 64) - 1 if last_pos is None else last_pos, C.byref(out)))
+        return out.value
+
+    def owner_section(self, dict_size, first_range):
+        self._chk(self.L.zdw_owner_section(self.h, dict_size, 1 if first_range else 0))
+
+    def model_counts(self):
+        """(entries, bytes, longest string) of this shard's dictionary: see model_upper_bound_mb"""
+        e, b, ml = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        self._chk(self.L.zdw_shard_model_counts(self.h, C.byref(e), C.byref(b), C.byref(ml)))
+        return e.value, b.value, ml.value
+
+    def positions(self, base):
+        p = C.c_void_p()
+        self._chk(self.L.zdw_shard_positions(self.h, base, C.byref(p)))
+        return p.value
+
+    def model_walk(self, d_flags, count, limit_mb, state):
+        """state: (arenas, entries, arena_free) from the shard before.  Returns (state, None) or (state, (row, fields, row_start, trip_pos))."""
+        st = ModelState(*state)
+        found, row, fields = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rs, tp = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.zdw_shard_model_walk(self.h, C.c_void_p(d_flags) if d_flags else None, count, float(limit_mb), C.byref(st), C.byref(found),
+                                              C.byref(row), C.byref(fields), C.byref(rs), C.byref(tp)))
+        new = (st.arenas, st.entries, st.arena_free)
+        return new, ((row.value, fields.value, rs.value, tp.value) if found.value else None)
+
+    def trim(self, row, fields, row_start):
+        res = Pass1Result()
+        self._chk(self.L.zdw_shard_trim(self.h, row, fields, row_start, C.byref(res)))
+        return res
 
     def owner_offsets(self, base):
         p = C.c_void_p()

@@ -424,107 +424,40 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
 
     PhaseClock clock;
     const bool several = devices.size() > 1 || (devices.size() == 1 && getenv("ZDW_MULTI_ALWAYS"));
-    if (several) {
-        // ---- one block over several devices (zdw_multi_*): header, block, done ----
-        const unsigned char *img = hostImage ? hostImage->data() : reinterpret_cast<const unsigned char *>(mappedImage);
-        zdw_multi *mm = NULL;
-        {
-            zdw_opts opts;
-            memset(&opts, 0, sizeof opts);
-            opts.struct_size = sizeof opts;
-            opts.trim_trailing_spaces = bTrimTrailingSpaces ? 1u : 0u;
-            std::vector<int32_t> devs(devices.begin(), devices.end());
-            const int rc = zdw_multi_create(schema.types.data(), static_cast<uint32_t>(numColumns), &opts, devs.data(), static_cast<uint32_t>(devs.size()), &mm);
-            if (rc != ZDW_OK) {
-                libError = zdw_multi_last_error(NULL);
-                statusOutput(ERROR, "GPU encoder unavailable: %s\n", libError.c_str());
-                return static_cast<ERR_CODE>(rc);
-            }
-        }
-        struct MultiGuard { zdw_multi *m; ~MultiGuard() { zdw_multi_destroy(m); } } mguard{mm};
-        int rc = zdw_multi_set_input_host(mm, img, imageLen);
-        zdw_multi_block blk;
-        memset(&blk, 0, sizeof blk);
-        if (rc == ZDW_OK) rc = zdw_multi_encode(mm, &blk);
-        if (rc == ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW) {
-            statusOutput(ERROR, "\nRow %u had the problem\n", blk.bad_row);
-            return WRONG_NUM_OF_COLUMNS_ON_A_ROW;
-        }
-        if (rc != ZDW_OK) {
-            libError = zdw_multi_last_error(mm);
-            statusOutput(ERROR, "%s\n", libError.c_str());
-            return static_cast<ERR_CODE>(rc);
-        }
-        std::string cmd = compressorCommand();
-        if (zArgs) { cmd += " "; cmd += zArgs; }
-        cmd += " > ";
-        cmd += tempName;
-        OutPipe out;
-        int gzLevel = 6;
-        const unsigned gzThreads = inProcessGzip(compressor == GZIP, zArgs, &gzLevel);
-        if (!out.open(cmd, tempName, gzThreads, gzLevel)) {
-            statusOutput(ERROR, "Could not open the process '%s' for writing!\n", cmd.c_str());
-            return FILE_CREATION_ERR;
-        }
-        bool ok = out.le(formatVersion, 2);
-        if (formatVersion >= 11) {
-            uint64_t metaLen = 0;
-            for (const auto &kv : metadata) metaLen += kv.first.size() + kv.second.size() + 2;
-            ok = ok && out.le(metaLen, 4);
-            for (const auto &kv : metadata)
-                ok = ok && out.put(kv.first.c_str(), kv.first.size() + 1) && out.put(kv.second.c_str(), kv.second.size() + 1);
-        }
-        for (size_t c = 0; c < numColumns; ++c) ok = ok && out.put(schema.names[c].c_str(), schema.names[c].size() + 1);
-        ok = ok && out.le(0, 1);
-        ok = ok && out.put(schema.types.data(), numColumns);
-        for (size_t c = 0; c < numColumns; ++c) ok = ok && out.le(static_cast<uint16_t>(schema.charSizes[c]), 2);
-        ERR_CODE res = OK;
-        if (blk.num_rows == 0) {
-            statusOutput(ERROR, "Empty data file -- nothing to process\n");
-        } else {
-            ok = ok && out.le(blk.num_rows, 4) && out.le(blk.longest_line, 4) && out.le(1, 1);
-            std::vector<unsigned char> colSize(numColumns ? numColumns : 1);
-            std::vector<uint64_t> colBase(numColumns ? numColumns : 1);
-            uint32_t used = 0;
-            rc = zdw_multi_dict_write(mm, writeToPipe, &out, NULL);
-            if (rc == ZDW_OK) rc = zdw_multi_stats(mm, colSize.data(), colBase.data(), &used);
-            if (rc == ZDW_OK) {
-                ok = ok && out.put(colSize.data(), numColumns);
-                for (uint32_t u = 0; u < used; ++u) ok = ok && out.le(colBase[u], 8);
-                rc = zdw_multi_rows_write(mm, writeToPipe, &out, NULL);
-            }
-            if (rc != ZDW_OK) {
-                libError = zdw_multi_last_error(mm);
-                statusOutput(ERROR, "%s\n", libError.c_str());
-                res = static_cast<ERR_CODE>(rc);
-            }
-        }
-        ok = out.finish() && ok;
-        const int childStatus = out.close();
-        if (res == OK && (!ok || childStatus != 0)) {
-            statusOutput(ERROR, "Writing through '%s' failed\n", cmd.c_str());
-            res = FILE_CREATION_ERR;
-        }
-        if (res == OK) {
-            if (!bQuiet) statusOutput(INFO, "Rows=%u\n", blk.num_rows);
-            if (rename(tempName.c_str(), finalName.c_str()) == 0) {
-                if (!bQuiet) statusOutput(INFO, "Done\n");
-            } else {
-                res = FILE_CREATION_ERR;
-                statusOutput(INFO, "Final create file failed -- you can use %s instead.\n", tempName.c_str());
-            }
-        } else {
-            unlink(tempName.c_str());
-        }
-        return res;
-    }
     // (declared before the context: its feeder thread reads through `source` until the context is destroyed)
     InSource source;
     std::string teeName;
     struct TeeGuard { InSource &s; ~TeeGuard() { if (s.tee) pclose(s.tee); } } teeGuard{source};
     // ---- GPU context first: nothing is created on disk when no device is usable ----
     CtxGuard guard;
-    {
+    struct MultiGuard { zdw_multi *m = NULL; ~MultiGuard() { if (m) zdw_multi_destroy(m); } } mguard;
+    const unsigned char *image = hostImage ? hostImage->data() : reinterpret_cast<const unsigned char *>(mappedImage);
+    if (several) {
+        // one block after the other over several devices (zdw_multi_*): every block row-sharded, --mem-limit ends them where the
+        // reference's end (the decision is taken on the node-wide dictionary)
+        zdw_opts opts;
+        memset(&opts, 0, sizeof opts);
+        opts.struct_size = sizeof opts;
+        opts.trim_trailing_spaces = bTrimTrailingSpaces ? 1u : 0u;
+        opts.mem_limit_mb = memLimitMB > 0.0 ? static_cast<uint64_t>(memLimitMB) : 0;
+        std::vector<int32_t> devs(devices.begin(), devices.end());
+        int rc = zdw_multi_create(schema.types.data(), static_cast<uint32_t>(numColumns), &opts, devs.data(), static_cast<uint32_t>(devs.size()), &mguard.m);
+        if (rc != ZDW_OK) {
+            libError = zdw_multi_last_error(NULL);
+            statusOutput(ERROR, "GPU encoder unavailable: %s\n", libError.c_str());
+            return static_cast<ERR_CODE>(rc);
+        }
+        if (!splitRows.empty()) {
+            statusOutput(ERROR, "ZDW_SPLIT_ROWS is not available with --gpus / --devices\n");
+            return BAD_PARAMETER;
+        }
+        rc = zdw_multi_set_input_host(mguard.m, image, imageLen);
+        if (rc != ZDW_OK) {
+            libError = zdw_multi_last_error(mguard.m);
+            statusOutput(ERROR, "%s\n", libError.c_str());
+            return static_cast<ERR_CODE>(rc);
+        }
+    } else {
         zdw_opts opts;
         memset(&opts, 0, sizeof opts);
         opts.struct_size = sizeof opts;
@@ -542,9 +475,9 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         }
     }
     zdw_ctx *ctx = guard.ctx;
+    zdw_multi *mm = mguard.m;
     clock.mark("ctx_create");
-    const unsigned char *image = hostImage ? hostImage->data() : reinterpret_cast<const unsigned char *>(mappedImage);
-    {
+    if (!several) {
         int rc;
         if (streamFd >= 0) {
             // the input is read while its blocks are encoded; with -i -v it is teed into <base>.tmp.1.gz on the way
@@ -604,7 +537,56 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
     bool more = true;
     std::vector<unsigned char> colSize(numColumns ? numColumns : 1);
     std::vector<uint64_t> colBase(numColumns ? numColumns : 1);
-    while (more && res == OK) {
+    while (several && more && res == OK) {
+        ++blocks;
+        if (!bQuiet) {
+            if (blocks == 1) statusOutput(INFO, "\nProcessing %s\n", filestub);
+            else statusOutput(INFO, "\nProcessing block %d of %s (%llu rows so far)\n", blocks, filestub, (unsigned long long)totalRows);
+        }
+        zdw_multi_block blk;
+        memset(&blk, 0, sizeof blk);
+        int rc = zdw_multi_encode(mm, &blk);
+        clock.mark("pass1+dict+pass2");
+        if (rc == ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW) {
+            statusOutput(ERROR, "\nRow %u had the problem\n", blk.bad_row);
+            res = WRONG_NUM_OF_COLUMNS_ON_A_ROW;
+            break;
+        }
+        if (rc != ZDW_OK) {
+            libError = zdw_multi_last_error(mm);
+            if (rc == ZDW_OUT_OF_MEMORY && blk.num_rows == 0) statusOutput(ERROR, "Not enough memory to run %s\n", exeName);
+            statusOutput(ERROR, "%s\n", libError.c_str());
+            res = static_cast<ERR_CODE>(rc);
+            break;
+        }
+        if (blk.num_rows == 0) {
+            if (blocks == 1) statusOutput(ERROR, "Empty data file -- nothing to process\n");
+            break;
+        }
+        if (!bQuiet) statusOutput(INFO, "\r%u rows\n", blk.num_rows);
+        ok = ok && out.le(blk.num_rows, 4) && out.le(blk.longest_line, 4) && out.le(blk.is_last_block ? 1 : 0, 1);
+        uint32_t used = 0;
+        rc = zdw_multi_dict_write(mm, writeToPipe, &out, NULL);
+        clock.mark("write_dict");
+        if (rc == ZDW_OK) rc = zdw_multi_stats(mm, colSize.data(), colBase.data(), &used);
+        if (rc == ZDW_OK) {
+            ok = ok && out.put(colSize.data(), numColumns);
+            for (uint32_t u = 0; u < used; ++u) ok = ok && out.le(colBase[u], 8);
+            rc = zdw_multi_rows_write(mm, writeToPipe, &out, NULL);
+            clock.mark("write_rows");
+        }
+        if (rc == ZDW_OK) rc = zdw_multi_next(mm);
+        if (rc != ZDW_OK) {
+            libError = zdw_multi_last_error(mm);
+            statusOutput(ERROR, "%s\n", libError.c_str());
+            res = static_cast<ERR_CODE>(rc);
+            break;
+        }
+        totalRows += blk.num_rows;
+        if (!bQuiet) statusOutput(INFO, "\r%u\nDone with block %d -- cleaning up...\n", blk.num_rows, blocks);
+        more = !blk.is_last_block;
+    }
+    while (!several && more && res == OK) {
         ++blocks;
         if (!bQuiet) {
             if (blocks == 1) statusOutput(INFO, "\nProcessing %s\n", filestub);

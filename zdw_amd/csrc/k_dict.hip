@@ -583,6 +583,113 @@ __global__ __launch_bounds__(64) void k_locate_field(const uint8_t *__restrict__
     if (lane == 0) { out[0] = rs; out[1] = total; }
 }
 
+// ---- the same walk over the shards of a row-sharded block (zdw_shard_model_walk) ----
+// The block's strings enter the reference's arenas in the order of their first occurrence: shard 0's, then those of shard 1 that
+// shard 0 does not hold, ...  Every shard walks its own node-wide-first strings from the state the shard before it left:
+// state[0] arenas taken, state[1] dictionary entries, state[2] bytes left in the open arena.  out[0] = index (in position order) of
+// the string whose arena trips the limit, or ~0; out[1..3] = the state behind this shard's strings.
+__global__ void k_model_trip_chained(const uint64_t *__restrict__ excl /* n + 1 */, uint32_t n, uint64_t arenas0, uint64_t entries0, uint64_t free0,
+                                     double base_mb, double node_bytes, double limit_mb, uint64_t arena_bytes, uint64_t *__restrict__ out)
+{
+    uint64_t start = 0, arenas = arenas0, trip = ~0ull, left = free0;
+    if (n && free0) {                                    // what still fits the arena that is open: the largest j with excl[j] <= free0
+        uint64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint64_t m = lo + (hi - lo + 1) / 2;
+            if (excl[m] - excl[0] <= free0) lo = m; else hi = m - 1;
+        }
+        start = lo;
+        left = free0 - (excl[lo] - excl[0]);
+    }
+    while (start < n) {
+        ++arenas;
+        const double vsize = base_mb + 64.0 * (double)arenas + node_bytes * (double)(entries0 + start + 1) / 1048576.0;
+        if (vsize >= limit_mb) { trip = start; break; }
+        const uint64_t need0 = excl[start + 1] - excl[start];
+        const uint64_t cap = need0 > arena_bytes ? need0 : arena_bytes;
+        uint64_t lo = start + 1, hi = n;
+        const uint64_t lim = excl[start] + cap;
+        while (lo < hi) {
+            const uint64_t m = lo + (hi - lo + 1) / 2;
+            if (excl[m] <= lim) lo = m; else hi = m - 1;
+        }
+        left = lim - excl[lo];
+        start = lo;
+    }
+    out[0] = trip;
+    out[1] = arenas;
+    out[2] = entries0 + n;
+    out[3] = left;
+}
+void launch_model_trip_chained(const uint64_t *excl, uint32_t n, uint64_t arenas0, uint64_t entries0, uint64_t free0, double base_mb, double node_bytes,
+                               double limit_mb, uint64_t arena_bytes, uint64_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_model_trip_chained, dim3(1), dim3(1), 0, s, excl, n, arenas0, entries0, free0, base_mb, node_bytes, limit_mb, arena_bytes, out);
+}
+
+// lengths of this shard's strings as the walk sees them: a string some earlier shard holds too is none of this shard's (length 0).
+// order[j] = unique id of the j-th exported string, flags[j] = the owner's verdict on it; mlen is zeroed beforehand; *count += firsts
+__global__ __launch_bounds__(256) void k_mask_first(const uint32_t *__restrict__ order, const uint32_t *__restrict__ flags, uint32_t n,
+                                                     const uint32_t *__restrict__ uniq_len, uint32_t *__restrict__ mlen, uint32_t *__restrict__ count)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    bool first = false;
+    if (j < n && flags[j]) {
+        const uint32_t id = order[j];
+        const uint32_t l = uniq_len[id];
+        if (l) { mlen[id] = l; first = true; }
+    }
+    const uint32_t k = popc64(__ballot(first));
+    if (k && lane_id() == 0) atomicAdd(count, k);
+}
+void launch_mask_first(const uint32_t *order, const uint32_t *flags, uint32_t n, const uint32_t *uniq_len, uint32_t *mlen, uint32_t *count, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_mask_first, dim3((n + 255) / 256), dim3(256), 0, s, order, flags, n, uniq_len, mlen, count);
+}
+
+// position of the first occurrence of every exported string (order[j] = its unique id), `base` added
+__global__ __launch_bounds__(256) void k_export_positions(const uint32_t *__restrict__ order, const uint64_t *__restrict__ uniq_pos, uint32_t n, uint64_t base,
+                                                           uint64_t *__restrict__ out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = base + (uniq_pos[order[j]] & POS_MASK);
+}
+void launch_export_positions(const uint32_t *order, const uint64_t *uniq_pos, uint32_t n, uint64_t base, uint64_t *out, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_export_positions, dim3((n + 255) / 256), dim3(256), 0, s, order, uniq_pos, n, base, out);
+}
+
+// owner side: the smallest position any shard reported for a string (ids[j] = unique id + 1 of arrival j, 0 = none)
+__global__ __launch_bounds__(256) void k_owner_minpos(const uint32_t *__restrict__ ids, const uint64_t *__restrict__ pos, uint32_t n, uint64_t *__restrict__ minpos)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && ids[j]) atomicMin(reinterpret_cast<unsigned long long *>(minpos + (ids[j] - 1u)), (unsigned long long)pos[j]);
+}
+__global__ __launch_bounds__(256) void k_owner_first(const uint32_t *__restrict__ ids, const uint64_t *__restrict__ pos, uint32_t n, const uint64_t *__restrict__ minpos,
+                                                      uint32_t *__restrict__ flags)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) flags[j] = (ids[j] && pos[j] == minpos[ids[j] - 1u]) ? 1u : 0u;
+}
+void launch_owner_minpos(const uint32_t *ids, const uint64_t *pos, uint64_t n, uint64_t *minpos, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_owner_minpos, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, ids, pos, (uint32_t)n, minpos);
+}
+void launch_owner_first(const uint32_t *ids, const uint64_t *pos, uint64_t n, const uint64_t *minpos, uint32_t *flags, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_owner_first, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, ids, pos, (uint32_t)n, minpos, flags);
+}
+// strings first met beyond last_pos are none of this block's: holes
+__global__ __launch_bounds__(256) void k_owner_filter(const uint64_t *__restrict__ minpos, uint32_t *__restrict__ ulen, uint32_t n, uint64_t last_pos)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ulen[i] && minpos[i] > last_pos) ulen[i] = 0;
+}
+void launch_owner_filter(const uint64_t *minpos, uint32_t *ulen, uint32_t n, uint64_t last_pos, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_owner_filter, dim3((n + 255) / 256), dim3(256), 0, s, minpos, ulen, n, last_pos);
+}
+
 void launch_model_sort(const uint64_t *uniq_pos, const uint32_t *uniq_len, uint32_t n, SortBuffers &b, uint32_t **vals_out, hipStream_t s)
 {
     uint64_t *keys = b.key_a, *keys_alt = b.key_b;

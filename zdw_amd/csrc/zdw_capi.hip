@@ -154,6 +154,7 @@ struct zdw_ctx {
     uint32_t partial_taken = 0;            // leading fields of the row after the current block that its pass 1 visited (zdw_block_partial_fields)
     uint64_t pass1_launches = 0;           // pass-1 kernel launches of this context (zdw_ctx_pass1_launches)
     uint32_t last_span_shift = 14;         // geometry of the last pass 1 (model_trip)
+    bool last_fold = false;                // ... which counted its own rows (span_state instead of span_rowbase)
     uint64_t last_span0 = 0;
     bool oom_seen = false;                 // a call ended in OUT_OF_MEMORY: the next pass 1 starts from released block buffers
     std::vector<LongRow> long_list;        // this block's rows of 16383 bytes or more, by position (zdw_shard_line_caps replays them)
@@ -203,8 +204,13 @@ struct zdw_ctx {
     bool uniques_sorted = false, presorted = false;
     // ... and as the owner of one key range of the node-wide dictionary
     DevBuf own_slots, own_upos, own_ulen, own_status, own_extra, own_lens, own_offs, own_ids, own_idoff, own_blob, own_out;
-    uint64_t own_count = 0, own_slice = 0;
-    bool own_built = false;
+    uint64_t own_count = 0, own_slice = 0, own_nids = 0;
+    uint32_t own_max_len = 24;
+    bool own_built = false, own_imported = false, own_has_pos = false;
+    DevBuf own_pos, own_minpos, own_flags;  // ... where a memory limit may end the block: every arrival's first position, the smallest per string
+    DevBuf model_len, exp_pos;             // requester side of that: lengths as the arena walk sees them, positions of the exported strings
+    bool track_first_opt = false;          // zdw_opts.track_first_occurrence
+    bool defer_bad_row = false;            // zdw_opts.defer_bad_row
     bool p1_all_in_one = false;            // the deferred-field queue would outgrow its budget: use the all-in-one kernel
     uint64_t dq_learned = 0;               // queue entries an earlier pass of this context needed
     double dq_rate = 0.0;                  // ... and the most it queued per input byte
@@ -284,7 +290,7 @@ void collect_times(zdw_ctx *c)
 void reset_block(zdw_ctx *c)
 {
     c->p1_done = c->dict_size_done = c->dict_done = c->stats_done = c->p2_size_done = c->p2_done = false;
-    c->uniques_sorted = c->own_built = false;
+    c->uniques_sorted = c->own_built = c->own_imported = false;
     c->nrows = 0; c->nuniq = 0; c->nids = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
     c->have_prev = false;
     c->nz_mode = false; c->rec_dense = true;
@@ -679,6 +685,8 @@ int ensure_dict(zdw_ctx *c)
 constexpr double MODEL_BASE_MB = 2.6, MODEL_NODE_BYTES = 64.0;
 constexpr uint64_t MODEL_ARENA = 64ull << 20;
 
+int locate_occurrence(zdw_ctx *c, uint64_t pos, uint32_t span_shift, uint64_t span0, uint32_t *row, uint32_t *fields, uint64_t *row_start);
+
 int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uint32_t *row, uint32_t *fields, uint64_t *row_start)
 {
     *found = false;
@@ -721,7 +729,14 @@ int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uin
     HIP_TRY(c, hipMemcpy(&pos, c->uniq_pos.as<uint64_t>() + id, 8, hipMemcpyDeviceToHost));
     pos &= POS_MASK;
     if (pos >= EXTRA_BASE) return ZDW_OK;                  // an imported string (multi-GPU merge): no position in this image
-    // the row and the column of that occurrence
+    *found = true;
+    return locate_occurrence(c, pos, span_shift, span0, row, fields, row_start);
+}
+
+// the row (within the block pass 1 has just parsed) and the field that hold input position `pos`
+int locate_occurrence(zdw_ctx *c, uint64_t pos, uint32_t span_shift, uint64_t span0, uint32_t *row, uint32_t *fields, uint64_t *row_start)
+{
+    hipStream_t s = c->stream;
     launch_locate_field(c->d_in, c->lo, pos, c->d_scalar.as<uint64_t>(), s);
     uint64_t loc[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(loc, c->d_scalar.p, 16, hipMemcpyDeviceToHost, s));
@@ -729,14 +744,20 @@ int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uin
     const uint64_t rs = loc[0];
     const uint64_t si = (rs >> span_shift) - span0;        // the span the row starts in; rows that start before it: span_rowbase
     uint32_t rowbase = 0, in_span = 0;
-    HIP_TRY(c, hipMemcpy(&rowbase, c->span_rowbase.as<uint32_t>() + si, 4, hipMemcpyDeviceToHost));
+    if (c->last_fold) {
+        // pass 1 counted its own rows: a word per span, the rows that start up to and including it (Pass1Args.span_state)
+        uint64_t w = 0;
+        if (si) HIP_TRY(c, hipMemcpy(&w, c->span_state.as<uint64_t>() + (si - 1), 8, hipMemcpyDeviceToHost));
+        rowbase = (uint32_t)(w & 0x3fffffffffffffffull);
+    } else {
+        HIP_TRY(c, hipMemcpy(&rowbase, c->span_rowbase.as<uint32_t>() + si, 4, hipMemcpyDeviceToHost));
+    }
     if (rs > std::max<uint64_t>((span0 + si) << span_shift, c->lo)) {
         // ... and the rows that start inside it before this one: the row scan's own kernel on that piece
         launch_count_row_starts(c->d_in, c->n, c->lo, rs, span0 + si, 1, span_shift, c->d_scalar.as<uint32_t>() + 8, c->status.as<P1Status>(), s);
         HIP_TRY(c, hipMemcpyAsync(&in_span, c->d_scalar.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
     }
-    *found = true;
     *row = rowbase + in_span;
     *fields = (uint32_t)loc[1] + 1;
     *row_start = rs;
@@ -749,7 +770,7 @@ int ensure_dense_rec(zdw_ctx *c);
 // has a record: row < the rows pass 1 kept).  Instead of a second pass 1 up to there, what the rows beyond that point added is
 // taken back (k_trim_scan: launch_trim_block): strings only they hold become holes among the unique ids, ranges and used columns
 // are rebuilt from the records that stay, the line buffer is replayed up to the new end.
-int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res)
+int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res, bool allow_no_rows = false)
 {
     hipStream_t s = c->stream;
     const bool sparse = c->nz_mode && !c->rec_dense;      // (the matrix means something only where the map says so: the scan goes by the map too)
@@ -793,7 +814,7 @@ int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zd
         HIP_TRY(c, hipMemcpy(c->h_max.data(), c->col_max.p, c->ncols * 8, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(c->h_seen.data(), c->col_seen.p, c->ncols, hipMemcpyDeviceToHost));
     }
-    if (row == 0) return fail(c, ZDW_OUT_OF_MEMORY, "block limit leaves no room for a single row");
+    if (row == 0 && !allow_no_rows) return fail(c, ZDW_OUT_OF_MEMORY, "block limit leaves no room for a single row");
     return ZDW_OK;
 }
 
@@ -970,7 +991,7 @@ std::vector<DevBuf *> all_device_buffers(zdw_ctx *c)
     return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->span_state, &c->nz, &c->d_used_col, &c->scan_tmp, &c->scan_tmp2, &c->rec,
                       &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
                       &c->own_upos, &c->own_ulen, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
-                      &c->own_out, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
+                      &c->own_out, &c->own_pos, &c->own_minpos, &c->own_flags, &c->model_len, &c->exp_pos, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
                       &c->uniq_pos, &c->uniq_len, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
                       &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
                       &c->extra_lens, &c->extra_offs, &c->exp_bytes, &c->d_used_recoff, &c->d_used_kind, &c->d_used_size,
@@ -1045,6 +1066,8 @@ int zdw_ctx_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *opt
         c->max_dict_bytes = opts->max_dict_bytes;
         if (opts->struct_size >= offsetof(zdw_opts, max_device_bytes) + sizeof(uint64_t)) c->budget.cap = opts->max_device_bytes;
         if (opts->struct_size >= offsetof(zdw_opts, mem_limit_mb) + sizeof(uint64_t)) c->mem_limit_mb = (double)opts->mem_limit_mb;
+        if (opts->struct_size >= offsetof(zdw_opts, track_first_occurrence) + sizeof(uint64_t)) c->track_first_opt = opts->track_first_occurrence != 0;
+        if (opts->struct_size >= offsetof(zdw_opts, defer_bad_row) + sizeof(uint64_t)) c->defer_bad_row = opts->defer_bad_row != 0;
     }
     for (DevBuf *b : all_device_buffers(c)) b->bud = &c->budget;
     int rc = upload_schema(c);
@@ -1458,7 +1481,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
             // the memory-limit model asks in which order the strings are first met: every occurrence takes part in a minimum
-            a.track_first = c->model_max_slots ? 1u : 0u;
+            a.track_first = (c->model_max_slots || c->track_first_opt) ? 1u : 0u;
             if (const char *e = getenv("ZDW_P1_TRACK_FIRST")) a.track_first = atoi(e) != 0;      // tests
             if (a.track_first) HIP_TRY(c, hipMemsetAsync(c->uniq_pos.p, 0xFF, (uint64_t)c->id_cap * 8, s));
             a.dense_boundaries = c->dense_boundaries ? 1u : 0u;
@@ -1503,7 +1526,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             }
             launch_pass1(a, s);
             ++c->pass1_launches;
-            c->last_span_shift = span_shift; c->last_span0 = span0;
+            c->last_span_shift = span_shift; c->last_span0 = span0; c->last_fold = fold;
             if (defer) {
                 HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
@@ -1565,7 +1588,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
 
     if (st.bad_row != 0xFFFFFFFFu && st.bad_row <= row_limit) {          // ConvertToZDW.cpp:810-812
         res->bad_row = st.bad_row + 1;
-        return fail(c, ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW, "Row %u had the problem", res->bad_row);
+        if (!c->defer_bad_row) return fail(c, ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW, "Row %u had the problem", res->bad_row);
     }
 
     // ---- m_LongestLine: replay the reference's buffer growth on rows that could have triggered it ----
@@ -2024,13 +2047,16 @@ int zdw_shard_partition(zdw_ctx *c, uint32_t nparts, const uint64_t *splitters, 
 }
 
 // Owner side: the strings of one key range from every shard (lens + NUL-terminated bytes, any order, duplicates
-// across shards): dedupe, sort, lay out.  slice_bytes = the bytes this range takes in the dictionary.
-int zdw_owner_build(zdw_ctx *c, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes, uint64_t *slice_bytes)
+// across shards): dedupe (zdw_owner_import), then sort and lay out (zdw_owner_finish).  slice_bytes = the bytes this range takes in
+// the dictionary.  With positions (where a memory limit may end the block, include/zdw_hip.h): the smallest position reported for a
+// string is kept, the arrival that reported it is its first occurrence node-wide (zdw_owner_first_flags), and strings first met
+// beyond the block's end are dropped before the sort (zdw_owner_finish's last_pos).
+int zdw_owner_import(zdw_ctx *c, const void *d_lens, const void *d_bytes, const void *d_pos, uint64_t count, uint64_t nbytes)
 {
     if (!c) return ZDW_UNKNOWN_ERROR;
     (void)hipSetDevice(c->device);
     hipStream_t s = c->stream;
-    c->own_built = false; c->own_count = count; c->own_slice = 0;
+    c->own_built = c->own_imported = false; c->own_count = count; c->own_slice = 0; c->own_nids = 0; c->own_has_pos = false;
     if (nbytes >= EXTRA_BASE || count >= 0xFFFFFFF0ull) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary range too large");
     uint64_t nslots = 1ull << 14;
     while (nslots < 2 * count) nslots <<= 1;
@@ -2055,7 +2081,7 @@ int zdw_owner_build(zdw_ctx *c, const void *d_lens, const void *d_bytes, uint64_
     HIP_TRY(c, hipMemcpyAsync(&total_in, c->own_offs.as<uint64_t>() + count, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     if (total_in != nbytes)
-        return fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_build: lengths add up to %llu bytes, %llu were passed", (unsigned long long)total_in,
+        return fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_import: lengths add up to %llu bytes, %llu were passed", (unsigned long long)total_in,
                     (unsigned long long)nbytes);
     launch_import_strings(nullptr, 0, c->own_extra.as<uint8_t>(), c->own_lens.as<uint32_t>(), c->own_offs.as<uint64_t>(), count,
                           c->own_slots.as<uint64_t>(), nslots - 1, (uint32_t)std::min<uint64_t>(nslots - nslots / 8, 0xFFFFFFF0ull),
@@ -2064,10 +2090,44 @@ int zdw_owner_build(zdw_ctx *c, const void *d_lens, const void *d_bytes, uint64_
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->own_status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (st.overflow || st.id_next > cap) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_build: range table overflow");
-    const uint64_t u = st.id_next;
-    int rc = sort_strings(c, nullptr, 0, c->own_extra.as<uint8_t>(), c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), u,
-                          std::max<uint32_t>(24, st.max_len));
+    if (st.overflow || st.id_next > cap) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_import: range table overflow");
+    c->own_nids = st.id_next;
+    c->own_max_len = std::max<uint32_t>(24, st.max_len);
+    if (d_pos) {
+        HIP_TRY(c, c->own_pos.ensure((count + 1) * 8)); HIP_TRY(c, c->own_minpos.ensure((c->own_nids + 1) * 8));
+        if (count) HIP_TRY(c, hipMemcpyAsync(c->own_pos.p, d_pos, count * 8, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(c->own_minpos.p, 0xFF, (c->own_nids + 1) * 8, s));
+        launch_owner_minpos(c->own_ids.as<uint32_t>(), c->own_pos.as<uint64_t>(), count, c->own_minpos.as<uint64_t>(), s);
+        HIP_TRY(c, hipStreamSynchronize(s));
+        c->own_has_pos = true;
+    }
+    c->own_imported = true;
+    return ZDW_OK;
+}
+
+// per arrival (u32): 1 = the arrival's position is the smallest any shard reported for its string
+int zdw_owner_first_flags(zdw_ctx *c, const void **d_flags)
+{
+    if (!c || !c->own_imported || !c->own_has_pos) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_import has not run with positions") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, c->own_flags.ensure((c->own_count + 1) * 4));
+    launch_owner_first(c->own_ids.as<uint32_t>(), c->own_pos.as<uint64_t>(), c->own_count, c->own_minpos.as<uint64_t>(), c->own_flags.as<uint32_t>(), c->stream);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (d_flags) *d_flags = c->own_flags.p;
+    return ZDW_OK;
+}
+
+int zdw_owner_finish(zdw_ctx *c, uint64_t last_pos, uint64_t *slice_bytes)
+{
+    if (!c || !c->own_imported) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_import has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    const uint64_t u = c->own_nids;
+    if (last_pos != ~0ull) {
+        if (!c->own_has_pos) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_finish: the strings came without positions");
+        launch_owner_filter(c->own_minpos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), (uint32_t)u, last_pos, s);
+    }
+    int rc = sort_strings(c, nullptr, 0, c->own_extra.as<uint8_t>(), c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), u, c->own_max_len);
     if (rc) return rc;
     {
         StageScope ts(c, ZDW_STAGE_DICT_EMIT);
@@ -2088,6 +2148,12 @@ int zdw_owner_build(zdw_ctx *c, const void *d_lens, const void *d_bytes, uint64_
     c->own_built = true;
     if (slice_bytes) *slice_bytes = c->own_slice;
     return ZDW_OK;
+}
+
+int zdw_owner_build(zdw_ctx *c, const void *d_lens, const void *d_bytes, uint64_t count, uint64_t nbytes, uint64_t *slice_bytes)
+{
+    const int rc = zdw_owner_import(c, d_lens, d_bytes, nullptr, count, nbytes);
+    return rc ? rc : zdw_owner_finish(c, ~0ull, slice_bytes);
 }
 
 // dictionary offsets of the strings zdw_owner_build received, in arrival order; base = offset of the range's first string
@@ -2121,6 +2187,15 @@ int zdw_shard_set_offsets(zdw_ctx *c, const void *d_offsets, uint64_t count, uin
                     (unsigned long long)dict_size, (unsigned long long)limit);
     HIP_TRY(c, c->slot_off.ensure((c->sorted_n + 1) * 4));
     launch_scatter_offsets(c->my_order.as<uint32_t>() + c->sorted_holes, static_cast<const uint32_t *>(d_offsets), real, c->slot_off.as<uint32_t>(), s);
+    c->nuniq = dict_size > 1 ? std::max<uint64_t>(real, 1) : 0;
+    return zdw_owner_section(c, dict_size, first_range);
+}
+
+int zdw_owner_section(zdw_ctx *c, uint64_t dict_size, int first_range)
+{
+    if (!c || !c->own_built) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_finish has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
     c->dict_size = dict_size;
     c->index_size = (uint8_t)bytes_for(dict_size);
     // this rank's piece of the dictionary section
@@ -2142,9 +2217,121 @@ int zdw_shard_set_offsets(zdw_ctx *c, const void *d_offsets, uint64_t count, uin
         c->dict_sec_off = 9; c->dict_sec_len = c->own_slice;
     }
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->nuniq = dict_size > 1 ? std::max<uint64_t>(real, 1) : 0;
+    if (!c->uniques_sorted) c->nuniq = dict_size > 1 ? 1 : 0;          // (no rows of this block here: only "is the section empty" is ever asked)
     c->dict_size_done = c->dict_done = true;
     c->stats_done = false;
+    invalidate_pass2(c);
+    return ZDW_OK;
+}
+
+// ---- where the reference's memory limit ends a row-sharded block (include/zdw_hip.h) ----
+double zdw_model_upper_bound_mb(uint64_t entries, uint64_t bytes, uint32_t max_len)
+{
+    // even with every arena wasting its tail (a string never straddles two arenas: stringheap.cpp:61-73)
+    const uint64_t ml = (uint64_t)std::max<uint32_t>(max_len, 24) + 1;
+    const double arenas = (double)(bytes / (MODEL_ARENA > 2 * ml ? MODEL_ARENA - ml : MODEL_ARENA / 2) + 1);
+    return MODEL_BASE_MB + 64.0 * arenas + MODEL_NODE_BYTES * (double)entries / 1048576.0;
+}
+
+int zdw_shard_model_counts(zdw_ctx *c, uint64_t *entries, uint64_t *bytes, uint32_t *max_len)
+{
+    if (!c || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    P1Status st{};
+    HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint64_t u = st.id_next;
+    if (u > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", st.id_next, c->id_cap);
+    HIP_TRY(c, c->lenp1.ensure((u + 1) * 4)); HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(u + 1)));
+    launch_dict_lengths(nullptr, c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (entries) *entries = st.entries;
+    if (bytes) *bytes = total;
+    if (max_len) *max_len = st.max_len;
+    return ZDW_OK;
+}
+
+int zdw_shard_positions(zdw_ctx *c, uint64_t base, const void **d_pos)
+{
+    if (!c || !c->uniques_sorted) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_partition has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    const uint64_t real = c->sorted_n - c->sorted_holes;
+    HIP_TRY(c, c->exp_pos.ensure((real + 1) * 8));
+    launch_export_positions(c->my_order.as<uint32_t>() + c->sorted_holes, c->uniq_pos.as<uint64_t>(), (uint32_t)real, base, c->exp_pos.as<uint64_t>(), c->stream);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (d_pos) *d_pos = c->exp_pos.p;
+    return ZDW_OK;
+}
+
+int zdw_shard_model_walk(zdw_ctx *c, const void *d_flags, uint64_t count, double limit_mb, zdw_model_state *state, uint32_t *found, uint32_t *row,
+                         uint32_t *fields, uint64_t *row_start, uint64_t *trip_pos)
+{
+    if (!c || !c->uniques_sorted || !state || !found) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_partition has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    *found = 0;
+    const uint64_t real = c->sorted_n - c->sorted_holes, u = c->sorted_n;
+    if (count != real) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_model_walk: %llu flags for %llu strings", (unsigned long long)count, (unsigned long long)real);
+    if (!real) return ZDW_OK;
+    // this shard's node-wide-first strings by position, prefix sums of len + 1 in that order, the walk over the arenas
+    HIP_TRY(c, c->model_len.ensure((u + 1) * 4));
+    HIP_TRY(c, c->d_scalar.ensure(64));
+    HIP_TRY(c, hipMemsetAsync(c->model_len.p, 0, (u + 1) * 4, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_scalar.p, 0, 64, s));
+    launch_mask_first(c->my_order.as<uint32_t>() + c->sorted_holes, static_cast<const uint32_t *>(d_flags), (uint32_t)real, c->uniq_len.as<uint32_t>(),
+                      c->model_len.as<uint32_t>(), c->d_scalar.as<uint32_t>() + 12, s);
+    uint32_t nfirst = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nfirst, c->d_scalar.as<uint32_t>() + 12, 4, hipMemcpyDeviceToHost, s));
+    SortBuffers b{};
+    int rc = sort_buffers(c, u, b);
+    if (rc) return rc;
+    HIP_TRY(c, c->lenp1.ensure((u + 1) * 4)); HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
+    HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(u + 1)));
+    uint32_t *by_pos = nullptr;
+    launch_model_sort(c->uniq_pos.as<uint64_t>(), c->model_len.as<uint32_t>(), (uint32_t)u, b, &by_pos, s);
+    launch_dict_lengths(by_pos, c->model_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);
+    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+    HIP_TRY(c, hipStreamSynchronize(s));          // nfirst
+    launch_model_trip_chained(c->off_excl.as<uint64_t>(), nfirst, state->arenas, state->entries, state->arena_free, MODEL_BASE_MB, MODEL_NODE_BYTES, limit_mb,
+                              MODEL_ARENA, c->d_scalar.as<uint64_t>(), s);
+    uint64_t res[4] = {~0ull, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(res, c->d_scalar.p, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    state->arenas = res[1]; state->entries = res[2]; state->arena_free = res[3];
+    if (res[0] == ~0ull) return ZDW_OK;
+    uint32_t id = 0;
+    uint64_t pos = 0;
+    HIP_TRY(c, hipMemcpy(&id, by_pos + res[0], 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&pos, c->uniq_pos.as<uint64_t>() + id, 8, hipMemcpyDeviceToHost));
+    pos &= POS_MASK;
+    if (pos >= EXTRA_BASE) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_model_walk: the tripping string has no position in this shard's image");
+    uint32_t r = 0, f = 0;
+    uint64_t rs = 0;
+    rc = locate_occurrence(c, pos, c->last_span_shift, c->last_span0, &r, &f, &rs);
+    if (rc) return rc;
+    *found = 1;
+    if (row) *row = r;
+    if (fields) *fields = f;
+    if (row_start) *row_start = rs;
+    if (trip_pos) *trip_pos = pos;
+    return ZDW_OK;
+}
+
+int zdw_shard_trim(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res)
+{
+    if (!c || !c->p1_done || !res) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    if (row >= c->nrows) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_trim: row %u is not among the shard's %u rows", row, c->nrows);
+    // (a shard that keeps no row still keeps the partial row's fields in the block's dictionary and ranges: no error here, the
+    // caller knows whether the whole block is left without a row)
+    const int rc = trim_block(c, row, fields, row_start, res, true);
+    if (rc) return rc;
+    c->dict_size_done = c->dict_done = c->stats_done = false;
     invalidate_pass2(c);
     return ZDW_OK;
 }

@@ -146,6 +146,14 @@ void launch_model_sort(const uint64_t *uniq_pos, const uint32_t *uniq_len, uint3
 void launch_model_trip(const uint64_t *excl, uint32_t nreal, double base_mb, double node_bytes, double limit_mb, uint64_t arena_bytes, uint64_t *out,
                        hipStream_t s);
 void launch_locate_field(const uint8_t *in, uint64_t lo, uint64_t p, uint64_t *out, hipStream_t s);
+// ... over the shards of a row-sharded block (zdw_shard_model_walk, zdw_owner_import / _first_flags / _finish)
+void launch_model_trip_chained(const uint64_t *excl, uint32_t n, uint64_t arenas0, uint64_t entries0, uint64_t free0, double base_mb, double node_bytes,
+                               double limit_mb, uint64_t arena_bytes, uint64_t *out /* 4 */, hipStream_t s);
+void launch_mask_first(const uint32_t *order, const uint32_t *flags, uint32_t n, const uint32_t *uniq_len, uint32_t *mlen, uint32_t *count, hipStream_t s);
+void launch_export_positions(const uint32_t *order, const uint64_t *uniq_pos, uint32_t n, uint64_t base, uint64_t *out, hipStream_t s);
+void launch_owner_minpos(const uint32_t *ids, const uint64_t *pos, uint64_t n, uint64_t *minpos, hipStream_t s);
+void launch_owner_first(const uint32_t *ids, const uint64_t *pos, uint64_t n, const uint64_t *minpos, uint32_t *flags, hipStream_t s);
+void launch_owner_filter(const uint64_t *minpos, uint32_t *ulen, uint32_t n, uint64_t last_pos, hipStream_t s);
 void launch_trim_block(const uint8_t *rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff, uint32_t rows,
                        uint32_t partial, uint8_t *live, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids,
                        uint32_t *entries, const uint32_t *nz, uint32_t nz_stride, hipStream_t s);

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,11 +81,12 @@ struct Shard {
     std::string err;
     // exchange buffers (device)
     void *d_ranges = nullptr;              // 3 x ncols u64: ~min, max, seen
-    void *d_recv_lens = nullptr, *d_recv_bytes = nullptr, *d_recv_offs = nullptr, *d_back = nullptr;
-    size_t cap_recv_lens = 0, cap_recv_bytes = 0, cap_recv_offs = 0, cap_back = 0;
+    void *d_recv_lens = nullptr, *d_recv_bytes = nullptr, *d_recv_offs = nullptr, *d_back = nullptr, *d_recv_pos = nullptr;
+    size_t cap_recv_lens = 0, cap_recv_bytes = 0, cap_recv_offs = 0, cap_back = 0, cap_recv_pos = 0;
+    bool p1_valid = false;                 // pass 1 has run over the rows this shard still holds and nothing has cut them back since
     // partition results
     std::vector<uint64_t> counts, nbytes;  // per destination range
-    const void *d_lens = nullptr, *d_bytes = nullptr;
+    const void *d_lens = nullptr, *d_bytes = nullptr, *d_pos = nullptr;
     const void *d_offsets = nullptr;
     uint64_t slice = 0;
 };
@@ -98,8 +100,13 @@ struct zdw_multi {
     std::string err;
     const uint8_t *image = nullptr;
     uint64_t image_len = 0;
-    bool encoded = false;
-    uint32_t longest_line = 16384;
+    bool encoded = false;                  // a block has been encoded and not been left yet (zdw_multi_next)
+    bool finished = false;                 // the input's last block has been left
+    uint32_t longest_line = 16384;         // m_LongestLine: persists across the blocks of one input
+    double mem_limit_mb = 0.0;             // zdw_opts.mem_limit_mb: where the reference's blocks end (0 = one block)
+    size_t first = 0;                      // the first shard that still holds rows
+    size_t blk_first = 0, blk_end = 0;     // the shards that hold the current block's rows
+    bool blk_tripped = false;              // ... which the memory limit ended
 };
 
 namespace {
@@ -213,7 +220,7 @@ void zdw_multi_destroy(zdw_multi *m)
     for (Shard &s : m->sh) {
         (void)hipSetDevice(s.device);
         if (s.ctx) zdw_ctx_destroy(s.ctx);
-        for (void *p : {s.d_ranges, s.d_recv_lens, s.d_recv_bytes, s.d_recv_offs, s.d_back}) if (p) (void)hipFree(p);
+        for (void *p : {s.d_ranges, s.d_recv_lens, s.d_recv_bytes, s.d_recv_offs, s.d_back, s.d_recv_pos}) if (p) (void)hipFree(p);
         if (s.comm) (void)rccl().CommDestroy(s.comm);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
@@ -239,7 +246,10 @@ int zdw_multi_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *o
         if (opts) memcpy(&o, opts, std::min<size_t>(sizeof o, opts->struct_size ? opts->struct_size : sizeof o));
         o.struct_size = sizeof o;
         o.device = s.device;
-        o.mem_limit_mb = 0;                       // one block: where it ends is not a per-shard decision
+        if (i == 0 && o.struct_size >= offsetof(zdw_opts, mem_limit_mb) + sizeof(uint64_t)) m->mem_limit_mb = (double)o.mem_limit_mb;
+        o.mem_limit_mb = 0;                       // where a block ends is not a per-shard decision: zdw_multi_encode
+        o.track_first_occurrence = m->mem_limit_mb > 0.0 ? 1 : 0;
+        o.defer_bad_row = 1;                      // ... nor is whether the block reaches a bad row
         const int rc = zdw_ctx_create(col_types, ncols, &o, &s.ctx);
         if (rc) { const int r2 = mfail(nullptr, rc, "shard %u (device %d): %s", i, s.device, zdw_last_error(nullptr)); zdw_multi_destroy(m); return r2; }
         if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
@@ -266,7 +276,8 @@ int zdw_multi_set_input_host(zdw_multi *m, const uint8_t *tsv, uint64_t len)
 {
     if (!m || (len && !tsv)) return m ? mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_set_input_host: tsv is NULL") : ZDW_UNKNOWN_ERROR;
     const size_t n = m->sh.size();
-    m->image = tsv; m->image_len = len; m->encoded = false;
+    m->image = tsv; m->image_len = len; m->encoded = false; m->finished = false; m->first = 0; m->longest_line = 16384;
+    for (Shard &s : m->sh) s.p1_valid = false;
     std::vector<uint64_t> cut(n + 1, len);
     cut[0] = 0;
     for (size_t i = 1; i < n; ++i) {
@@ -283,87 +294,65 @@ int zdw_multi_set_input_host(zdw_multi *m, const uint8_t *tsv, uint64_t len)
     return first_failure(m, "loading the input");
 }
 
+// One block of the input (ConvertToZDW.cpp:765-894 is the reference's loop over them).  The shards that still hold rows take part as
+// requesters; every shard owns a key range of the block's dictionary.  Under a memory limit the dictionary exchange pauses in the
+// middle: the owners say which occurrence of every string is the first node-wide, the shards walk the reference's arenas over
+// their own first occurrences in row order, and the shard in which the limit trips cuts its part of the block back to that field
+// (stringheap.cpp:74-86, memory.cpp:76-81, ConvertToZDW.cpp:338,404); the owners then drop what was first met beyond it.
 int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
 {
     if (!m || !blk) return ZDW_UNKNOWN_ERROR;
     memset(blk, 0, sizeof *blk);
+    blk->longest_line = m->longest_line;
+    if (m->finished) { blk->is_last_block = 1; return ZDW_OK; }
+    if (m->encoded) return mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_next has not been called for the block before");
     const size_t n = m->sh.size();
     const uint32_t nc = m->ncols;
-    // ---- pass 1 on every shard ----
+    const bool limited = m->mem_limit_mb > 0.0;
+    const size_t first = m->first, last = n - 1;            // the requesters: shards that still hold rows
+    int rc = ZDW_OK;
+
+    // ---- pass 1 on every requester that has none yet for the rows it still holds ----
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
+        s.rc = 0;
+        if (i < first || s.p1_valid) return;
         s.rc = zdw_block_pass1(s.ctx, nullptr, &s.p1);
-        if (s.rc) s.err = zdw_last_error(s.ctx);
+        if (s.rc) s.err = zdw_last_error(s.ctx); else s.p1_valid = true;
     });
-    {
-        uint32_t rows_before = 0;
-        for (size_t i = 0; i < n; ++i) {
-            if (m->sh[i].rc == ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW) {       // the first bad row of the block (ConvertToZDW.cpp:810-812)
-                blk->bad_row = rows_before + m->sh[i].p1.bad_row;
-                return mfail(m, ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW, "Row %u had the problem", blk->bad_row);
-            }
-            if (m->sh[i].rc) break;
-            rows_before += m->sh[i].p1.num_rows;
-        }
-    }
-    int rc = first_failure(m, "pass 1");
+    rc = first_failure(m, "pass 1");
     if (rc) return rc;
-    for (size_t i = 0; i < n; ++i)
+    for (size_t i = first; i <= last; ++i)
         if (!m->sh[i].p1.is_last_block) return mfail(m, ZDW_OUT_OF_MEMORY, "shard %zu does not fit its device as one block: use more devices or the one-GPU path", i);
-
-    // ---- 1. column ranges: all-reduce of [~min, max, seen] with max (~x reverses the unsigned order) ----
-    {
-        std::vector<std::vector<uint64_t>> host(n, std::vector<uint64_t>(3 * (size_t)nc + 1));
-        for (size_t i = 0; i < n; ++i) {
-            Shard &s = m->sh[i];
-            std::vector<uint64_t> mn(nc + 1), mx(nc + 1);
-            std::vector<uint8_t> seen(nc + 1);
-            rc = zdw_shard_export_ranges(s.ctx, mn.data(), mx.data(), seen.data());
-            if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
-            for (uint32_t k = 0; k < nc; ++k) { host[i][k] = ~mn[k]; host[i][nc + k] = mx[k]; host[i][2 * (size_t)nc + k] = seen[k]; }
-        }
-        const size_t cnt = 3 * (size_t)nc;
-        if (cnt && n > 1) {
-            for (size_t i = 0; i < n; ++i) {
-                Shard &s = m->sh[i];
-                size_t cap = s.d_ranges ? cnt * 8 : 0;
-                if (!s.d_ranges) { rc = grow(m, s.device, &s.d_ranges, &cap, cnt * 8); if (rc) return rc; }
-                M_HIP(m, hipSetDevice(s.device));
-                M_HIP(m, hipMemcpyAsync(s.d_ranges, host[i].data(), cnt * 8, hipMemcpyHostToDevice, s.stream));
-            }
-            if (m->use_rccl) {
-                M_NCCL(m, rccl().GroupStart());
-                for (size_t i = 0; i < n; ++i) M_NCCL(m, rccl().AllReduce(m->sh[i].d_ranges, m->sh[i].d_ranges, cnt, ncclUint64, ncclMax, m->sh[i].comm, m->sh[i].stream));
-                M_NCCL(m, rccl().GroupEnd());
-                for (size_t i = 0; i < n; ++i) {
-                    M_HIP(m, hipSetDevice(m->sh[i].device));
-                    M_HIP(m, hipMemcpyAsync(host[i].data(), m->sh[i].d_ranges, cnt * 8, hipMemcpyDeviceToHost, m->sh[i].stream));
-                    M_HIP(m, hipStreamSynchronize(m->sh[i].stream));
-                }
-            } else {
-                for (size_t i = 0; i < n; ++i) { M_HIP(m, hipSetDevice(m->sh[i].device)); M_HIP(m, hipStreamSynchronize(m->sh[i].stream)); }
-                for (size_t k = 0; k < cnt; ++k) {
-                    uint64_t v = 0;
-                    for (size_t i = 0; i < n; ++i) v = std::max(v, host[i][k]);
-                    for (size_t i = 0; i < n; ++i) host[i][k] = v;
-                }
-            }
-        }
-        for (size_t i = 0; i < n; ++i) {
-            std::vector<uint64_t> mn(nc + 1), mx(nc + 1);
-            std::vector<uint8_t> seen(nc + 1);
-            for (uint32_t k = 0; k < nc; ++k) { mn[k] = ~host[i][k]; mx[k] = host[i][nc + k]; seen[k] = host[i][2 * (size_t)nc + k] ? 1 : 0; }
-            rc = zdw_shard_import_ranges(m->sh[i].ctx, mn.data(), mx.data(), seen.data());
-            if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
-        }
+    // the first row with a wrong field count, if any (the shards do not fail on one: the block may end before it)
+    size_t bad_shard = n;
+    uint64_t rows_before_bad = 0;
+    for (size_t i = first; i <= last; ++i) {
+        if (m->sh[i].p1.bad_row) { bad_shard = i; break; }
+        rows_before_bad += m->sh[i].p1.num_rows;
     }
 
-    // ---- 2. dictionary, range-partitioned ----
+    // ---- can the limit trip at all?  (all shards' strings as if none were shared: an upper bound) ----
+    bool maybe = false;
+    if (limited) {
+        uint64_t entries = 0, bytes = 0;
+        uint32_t max_len = 0;
+        for (size_t i = first; i <= last; ++i) {
+            uint64_t e = 0, b = 0;
+            uint32_t ml = 0;
+            rc = zdw_shard_model_counts(m->sh[i].ctx, &e, &b, &ml);
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
+            entries += e; bytes += b; max_len = std::max(max_len, ml);
+        }
+        maybe = zdw_model_upper_bound_mb(entries, bytes, max_len) >= m->mem_limit_mb;
+    }
+
+    // ---- dictionary, range-partitioned: the strings travel to the owners of their key ranges ----
     constexpr uint32_t SAMPLES = 256;
     std::vector<uint64_t> splitters;            // 2 words each, n - 1 of them
     {
         std::vector<std::pair<uint64_t, uint64_t>> all;
-        for (size_t i = 0; i < n; ++i) {
+        for (size_t i = first; i <= last; ++i) {
             uint64_t cnt = 0;
             rc = zdw_shard_sort_uniques(m->sh[i].ctx, &cnt);
             if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
@@ -380,33 +369,158 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
             splitters.push_back(k.first); splitters.push_back(k.second);
         }
     }
-    std::vector<std::vector<uint64_t>> cnt(n, std::vector<uint64_t>(n)), nby(n, std::vector<uint64_t>(n));
+    std::vector<std::vector<uint64_t>> cnt(n, std::vector<uint64_t>(n, 0)), nby(n, std::vector<uint64_t>(n, 0));
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
         s.counts.assign(n, 0); s.nbytes.assign(n, 0);
+        s.d_lens = s.d_bytes = s.d_pos = nullptr;
+        s.rc = 0;
+        if (i < first) return;                  // no rows left here: sends nothing
         s.rc = zdw_shard_partition(s.ctx, (uint32_t)n, splitters.data(), s.counts.data(), s.nbytes.data(), &s.d_lens, &s.d_bytes);
+        if (!s.rc && maybe) s.rc = zdw_shard_positions(s.ctx, s.in_off, &s.d_pos);
         if (s.rc) s.err = zdw_last_error(s.ctx);
     });
     rc = first_failure(m, "partitioning the dictionary");
     if (rc) return rc;
     for (size_t q = 0; q < n; ++q) for (size_t r = 0; r < n; ++r) { cnt[q][r] = m->sh[q].counts[r]; nby[q][r] = m->sh[q].nbytes[r]; }
-    std::vector<uint64_t> rc_cnt(n, 0), rc_by(n, 0);      // what every owner receives
-    for (size_t r = 0; r < n; ++r) for (size_t q = 0; q < n; ++q) { rc_cnt[r] += cnt[q][r]; rc_by[r] += nby[q][r]; }
+    std::vector<uint64_t> rc_cnt(n, 0), rc_by(n, 0), sent(n, 0);      // what every owner receives, what every requester sent
+    for (size_t r = 0; r < n; ++r) for (size_t q = 0; q < n; ++q) { rc_cnt[r] += cnt[q][r]; rc_by[r] += nby[q][r]; sent[q] += cnt[q][r]; }
     {
-        std::vector<const void *> src_l(n), src_b(n);
-        std::vector<void *> dst_l(n), dst_b(n);
+        std::vector<const void *> src_l(n), src_b(n), src_p(n);
+        std::vector<void *> dst_l(n), dst_b(n), dst_p(n);
         for (size_t i = 0; i < n; ++i) {
             Shard &s = m->sh[i];
             rc = grow(m, s.device, &s.d_recv_lens, &s.cap_recv_lens, rc_cnt[i] * 4 + 16); if (rc) return rc;
             rc = grow(m, s.device, &s.d_recv_bytes, &s.cap_recv_bytes, rc_by[i] + 32); if (rc) return rc;
-            src_l[i] = s.d_lens; src_b[i] = s.d_bytes; dst_l[i] = s.d_recv_lens; dst_b[i] = s.d_recv_bytes;
+            if (maybe) { rc = grow(m, s.device, &s.d_recv_pos, &s.cap_recv_pos, rc_cnt[i] * 8 + 16); if (rc) return rc; }
+            src_l[i] = s.d_lens; src_b[i] = s.d_bytes; src_p[i] = s.d_pos; dst_l[i] = s.d_recv_lens; dst_b[i] = s.d_recv_bytes; dst_p[i] = s.d_recv_pos;
         }
         rc = all_to_all_v(m, src_l, dst_l, cnt, 4); if (rc) return rc;
         rc = all_to_all_v(m, src_b, dst_b, nby, 1); if (rc) return rc;
+        if (maybe) { rc = all_to_all_v(m, src_p, dst_p, cnt, 8); if (rc) return rc; }
     }
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
-        s.rc = zdw_owner_build(s.ctx, s.d_recv_lens, s.d_recv_bytes, rc_cnt[i], rc_by[i], &s.slice);
+        s.rc = zdw_owner_import(s.ctx, s.d_recv_lens, s.d_recv_bytes, maybe ? s.d_recv_pos : nullptr, rc_cnt[i], rc_by[i]);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    });
+    rc = first_failure(m, "building a dictionary range");
+    if (rc) return rc;
+    // what travels back to the requesters, owner r -> requester q: cnt[q][r] words in the order q sent its strings (range by range)
+    std::vector<std::vector<uint64_t>> back(n, std::vector<uint64_t>(n));
+    for (size_t r = 0; r < n; ++r) for (size_t q = 0; q < n; ++q) back[r][q] = cnt[q][r];
+    auto words_back = [&](const std::vector<const void *> &src) -> int {
+        std::vector<void *> dst(n);
+        for (size_t i = 0; i < n; ++i) {
+            Shard &s = m->sh[i];
+            const int r2 = grow(m, s.device, &s.d_back, &s.cap_back, sent[i] * 4 + 16);
+            if (r2) return r2;
+            dst[i] = s.d_back;
+        }
+        return all_to_all_v(m, src, dst, back, 4);
+    };
+
+    // ---- where does the block end? ----
+    size_t end_shard = last;                    // the shard that holds the block's last row
+    bool tripped = false;
+    uint32_t trip_row = 0, trip_fields = 0;
+    uint64_t trip_row_start = 0, trip_gpos = ~0ull;
+    if (maybe) {
+        std::vector<const void *> src(n);
+        for_shards(m, [&](size_t i) {
+            Shard &s = m->sh[i];
+            s.d_offsets = nullptr;
+            s.rc = zdw_owner_first_flags(s.ctx, &s.d_offsets);
+            if (s.rc) s.err = zdw_last_error(s.ctx);
+        });
+        rc = first_failure(m, "first occurrences");
+        if (rc) return rc;
+        for (size_t i = 0; i < n; ++i) src[i] = m->sh[i].d_offsets;
+        rc = words_back(src);
+        if (rc) return rc;
+        zdw_model_state st = {0, 0, 0};
+        for (size_t i = first; i <= last && !tripped; ++i) {            // in row order: the state goes from shard to shard
+            Shard &s = m->sh[i];
+            uint32_t found = 0;
+            uint64_t pos = 0;
+            (void)hipSetDevice(s.device);
+            rc = zdw_shard_model_walk(s.ctx, s.d_back, sent[i], m->mem_limit_mb, &st, &found, &trip_row, &trip_fields, &trip_row_start, &pos);
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+            if (found) { tripped = true; end_shard = i; trip_gpos = s.in_off + pos; }
+        }
+    }
+    if (bad_shard < n) {
+        // the reference meets the rows in order: it reports the bad row unless the block ends before it (ConvertToZDW.cpp:336-338)
+        const uint32_t bad0 = m->sh[bad_shard].p1.bad_row - 1;
+        const bool reached = !tripped || bad_shard < end_shard || (bad_shard == end_shard && bad0 <= trip_row);
+        if (reached) {
+            blk->bad_row = (uint32_t)(rows_before_bad + m->sh[bad_shard].p1.bad_row);
+            for (size_t i = first; i <= last; ++i) m->sh[i].p1_valid = false;
+            return mfail(m, ZDW_WRONG_NUM_OF_COLUMNS_ON_A_ROW, "Row %u had the problem", blk->bad_row);
+        }
+    }
+    if (tripped) {
+        Shard &s = m->sh[end_shard];
+        (void)hipSetDevice(s.device);
+        rc = zdw_shard_trim(s.ctx, trip_row, trip_fields, trip_row_start, &s.p1);
+        if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+    }
+    uint64_t rows = 0;
+    for (size_t i = first; i <= end_shard; ++i) rows += m->sh[i].p1.num_rows;
+    if (rows >= 0xFFFFFFFFull) return mfail(m, ZDW_UNKNOWN_ERROR, "more than 2^32-2 rows in one block");
+    if (tripped && rows == 0) return mfail(m, ZDW_OUT_OF_MEMORY, "block limit leaves no room for a single row");      // ConvertToZDW.cpp:824-835
+
+    // ---- 1. column ranges of the block's shards: all-reduce of [~min, max, seen] with max (~x reverses the unsigned order) ----
+    {
+        std::vector<std::vector<uint64_t>> host(n, std::vector<uint64_t>(3 * (size_t)nc + 1, 0));
+        for (size_t i = first; i <= end_shard; ++i) {
+            Shard &s = m->sh[i];
+            std::vector<uint64_t> mn(nc + 1), mx(nc + 1);
+            std::vector<uint8_t> seen(nc + 1);
+            rc = zdw_shard_export_ranges(s.ctx, mn.data(), mx.data(), seen.data());
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+            for (uint32_t k = 0; k < nc; ++k) { host[i][k] = ~mn[k]; host[i][nc + k] = mx[k]; host[i][2 * (size_t)nc + k] = seen[k]; }
+        }
+        const size_t cntw = 3 * (size_t)nc;
+        if (cntw && n > 1) {
+            for (size_t i = 0; i < n; ++i) {
+                Shard &s = m->sh[i];
+                size_t cap = s.d_ranges ? cntw * 8 : 0;
+                if (!s.d_ranges) { rc = grow(m, s.device, &s.d_ranges, &cap, cntw * 8); if (rc) return rc; }
+                M_HIP(m, hipSetDevice(s.device));
+                M_HIP(m, hipMemcpyAsync(s.d_ranges, host[i].data(), cntw * 8, hipMemcpyHostToDevice, s.stream));
+            }
+            if (m->use_rccl) {
+                M_NCCL(m, rccl().GroupStart());
+                for (size_t i = 0; i < n; ++i) M_NCCL(m, rccl().AllReduce(m->sh[i].d_ranges, m->sh[i].d_ranges, cntw, ncclUint64, ncclMax, m->sh[i].comm, m->sh[i].stream));
+                M_NCCL(m, rccl().GroupEnd());
+                for (size_t i = 0; i < n; ++i) {
+                    M_HIP(m, hipSetDevice(m->sh[i].device));
+                    M_HIP(m, hipMemcpyAsync(host[i].data(), m->sh[i].d_ranges, cntw * 8, hipMemcpyDeviceToHost, m->sh[i].stream));
+                    M_HIP(m, hipStreamSynchronize(m->sh[i].stream));
+                }
+            } else {
+                for (size_t i = 0; i < n; ++i) { M_HIP(m, hipSetDevice(m->sh[i].device)); M_HIP(m, hipStreamSynchronize(m->sh[i].stream)); }
+                for (size_t k = 0; k < cntw; ++k) {
+                    uint64_t v = 0;
+                    for (size_t i = 0; i < n; ++i) v = std::max(v, host[i][k]);
+                    for (size_t i = 0; i < n; ++i) host[i][k] = v;
+                }
+            }
+        }
+        for (size_t i = first; i <= end_shard; ++i) {
+            std::vector<uint64_t> mn(nc + 1), mx(nc + 1);
+            std::vector<uint8_t> seen(nc + 1);
+            for (uint32_t k = 0; k < nc; ++k) { mn[k] = ~host[i][k]; mx[k] = host[i][nc + k]; seen[k] = host[i][2 * (size_t)nc + k] ? 1 : 0; }
+            rc = zdw_shard_import_ranges(m->sh[i].ctx, mn.data(), mx.data(), seen.data());
+            if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
+        }
+    }
+
+    // ---- 2. the owners sort and lay out what belongs to the block; every string's offset travels back ----
+    for_shards(m, [&](size_t i) {
+        Shard &s = m->sh[i];
+        s.rc = zdw_owner_finish(s.ctx, tripped ? trip_gpos : ~0ull, &s.slice);
         if (s.rc) s.err = zdw_last_error(s.ctx);
     });
     rc = first_failure(m, "building a dictionary range");
@@ -414,7 +528,7 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     uint64_t dict_size = 1;                     // offset 0 is the origin byte (dictionary.cpp:96)
     std::vector<uint64_t> base(n);
     for (size_t i = 0; i < n; ++i) { base[i] = dict_size; dict_size += m->sh[i].slice; }
-    if (dict_size >= (1ull << 32)) return mfail(m, ZDW_OUT_OF_MEMORY, "the block's dictionary exceeds 2^32 bytes: it has to be split (one-GPU path)");
+    if (dict_size >= (1ull << 32)) return mfail(m, ZDW_OUT_OF_MEMORY, "the block's dictionary exceeds 2^32 bytes: it has to be split (a memory limit does that)");
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
         s.rc = zdw_owner_offsets(s.ctx, base[i], &s.d_offsets);
@@ -423,36 +537,27 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     rc = first_failure(m, "dictionary offsets");
     if (rc) return rc;
     {
-        // the offsets travel back: owner r -> requester q, cnt[q][r] of them, in the order q sent its strings (range by range)
-        std::vector<std::vector<uint64_t>> back(n, std::vector<uint64_t>(n));
-        for (size_t r = 0; r < n; ++r) for (size_t q = 0; q < n; ++q) back[r][q] = cnt[q][r];
         std::vector<const void *> src(n);
-        std::vector<void *> dst(n);
-        for (size_t i = 0; i < n; ++i) {
-            Shard &s = m->sh[i];
-            uint64_t mine = 0;
-            for (size_t r = 0; r < n; ++r) mine += cnt[i][r];
-            rc = grow(m, s.device, &s.d_back, &s.cap_back, mine * 4 + 16); if (rc) return rc;
-            src[i] = s.d_offsets; dst[i] = s.d_back;
-        }
-        rc = all_to_all_v(m, src, dst, back, 4); if (rc) return rc;
+        for (size_t i = 0; i < n; ++i) src[i] = m->sh[i].d_offsets;
+        rc = words_back(src);
+        if (rc) return rc;
     }
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
-        uint64_t mine = 0;
-        for (size_t r = 0; r < n; ++r) mine += cnt[i][r];
-        s.rc = zdw_shard_set_offsets(s.ctx, s.d_back, mine, dict_size, i == 0 ? 1 : 0);
+        // (a shard without rows in this block still owns its key range: its piece of the dictionary section)
+        if (i >= first && i <= end_shard) s.rc = zdw_shard_set_offsets(s.ctx, s.d_back, sent[i], dict_size, i == 0 ? 1 : 0);
+        else s.rc = zdw_owner_section(s.ctx, dict_size, i == 0 ? 1 : 0);
         if (s.rc) s.err = zdw_last_error(s.ctx);
     });
     rc = first_failure(m, "dictionary offsets");
     if (rc) return rc;
 
-    // ---- 3. the row halo and the block's line buffer, chained over the shards in row order ----
+    // ---- 3. the row halo and the line buffer, chained over the block's shards in row order ----
     {
         std::vector<uint64_t> cur(nc + 1, 0);
         bool have = false;
-        uint32_t cap = 16384;
-        for (size_t i = 0; i < n; ++i) {
+        uint32_t cap = m->longest_line;                     // (it never shrinks, across blocks either: getnextrow.cpp:57-65)
+        for (size_t i = first; i <= end_shard; ++i) {
             Shard &s = m->sh[i];
             rc = zdw_shard_set_prev_row(s.ctx, have ? cur.data() : nullptr);
             if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
@@ -471,30 +576,48 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
         m->longest_line = cap;
     }
 
-    // ---- the shards' outputs ----
+    // ---- the shards' rows ----
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
+        s.rc = 0;
+        if (i < first || i > end_shard) return;
         s.rc = zdw_block_pass2_device(s.ctx, nullptr, nullptr);
         if (s.rc) s.err = zdw_last_error(s.ctx);
     });
     rc = first_failure(m, "pass 2");
     if (rc) return rc;
-    uint64_t rows = 0;
-    for (size_t i = 0; i < n; ++i) rows += m->sh[i].p1.num_rows;
-    if (rows >= 0xFFFFFFFFull) return mfail(m, ZDW_UNKNOWN_ERROR, "more than 2^32-2 rows in one block");
     blk->num_rows = (uint32_t)rows;
     blk->longest_line = m->longest_line;
-    blk->is_last_block = 1;
+    blk->is_last_block = tripped ? 0 : 1;
     blk->dict_bytes = dict_size;
+    m->blk_first = first; m->blk_end = end_shard; m->blk_tripped = tripped;
     m->encoded = true;
+    return ZDW_OK;
+}
+
+int zdw_multi_next(zdw_multi *m)
+{
+    if (!m) return ZDW_UNKNOWN_ERROR;
+    if (!m->encoded) return ZDW_OK;
+    m->encoded = false;
+    if (!m->blk_tripped) { m->finished = true; return ZDW_OK; }
+    // the shard that held the block's end goes on behind it; the shards before it are done, those behind it keep their pass 1
+    Shard &s = m->sh[m->blk_end];
+    (void)hipSetDevice(s.device);
+    const int rc = zdw_block_next(s.ctx);
+    if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+    s.p1_valid = false;
+    m->first = m->blk_end;
     return ZDW_OK;
 }
 
 int zdw_multi_stats(zdw_multi *m, uint8_t *col_size, uint64_t *col_base, uint32_t *used)
 {
     if (!m || !m->encoded) return m ? mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_encode has not run") : ZDW_UNKNOWN_ERROR;
-    const int rc = zdw_block_stats(m->sh[0].ctx, col_size, col_base, used);      // the same on every shard (merged ranges, one dictionary size)
-    if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[0].ctx));
+    Shard &s0 = m->sh[m->blk_first];                                             // the same on every shard of the block (merged ranges, one dictionary size)
+    (void)hipSetDevice(s0.device);
+    const int rc = zdw_block_stats(s0.ctx, col_size, col_base, used);
+    if (rc) return mfail(m, rc, "%s", zdw_last_error(s0.ctx));
     return ZDW_OK;
 }
 
@@ -517,7 +640,8 @@ int zdw_multi_rows_write(zdw_multi *m, zdw_write_fn write, void *user, uint64_t 
 {
     if (!m || !m->encoded || !write) return m ? mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_encode has not run") : ZDW_UNKNOWN_ERROR;
     uint64_t total = 0;
-    for (Shard &s : m->sh) {
+    for (size_t i = m->blk_first; i <= m->blk_end; ++i) {
+        Shard &s = m->sh[i];
         uint64_t len = 0;
         (void)hipSetDevice(s.device);
         const int rc = zdw_block_pass2_write(s.ctx, write, user, &len);

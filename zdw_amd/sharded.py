@@ -96,11 +96,12 @@ def chain_prev_rows(last_rows, nrows):
 FIRST_ROW_CAP = 16384
 
 
-def compose_line_caps(tables):
+def compose_line_caps(tables, start=FIRST_ROW_CAP):
     """tables[i][k] = the reference's line buffer after shard i's rows when it held 16384 << k before them
     (capi.Encoder.line_caps).  Returns the buffer after shards 0..i for every i: m_LongestLine of the block is the
-    last entry (the buffer starts at 16384 and only ever doubles, getnextrow.cpp:57-65)."""
-    out, cap = [], FIRST_ROW_CAP
+    last entry (the buffer starts at 16384 -- `start`: what the blocks before left -- and only ever doubles,
+    getnextrow.cpp:57-65)."""
+    out, cap = [], start
     for t in tables:
         k = max(0, (int(cap) // FIRST_ROW_CAP).bit_length() - 1)
         cap = int(t[min(k, len(t) - 1)])
@@ -470,7 +471,7 @@ def allgather_uniques(lens, byts, rank, world, group=None):
     return concat_uniques(parts, skip=rank)
 
 
-def exchange_prev_row(last_row, nrows, rank, world, device, group=None, line_caps=None):
+def exchange_prev_row(last_row, nrows, rank, world, device, group=None, line_caps=None, start_cap=FIRST_ROW_CAP, first=0):
     """Row halo: every rank learns the stored values that precede its first row.  With `line_caps` (this rank's
     capi.Encoder.line_caps()) the same all-gather carries the tables and the block's m_LongestLine is returned too."""
     import torch.distributed as dist
@@ -488,10 +489,11 @@ def exchange_prev_row(last_row, nrows, rank, world, device, group=None, line_cap
     allr = [t.cpu() for t in allr]
     rows = [ordered_i64_to_u64(t[1:ncols + 1]) for t in allr]
     counts = [int(t[0].item()) for t in allr]
-    prev = chain_prev_rows(rows, counts)[rank]
+    # (`first`: the ranks before it hold none of the block's rows and say nothing about the row before its first one)
+    prev = ([None] * first + chain_prev_rows(rows[first:], counts[first:]))[rank]
     if line_caps is None:
         return prev
-    return prev, compose_line_caps([[int(x) for x in t[ncols + 1:].tolist()] for t in allr])[-1]
+    return prev, compose_line_caps([[int(x) for x in t[ncols + 1:].tolist()] for t in allr], start=start_cap)[-1]
 
 
 def encode_shard_dist(enc, rank, world, group=None, fetch=False, merge=None):
@@ -533,3 +535,243 @@ def encode_shard_dist(enc, rank, world, group=None, fetch=False, merge=None):
     enc.stats()
     _, rlen = enc.pass2_device()
     return p1.num_rows, dlen, rlen
+
+
+# ------------------------------------------------------------------------------------------------
+# Several blocks of a row-sharded input: where the reference's memory limit ends a block (SURVEY.md 8e "Invariance
+# requirement", Q9; stringheap.cpp:74-86, memory.cpp:76-81, ConvertToZDW.cpp:338,404,765-894).  The decision is taken on the
+# node-wide dictionary: the dictionary exchange pauses once the owners hold every string with the position of its first
+# occurrence; they tell the requesters which of their occurrences are the first node-wide; the ranks walk the reference's arenas
+# over their own first occurrences in row order (the state goes from rank to rank); the rank in which the limit trips cuts its
+# part of the block back to that field, the ranks behind it keep their rows for the next block, and the owners drop what was
+# first met beyond the end before they sort.  zdw_multi_encode (csrc/zdw_multi.hip) is the same protocol inside one process.
+# ------------------------------------------------------------------------------------------------
+IDENTITY_CAPS = [FIRST_ROW_CAP << k for k in range(18)]          # the line-buffer table of a rank without rows in the block
+
+
+class EncoderPort:
+    """What the block driver needs from a shard, in torch tensors (the collectives move those): a thin adapter over
+    capi.Encoder (created with track_first_occurrence and defer_bad_row).  tests/ has a pure-Python stand-in with the same
+    methods for the CPU (gloo) test of the protocol."""
+
+    def __init__(self, enc, device):
+        self.enc, self.device, self.ncols = enc, device, enc.ncols
+        self._sent = 0
+
+    def pass1(self):
+        rc, p1 = self.enc.pass1()
+        return rc, p1.num_rows, p1.bad_row, p1.is_last_block
+
+    def model_counts(self):
+        return self.enc.model_counts()
+
+    def export_ranges(self):
+        return self.enc.export_ranges()
+
+    def import_ranges(self, mn, mx, seen):
+        self.enc.import_ranges(mn, mx, seen)
+
+    def sample_keys(self, nsamples):
+        self.enc.sort_uniques()
+        return self.enc.sample_keys(nsamples)
+
+    def partition(self, splitters, base, with_pos):
+        counts, nb, d_lens, d_bytes = self.enc.partition(splitters)
+        self._sent = sum(counts)
+        lens = _wrap(d_lens, sum(counts) * 4, "<i4", self.device).clone()
+        byts = _wrap(d_bytes, sum(nb), "|u1", self.device).clone()
+        pos = None
+        if with_pos:
+            pos = _wrap(self.enc.positions(base), sum(counts) * 8, "<i8", self.device).clone() if sum(counts) else torch.empty(0, dtype=torch.int64, device=self.device)
+        _torch_done()
+        return counts, nb, lens, byts, pos
+
+    def owner_import(self, lens, byts, pos):
+        _torch_done()
+        self._keep = (lens, byts, pos)
+        self._received = lens.numel()
+        self.enc.owner_import(lens.data_ptr() if lens.numel() else 0, byts.data_ptr() if byts.numel() else 0,
+                              pos.data_ptr() if pos is not None and pos.numel() else (1 if pos is not None else 0), lens.numel(), byts.numel())
+
+    def owner_first_flags(self):
+        t = _wrap(self.enc.owner_first_flags(), self._received * 4, "<i4", self.device).clone()
+        _torch_done()
+        return t
+
+    def model_walk(self, flags, limit_mb, state):
+        _torch_done()
+        return self.enc.model_walk(flags.data_ptr() if flags.numel() else 0, flags.numel(), limit_mb, state)
+
+    def trim(self, row, fields, row_start):
+        return self.enc.trim(row, fields, row_start).num_rows
+
+    def owner_finish(self, last_pos):
+        return self.enc.owner_finish(last_pos)
+
+    def owner_offsets(self, base):
+        t = _wrap(self.enc.owner_offsets(base), self._received * 4, "<i4", self.device).clone()
+        _torch_done()
+        return t
+
+    def set_offsets(self, offs, dict_size, first_range):
+        _torch_done()
+        self.enc.set_offsets(offs.data_ptr() if offs.numel() else 0, offs.numel(), dict_size, first_range)
+
+    def owner_section(self, dict_size, first_range):
+        self.enc.owner_section(dict_size, first_range)
+
+    def last_row(self):
+        return self.enc.last_row()
+
+    def line_caps(self):
+        return self.enc.line_caps()
+
+    def set_prev_row(self, prev):
+        self.enc.set_prev_row(prev)
+
+    def dict_piece(self):
+        return self.enc.dict_section()[0]
+
+    def stats(self):
+        return self.enc.stats()
+
+    def rows(self):
+        return self.enc.pass2()
+
+    def next_block(self):
+        self.enc.next_block()
+
+
+def broadcast_i64(vals, src, device, group=None):
+    """rank `src`'s list of int64 on every rank (the others pass a list of the same length)"""
+    import torch.distributed as dist
+    t = torch.tensor([int(v) for v in vals], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=src, group=group)
+    return [int(x) for x in t.cpu().tolist()]
+
+
+def encode_blocks_dist(port, rank, world, nbytes, mem_limit_mb, group=None, device="cpu"):
+    """All blocks of an input whose rows lie on the ranks in rank order (rank r holds `nbytes` bytes of it: whole rows).
+    Returns this rank's share of every block: [dict(num_rows=block's rows, longest_line, is_last, dict_piece, col_size,
+    col_base, rows)] -- the block's dictionary section is the ranks' pieces in rank order, its rows are the ranks' rows in rank
+    order (a rank without rows in a block contributes b"")."""
+    from . import capi
+    sizes = [a[0] for a in allgather_i64([nbytes], device, group=group)]
+    bases = [sum(sizes[:r]) for r in range(world)]
+    first, have_p1, longest = 0, False, FIRST_ROW_CAP
+    my_rows = my_bad = 0
+    out = []
+    while True:
+        # ---- pass 1 where this rank still holds rows and has none ----
+        rc = 0
+        if rank >= first and not have_p1:
+            rc, my_rows, my_bad, is_last = port.pass1()
+            if rc == 0 and not is_last:
+                rc = capi.OUT_OF_MEMORY                       # the rank's rows do not fit its device as one block
+            have_p1 = rc == 0
+        cnts = port.model_counts() if (rank >= first and rc == 0 and mem_limit_mb) else (0, 0, 0)
+        info = allgather_i64([rc, my_rows if rank >= first else 0, my_bad if rank >= first else 0] + list(cnts), device, group=group)
+        if any(a[0] for a in info):
+            raise capi.ZdwError(rc or max(a[0] for a in info), "pass 1 failed on a rank")
+        rows_of = [a[1] for a in info]
+        bad_rank = next((r for r in range(first, world) if info[r][2]), None)
+        maybe = bool(mem_limit_mb) and capi.model_upper_bound_mb(sum(a[3] for a in info), sum(a[4] for a in info), max(a[5] for a in info)) >= mem_limit_mb
+
+        # ---- the strings travel to the owners of their key ranges ----
+        mine = _guarded(lambda: port.sample_keys(SAMPLES_PER_SHARD) if rank >= first else [], device, group, "sampling the dictionary")
+        flat = [_u64_to_i64(w) for k in mine for w in k] + [0] * (2 * SAMPLES_PER_SHARD - 2 * len(mine))
+        allk = allgather_i64([len(mine)] + flat, device, group=group)
+        samples = [(_i64_to_u64(a[1 + 2 * i]), _i64_to_u64(a[2 + 2 * i])) for a in allk for i in range(a[0])]
+        splitters = pick_splitters(samples, world)
+        if rank >= first:
+            counts, nb, lens, byts, pos = _guarded(lambda: port.partition(splitters, bases[rank], maybe), device, group, "partitioning the dictionary")
+        else:
+            _guarded(lambda: None, device, group, "partitioning the dictionary")
+            counts, nb = [0] * world, [0] * world
+            lens, byts = torch.empty(0, dtype=torch.int32, device=device), torch.empty(0, dtype=torch.uint8, device=device)
+            pos = torch.empty(0, dtype=torch.int64, device=device) if maybe else None
+        rcounts, rbytes = exchange_counts(counts, device, group, nb)
+        got_lens = alltoallv(lens, counts, rcounts, group=group)
+        got_byts = alltoallv(byts, nb, rbytes, group=group)
+        got_pos = alltoallv(pos, counts, rcounts, group=group) if maybe else None
+        _guarded(lambda: port.owner_import(got_lens, got_byts, got_pos), device, group, "building a dictionary range")
+
+        # ---- where does the block end? ----
+        end, trip = world - 1, None
+        if maybe:
+            flags = _guarded(port.owner_first_flags, device, group, "first occurrences")
+            my_flags = alltoallv(flags, rcounts, counts, group=group)
+            state = (0, 0, 0)
+            for i in range(first, world):                      # in row order: the state goes from rank to rank
+                msg = [0] * 9
+                if rank == i:
+                    try:
+                        state, hit = port.model_walk(my_flags, mem_limit_mb, state)
+                        msg = [0] + list(state) + ([1] + list(hit) if hit else [0, 0, 0, 0, 0])
+                    except capi.ZdwError as e:
+                        msg[0] = e.code or 20
+                msg = broadcast_i64(msg, i, device, group=group)
+                if msg[0]:
+                    raise capi.ZdwError(msg[0], "the block-limit walk failed on rank %d" % i)
+                state = tuple(msg[1:4])
+                if msg[4]:
+                    trip = (msg[5], msg[6], msg[7], bases[i] + msg[8])      # row, fields, row_start (in rank i's image), position in the input
+                    end = i
+                    break
+        if bad_rank is not None:
+            # the reference meets the rows in order: it reports the bad row unless the block ends before it (ConvertToZDW.cpp:336-338)
+            bad0 = info[bad_rank][2] - 1
+            if trip is None or bad_rank < end or (bad_rank == end and bad0 <= trip[0]):
+                e = capi.ZdwError(capi.WRONG_NUM_OF_COLUMNS_ON_A_ROW, "Row %u had the problem" % (sum(rows_of[first:bad_rank]) + info[bad_rank][2]))
+                e.bad_row = sum(rows_of[first:bad_rank]) + info[bad_rank][2]
+                raise e
+        if trip is not None:
+            kept = _guarded(lambda: port.trim(trip[0], trip[1], trip[2]) if rank == end else 0, device, group, "cutting the block back")
+            rows_of[end] = broadcast_i64([kept], end, device, group=group)[0]
+            if rank == end:
+                my_rows = rows_of[end]
+        in_block = first <= rank <= end
+        block_rows = sum(rows_of[first:end + 1])
+        if trip is not None and block_rows == 0:
+            raise capi.ZdwError(capi.OUT_OF_MEMORY, "block limit leaves no room for a single row")
+
+        # ---- column ranges of the block's ranks ----
+        ncols = port.ncols
+        mine_r = port.export_ranges() if in_block else ([NO_MIN] * ncols, [0] * ncols, [0] * ncols)
+        mn, mx, seen = allreduce_ranges(*mine_r, device=device, group=group)
+        if in_block:
+            port.import_ranges(mn, mx, seen)
+
+        # ---- the owners sort and lay out what belongs to the block; every string's offset travels back ----
+        rc_own, slice_bytes = 0, 0
+        try:
+            slice_bytes = port.owner_finish(trip[3] if trip is not None else None)
+        except capi.ZdwError as e:
+            rc_own = e.code or 20
+        gathered = allgather_i64([slice_bytes, rc_own], device, group=group)
+        if any(a[1] for a in gathered):
+            raise capi.ZdwError(rc_own or max(a[1] for a in gathered), "building a dictionary range failed on a rank")
+        range_base, total = range_bases([a[0] for a in gathered])
+        if total >= 1 << 32:
+            raise capi.ZdwError(capi.OUT_OF_MEMORY, "the block's dictionary exceeds 2^32 bytes")
+        offs = _guarded(lambda: port.owner_offsets(range_base[rank]), device, group, "dictionary offsets")
+        back = alltoallv(offs, rcounts, counts, group=group)
+        _guarded(lambda: port.set_offsets(back, total, rank == 0) if in_block else port.owner_section(total, rank == 0), device, group, "dictionary offsets")
+
+        # ---- row halo and line buffer over the block's ranks ----
+        last, caps = _guarded(lambda: (port.last_row(), port.line_caps()) if in_block else ([0] * ncols, IDENTITY_CAPS), device, group, "the row halo")
+        prev, longest = exchange_prev_row(last, my_rows if in_block else 0, rank, world, device, group=group, line_caps=caps, start_cap=longest,
+                                          first=first)
+        if in_block:
+            port.set_prev_row(prev)
+        piece = port.dict_piece()
+        cs, cb = port.stats() if in_block else (b"", [])
+        rows = port.rows() if in_block else b""
+        out.append(dict(num_rows=block_rows, longest_line=longest, is_last=trip is None, dict_piece=piece, col_size=cs, col_base=cb, rows=rows,
+                        my_rows=my_rows if in_block else 0))
+        if trip is None:
+            return out
+        if rank == end:
+            port.next_block()
+            have_p1 = False
+        first = end
