@@ -768,7 +768,7 @@ def encode_blocks_dist(port, rank, world, nbytes, mem_limit_mb, group=None, devi
         cs, cb = port.stats() if in_block else (b"", [])
         rows = port.rows() if in_block else b""
         out.append(dict(num_rows=block_rows, longest_line=longest, is_last=trip is None, dict_piece=piece, col_size=cs, col_base=cb, rows=rows,
-                        my_rows=my_rows if in_block else 0))
+                        my_rows=my_rows if in_block else 0, partial_fields=trip[1] if trip is not None else 0))
         if trip is None:
             return out
         if rank == end:
