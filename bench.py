@@ -9,7 +9,8 @@ weak scaling, every rank holds its own 10 GB row range of ONE ZDW block; RCCL ca
 range all-reduce, the dictionary merge (range-partitioned: two all-to-all-v of unique strings / offsets,
 small all-gathers of samples and range sizes) and the previous-row halo.
 
-After the timed region (never inside it) rank 0 also: verifies the last step's outputs ("verified": row count,
+After the timed region (never inside it) rank 0 also: verifies the last step's outputs ("verified": the bytes the compiled
+reference wrote for the CPU baseline's sample -- the head of the same table -- equal to the HIP encode of those rows; row count,
 dictionary header + strict strcmp order of every entry, a walk of the first rows, and byte equality of the
 dictionary / column stats / row section with the same table encoded as THREE row shards, whose positions all stay
 below 2^32); times the reference encoder on the host ("cpu_baseline"); and times the shipped convertDWfile
@@ -39,6 +40,7 @@ def cpu_baseline(desc, sample, cores_note=1):
     """Times the reference encoder (oracle/_ref, kind 'reference') or the C oracle ('port') on `sample`."""
     from oracle import oracle
     mb = len(sample) / 1e6
+    ref_out = None
     if oracle.have_ref():
         d = tempfile.mkdtemp(prefix="zdwbase_")
         try:
@@ -52,6 +54,9 @@ def cpu_baseline(desc, sample, cores_note=1):
             p = subprocess.run([oracle.REF_BIN, "-q", os.path.join(d, "s.sql")], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             dt = time.perf_counter() - t0
             out_bytes = os.path.getsize(os.path.join(d, "s.zdw.gz")) if p.returncode == 0 else 0
+            if p.returncode == 0:
+                with open(os.path.join(d, "s.zdw.gz"), "rb") as f:
+                    ref_out = f.read()              # (the compressor child is `cat`: the raw stream) -- compared with the HIP encode of the same rows
             kind = "reference"
         finally:
             shutil.rmtree(d, ignore_errors=True)
@@ -62,8 +67,9 @@ def cpu_baseline(desc, sample, cores_note=1):
         rc, out, _ = oracle.encode(desc, sample)
         dt = time.perf_counter() - t0
         out_bytes = len(out) if rc == 0 else 0
+        ref_out = out if rc == 0 else None
         kind = "port"
-    return {"value": round(mb / dt, 2), "unit": "MB/s", "cores": 1, "kind": kind,
+    return {"_out": ref_out, "value": round(mb / dt, 2), "unit": "MB/s", "cores": 1, "kind": kind,
             "sample": "first %.1f MB (whole rows) of the same synthetic table, compressor child replaced by cat, %.1f s, ratio %.2f"
                       % (mb, dt, len(sample) / max(1, out_bytes))}
 
@@ -152,6 +158,24 @@ def verify_outputs(torch, capi, sharded, table, buf, nbytes, enc, nrows, p1, dic
     return {"rows": int(nrows), "dict_entries": int(p1.dict_entries), "rows_walked": walked, "dict_sha256": h_dict[:16], "rows_sha256": h_rows[:16],
             "checks": "row count; dictionary size header, entry count and strict strcmp order of every entry; walk of the first rows; "
                       "dictionary, column stats and row bytes equal to the same table encoded as 3 row shards"}
+
+
+def reference_prefix_equal(capi, table, sample, ref_file, device):
+    """The bytes the CPU baseline wrote for `sample` (the head of the benchmark's table) against the HIP encode of the same rows:
+    the whole block -- header, dictionary, column stats, rows -- byte for byte (the file header is the host shim's)."""
+    import hashlib
+    names = [ln.split(b"\t")[0] for ln in table.desc.splitlines() if ln]
+    header_len = 2 + 4 + sum(len(n) + 1 for n in names) + 1 + 3 * len(names)        # version, metadata length, names, types, char sizes
+    enc = capi.Encoder(table.types, device=device)
+    try:
+        enc.set_input_host(sample)
+        rc, blk, p1 = enc.encode_block()
+        got = blk.tobytes() if rc == 0 and blk is not None else b""
+    finally:
+        enc.close()
+    want = ref_file[header_len:]
+    return {"equal": got == want, "bytes_compared": len(want), "hip_sha256": hashlib.sha256(got).hexdigest()[:16],
+            "reference_sha256": hashlib.sha256(want).hexdigest()[:16], "rows": int(p1.num_rows)}
 
 
 def e2e_cli(torch, table, gb=2.0):
@@ -473,6 +497,19 @@ def main():
             cut = head.rfind(b"\n") + 1
             res["cpu_baseline"] = cpu_baseline(table.desc, head[:cut])
             res["cpu_baseline"]["host_cores"] = os.cpu_count()
+            # ... and its bytes against the HIP path's for the same rows: reference bytes at bench scale (checker only; outside the timed region)
+            ref_file = res["cpu_baseline"].pop("_out", None)
+            if ref_file is not None and not args.no_verify:
+                try:
+                    cmp_ = reference_prefix_equal(capi, table, head[:cut], ref_file, local)
+                    res.setdefault("verify", {})["reference_prefix"] = cmp_
+                    res["verify"]["reference_prefix_equal"] = cmp_["equal"]
+                    if not cmp_["equal"]:
+                        res["verified"] = False
+                except Exception as e:  # noqa: BLE001
+                    res.setdefault("verify", {})["reference_prefix"] = {"error": repr(e)[:200]}
+                    res["verified"] = False
+            del ref_file
         else:
             res["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 1, "kind": "reference", "sample": "skipped (--no-cpu, or N > 1: measured at N = 1)"}
         if not args.no_e2e and not args.pass1_only and world == 1:

@@ -37,6 +37,14 @@
 
 namespace zdw {
 
+// Ablation hooks of the profiling tools (work removed from the kernel: NOT a valid encode) exist only in a build made with
+// -DZDW_EXPERIMENTS (tools/ build their own copy of the library); the shipped kernel has none of them.
+#ifdef ZDW_EXPERIMENTS
+#define P1_ABLATE(a, bit) (((a).debug_skip & (bit)) != 0u)
+#else
+#define P1_ABLATE(a, bit) false
+#endif
+
 constexpr uint32_t WROUND = 1024;                 // bytes per load step (a chunk): one 16-byte load per lane
 constexpr uint32_t ROUND = 2 * WROUND;            // bytes per tokeniser round: chunks A and B
 constexpr uint32_t DQ_CHUNK = 256;                // deferred-queue entries a wave takes per atomic
@@ -458,7 +466,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             ws.col_cur += cnt;
         }
         in_block = row < a.row_limit;
-        is_field = !dead & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) & !(a.debug_skip & 1u);
+        is_field = !dead & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) & !P1_ABLATE(a, 1u);
         ws.prev_nl = false;
         ws.last_e = e_last; ws.last_ord = d_last >> 24;
         ws.far = false;
@@ -541,7 +549,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     }
     in_block = row < a.row_limit;
     is_field = !dead & !sentinel & !blank & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) &
-               !(a.debug_skip & 1u);
+               !P1_ABLATE(a, 1u);
     // state for the next call
     ws.row_cur += popc64(rm);
     if (SKIP) ws.col_cur = nlm ? incl_all - incl_at_last_nl : ws.col_cur + incl_all;
@@ -566,7 +574,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // tables of mostly empty fields: the record matrix was zeroed beforehand (one streaming write instead of a scattered 4- or
     // 8-byte store per empty field), so an empty field -- no record but zero, no range, no string (ConvertToZDW.cpp:340-341) -- is done
     // (SKIP: the empty fields in front of mine have no descriptor of their own; the record matrix was zeroed before the launch)
-    if (a.rec_zeroed) is_field = is_field & (raw_len != 0);
+    constexpr bool MAY_BE_ZEROED = SKIP || QCAP == QCAP_LARGE;      // (only the forms for tables of mostly empty fields run on a zeroed matrix: launch_pass1)
+    if (MAY_BE_ZEROED && a.rec_zeroed) is_field = is_field & (raw_len != 0);
     // a field that begins further back than a descriptor can say (the visit moved its base past its start): the general form
     uint64_t abs_start = ws.vbase + fs;
     if (SKIP && __ballot(far_me)) {
@@ -580,7 +589,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     uint32_t meta = 0;
     if (is_field && t.cols_in_lds) meta = lds_u32(t.meta + 4u * col);
     const uint32_t kind = meta & 3u;
-    bool slow = is_field && (!t.cols_in_lds || (!TRIM && a.trim != 0) || fs < ws.ring_lo || far_me);
+    bool slow = is_field && (!t.cols_in_lds || fs < ws.ring_lo || far_me);      // (a.trim == TRIM: launch_pass1 picks the kernel by it)
     const uint32_t ra = ws.bytes + (fs & (BYTE_RING - 1u));
     if (TRIM) {
         if (is_field && !slow && len) {
@@ -619,7 +628,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 c0 = u64_of(fw[0], fw[1]) & lds_u64(lo); c1 = u64_of(fw[2], fw[3]) & lds_u64(lo + 8); c2 = u64_of(fw[4], fw[5]) & lds_u64(lo + 16);
                 acc = nh24(c0, c1, c2);
                 i = hash_place(acc) & a.slot_mask;
-                pending = !(a.debug_skip & 2u);
+                pending = !P1_ABLATE(a, 2u);
             }
             // uniform over the text lanes (runs while any of them is undecided): ids are handed out at loop level
             for (uint32_t probe = 0; probe < 4; ++probe) {
@@ -648,7 +657,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 }
             }
             if (pending) slow = true;
-            if (!slow && in_block && !(a.debug_skip & 4u)) {
+            if (!slow && in_block && !P1_ABLATE(a, 4u)) {
                 *reinterpret_cast<uint32_t *>(recp) = id;
                 if (SKIP && a.nz && id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
             }
@@ -660,7 +669,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     bool fn = fast && kind != K_TEXT;
     if (fn && kind == K_INT && len > 16u) { slow = true; fn = false; }
     if (fn && len == 0u) {                 // an empty numeric field is a zero record and touches no range (sparse tables: most of them)
-        if (in_block && !(a.debug_skip & 4u)) *reinterpret_cast<uint64_t *>(recp) = 0ull;
+        if (in_block && !P1_ABLATE(a, 4u)) *reinterpret_cast<uint64_t *>(recp) = 0ull;
         fn = false;
     }
     if (__ballot(fn)) {
@@ -696,7 +705,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (!ok) slow = true;
             else {
                 if (v_range > 0) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
-                if (in_block && !(a.debug_skip & 4u)) {
+                if (in_block && !P1_ABLATE(a, 4u)) {
                     *reinterpret_cast<uint64_t *>(recp) = v_rec;
                     if (SKIP && a.nz && v_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
                 }
@@ -740,7 +749,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     }
     return popc64(__ballot(is_new));
 }
-template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP>
+// FOLD: no row scan has run -- the waves take the spans in order (a ticket each), count the rows that start in theirs and learn their
+// first row's number from the spans before (Pass1Args.span_state).
+template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP, bool FOLD>
 __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass1Args a)
 {
     constexpr uint32_t QM = QCAP * 4u - 1u;
@@ -750,9 +761,11 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     const uint32_t wv = uniform32(threadIdx.x >> 6);
     const uint32_t wave_id = blockIdx.x * P1_WPB + wv, wave_count = gridDim.x * P1_WPB;
     const uint32_t lane = lane_id();
-    const P1Lds L = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, QCAP);
+    // (the kernel that queues its general-form fields is only launched with the column tables in LDS: zdw_capi.hip)
+    const bool cols_in_lds = DEFER ? true : a.use_lds_ranges != 0;
+    const P1Lds L = p1_layout(a.ncols, a.nnum, cols_in_lds, QCAP);
     ColTables t;
-    t.meta = L.meta; t.mn = L.mn; t.mx = L.mx; t.seen = L.seen; t.cols_in_lds = a.use_lds_ranges != 0;
+    t.meta = L.meta; t.mn = L.mn; t.mx = L.mx; t.seen = L.seen; t.cols_in_lds = cols_in_lds;
 
     // workgroup tables
     for (uint32_t i = threadIdx.x; i < LUT_ROWS * 8u; i += 64 * P1_WPB) {
@@ -784,7 +797,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st; d.track_first = a.track_first;
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
-    const bool fold = a.span_state != nullptr;      // no row scan has run: spans by ticket, their rows counted here
+    constexpr bool fold = FOLD;                     // no row scan has run: spans by ticket, their rows counted here
     for (uint32_t si = wave_id;; si += wave_count) {
         if (uniform32(*reinterpret_cast<volatile const uint32_t *>(&a.st->overflow))) break;      // an ordinary (cached) read: a stale 0 only delays the exit
         if (new_entries >= 128) {        // publish this wave's inserts in bulk; stop everybody once the table is half full
@@ -1065,7 +1078,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
             __builtin_amdgcn_wave_barrier();      // one wave per worker: LDS operations of a wave execute in order
             while (!ws.done && ws.q_count > keep) {
                 const uint32_t cnt = ws.q_count < 64u ? ws.q_count : 64u;
-                if (a.debug_skip & 32u) { if (near_end && ws.q_count <= 64u) ws.done = true; }      // profiling only: the tokeniser alone
+                if (P1_ABLATE(a, 32u)) { if (near_end && ws.q_count <= 64u) ws.done = true; }      // profiling only: the tokeniser alone
                 else new_entries += consume<DEFER, TRIM, QCAP, SKIP>(a, t, d, L, ws, cnt, lane);
                 ws.q_head += cnt;
                 ws.q_count -= cnt;
@@ -1180,12 +1193,11 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     typedef void (*P1Fn)(const Pass1Args);
-    static const P1Fn fns[2][2][3] = {
-        {{k_pass1<false, false, QCAP_SMALL, false>, k_pass1<false, false, QCAP_LARGE, false>, k_pass1<false, false, QCAP_SMALL, true>},
-         {k_pass1<false, true, QCAP_SMALL, false>, k_pass1<false, true, QCAP_LARGE, false>, k_pass1<false, true, QCAP_SMALL, true>}},
-        {{k_pass1<true, false, QCAP_SMALL, false>, k_pass1<true, false, QCAP_LARGE, false>, k_pass1<true, false, QCAP_SMALL, true>},
-         {k_pass1<true, true, QCAP_SMALL, false>, k_pass1<true, true, QCAP_LARGE, false>, k_pass1<true, true, QCAP_SMALL, true>}}};
-    const P1Fn kfn = fns[defer][trim][mode];
+#define P1_MODES(D, T, F) {k_pass1<D, T, QCAP_SMALL, false, F>, k_pass1<D, T, QCAP_LARGE, false, F>, k_pass1<D, T, QCAP_SMALL, true, F>}
+    static const P1Fn fns[2][2][2][3] = {{{P1_MODES(false, false, false), P1_MODES(false, true, false)}, {P1_MODES(true, false, false), P1_MODES(true, true, false)}},
+                                         {{P1_MODES(false, false, true), P1_MODES(false, true, true)}, {P1_MODES(true, false, true), P1_MODES(true, true, true)}}};
+#undef P1_MODES
+    const P1Fn kfn = fns[a.span_state != nullptr][defer][trim][mode];
     const void *fn = (const void *)kfn;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
     const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules

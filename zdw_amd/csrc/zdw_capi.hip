@@ -1479,7 +1479,9 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             a.uniq_pos = c->uniq_pos.as<uint64_t>(); a.uniq_len = c->uniq_len.as<uint32_t>(); a.id_cap = c->id_cap;
             a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 8 * 5, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
+#ifdef ZDW_EXPERIMENTS
             if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
+#endif
             // the memory-limit model asks in which order the strings are first met: every occurrence takes part in a minimum
             a.track_first = (c->model_max_slots || c->track_first_opt) ? 1u : 0u;
             if (const char *e = getenv("ZDW_P1_TRACK_FIRST")) a.track_first = atoi(e) != 0;      // tests

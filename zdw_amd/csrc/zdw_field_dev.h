@@ -110,7 +110,7 @@ __device__ inline void process_field_general(const Pass1Args &a, const ColTables
         if (len) mark_seen(a, t, col);                                // empty fields are skipped (:340-341)
     }
     // the table insert is wave-level (ids are handed out by ballot): all calling lanes pass through it
-    const bool want = kind == K_TEXT && len && !(a.debug_skip & 2u);
+    const bool want = kind == K_TEXT && len;
     if (__ballot(want)) {
         uint32_t id = 0;
         const uint64_t wm = __ballot(want);

@@ -67,7 +67,9 @@ struct Pass1Args {
     uint32_t skip_empty;                  // tabs that directly follow a boundary (empty fields) get no descriptor (tables of mostly empty fields)
     uint32_t rebase_at;                   // relative position at which a visit moves its base (2^23: a descriptor holds 24 bits of position; tests lower it)
     uint64_t *dq; uint32_t dq_cap;        // deferred fields (two words each: position | column << 40, length | row << 32); dq == nullptr: none, one kernel does everything
-    uint32_t debug_skip;                  // profiling only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary
+#ifdef ZDW_EXPERIMENTS
+    uint32_t debug_skip;                  // profiling builds only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary, 4 no record stores, 32 the tokeniser alone
+#endif
     uint32_t rec_zeroed;                  // 1: rec was zeroed before the launch: empty fields leave nothing to do
     uint32_t *nz; uint32_t nz_stride;     // not null (with rec_zeroed, instead of a zeroed rec): a bit per field, bit (column & 31) of word nz[row * nz_stride + column / 32], set where a non-zero record was
                                           // written; what rec holds elsewhere means nothing (tables of mostly empty fields: pass 2 goes by this map)
