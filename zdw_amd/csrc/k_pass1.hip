@@ -33,6 +33,7 @@
 #include "zdw_dict_dev.h"
 #include "zdw_field_dev.h"
 
+#include <cstddef>
 #include <cstdlib>
 
 namespace zdw {
@@ -44,6 +45,21 @@ namespace zdw {
 #else
 #define P1_ABLATE(a, bit) false
 #endif
+
+// Arguments the kernel needs once per span visit or on rare paths are NOT kept in scalar registers for its whole run (the kernel holds
+// ~170 wave-uniform values against 102 SGPRs; what does not fit is spilled into lanes of a vector register and read back with
+// v_readlane + wait states -- and the allocator picked the hash table's pointers for that).  They are read from the kernel-argument
+// segment where they are used: the pointer passes through an empty asm statement, so the compiler cannot hoist the load to the
+// kernel's entry.  (The kernel's first parameter is the Pass1Args: offset 0 of the segment.)
+template <typename T>
+__device__ __forceinline__ T kernarg_at(uint32_t off)
+{
+    typedef __attribute__((address_space(4))) const uint8_t *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *reinterpret_cast<__attribute__((address_space(4))) const T *>(ka + off);
+}
+#define COLD(field) kernarg_at<decltype(Pass1Args::field)>((uint32_t)offsetof(Pass1Args, field))
 
 constexpr uint32_t WROUND = 1024;                 // bytes per load step (a chunk): one 16-byte load per lane
 constexpr uint32_t ROUND = 2 * WROUND;            // bytes per tokeniser round: chunks A and B
@@ -425,8 +441,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             bool esc = false;
             if (odd) {
                 const uint64_t p = ws.vbase + e_pos;
-                const bool nl = a.in[p] == '\n';
-                esc = (backslashes_before(a.in, a.lo, p) & 1u) != 0;
+                const uint8_t *img = COLD(in);
+                const bool nl = img[p] == '\n';
+                esc = (backslashes_before(img, COLD(lo), p) & 1u) != 0;
                 e_nl = nl && !esc;
                 if (esc) dead = true;
             }
@@ -530,8 +547,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             const uint64_t start = prev ? ws.vbase + e_prev + 1 : ws.row_start;
             const uint64_t rl = ws.vbase + e_pos + 1 - start;
             if (e_nl && !sentinel && rl >= FIRST_ROW_CAP - 1) {
-                const uint32_t li = atomicAdd(&a.st->long_count, 1u);
-                if (li < a.long_cap) { a.long_rows[li].start = start; a.long_rows[li].len = rl; }
+                const uint32_t li = atomicAdd(&COLD(st)->long_count, 1u);
+                if (li < COLD(long_cap)) { LongRow *lr = COLD(long_rows); lr[li].start = start; lr[li].len = rl; }
             }
         }
         ws.row_start = abs_h + 1;
@@ -543,8 +560,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     }
     if (rm) {
         if (ends_row && row <= a.row_limit) {
-            if (col + 1 != a.ncols) atomicMin(&a.st->bad_row, row);              // ConvertToZDW.cpp:336-337
-            if (row + 1 == a.row_limit) a.st->split_pos = ws.vbase + e_pos + 1;  // the next block starts after this row
+            if (col + 1 != a.ncols) atomicMin(&COLD(st)->bad_row, row);          // ConvertToZDW.cpp:336-337
+            if (row + 1 == a.row_limit) COLD(st)->split_pos = ws.vbase + e_pos + 1;  // the next block starts after this row
         }
     }
     in_block = row < a.row_limit;
@@ -582,7 +599,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         if (far_me) {
             abs_start = ws.far_abs + 1u + n_prev;
             const uint64_t l64 = ws.vbase + e_pos - abs_start;
-            if (l64 >= (1ull << 30)) { a.st->nul_seen = 2; }                // a single field of 1 GiB or more
+            if (l64 >= (1ull << 30)) { COLD(st)->nul_seen = 2; }            // a single field of 1 GiB or more
             raw_len = len = (uint32_t)l64;
         }
     }
@@ -638,15 +655,17 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 w.key = 1; w.s0 = w.s1 = w.s2 = 0;
                 if (pending) w = load_slot(slot);
                 const bool same = pending && w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len;
-                const uint32_t nid = alloc_ids(ws.ids, pending && !same && w.key == 0, a.st, ID_CHUNK);
+                const bool wants_id = pending && !same && w.key == 0;
+                uint32_t nid = 0;
+                if (__ballot(wants_id)) nid = alloc_ids(ws.ids, wants_id, COLD(st), ID_CHUNK);          // (inserts are rare: one string in eighty of the benchmark's table)
                 if (!pending) continue;
                 if (same) {
                     id = (uint32_t)w.key; pending = false;
                     if (a.track_first) note_occurrence(a.uniq_pos, id - 1u, abs_start);
                 } else if (w.key == 0) {
-                    if (nid >= a.id_cap) { a.st->overflow = 1; }
+                    if (nid >= COLD(id_cap)) { COLD(st)->overflow = 1; }
                     else {
-                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, a.uniq_pos, a.uniq_len, c0, c1, c2, a.track_first != 0);
+                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, a.track_first != 0);
                         if (old == 0) { is_new = true; id = nid + 1; } else slow = true;          // lost the race: general form
                     }
                     pending = false;
@@ -725,21 +744,26 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             uint32_t cur = lds_u32(qs), end = lds_u32(qs + 4u);
             if (end - cur < k) {
                 const uint32_t left = end - cur;
-                if (lane < left && cur + lane < a.dq_cap) a.dq[2ull * (cur + lane) + 1] = ~0ull;
+                uint64_t *dq0 = COLD(dq);
+                if (lane < left && cur + lane < COLD(dq_cap)) dq0[2ull * (cur + lane) + 1] = ~0ull;
                 uint32_t fresh = 0;
-                if (lane == 0) fresh = atomicAdd(&a.st->deferred, DQ_CHUNK);
+                if (lane == 0) fresh = atomicAdd(&COLD(st)->deferred, DQ_CHUNK);
                 cur = lane_value(fresh, 0);
                 end = cur + DQ_CHUNK;
                 if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + qs + 4u) = end;
             }
             const uint32_t qb = cur + mbcnt64(sm);
             if (lane == 0) *reinterpret_cast<uint32_t *>(zdw_lds + qs) = cur + k;
-            if (slow) {
-                if (qb < a.dq_cap) {
-                    a.dq[2ull * qb] = abs_start | ((uint64_t)col << 40);
-                    a.dq[2ull * qb + 1] = (uint64_t)raw_len | ((uint64_t)row << 32);
-                } else {
-                    a.st->deferred_lost = 1;
+            {
+                uint64_t *dq0 = COLD(dq);
+                const uint32_t dqc = COLD(dq_cap);
+                if (slow) {
+                    if (qb < dqc) {
+                        dq0[2ull * qb] = abs_start | ((uint64_t)col << 40);
+                        dq0[2ull * qb + 1] = (uint64_t)raw_len | ((uint64_t)row << 32);
+                    } else {
+                        COLD(st)->deferred_lost = 1;
+                    }
                 }
             }
         } else {
@@ -775,7 +799,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     }
     if (t.cols_in_lds) {
         for (uint32_t c = threadIdx.x; c < a.ncols; c += 64 * P1_WPB) {
-            *reinterpret_cast<uint32_t *>(zdw_lds + t.meta + 4 * c) = pack_col_meta(a.col_kind[c], (uint32_t)a.col_numidx[c] & 0x3fffu, a.col_recoff[c]);
+            *reinterpret_cast<uint32_t *>(zdw_lds + t.meta + 4 * c) = pack_col_meta(COLD(col_kind)[c], (uint32_t)COLD(col_numidx)[c] & 0x3fffu, COLD(col_recoff)[c]);
             zdw_lds[t.seen + c] = 0;
         }
         for (uint32_t i = threadIdx.x; i < a.nnum; i += 64 * P1_WPB) {
@@ -799,43 +823,49 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
 
     constexpr bool fold = FOLD;                     // no row scan has run: spans by ticket, their rows counted here
     for (uint32_t si = wave_id;; si += wave_count) {
-        if (uniform32(*reinterpret_cast<volatile const uint32_t *>(&a.st->overflow))) break;      // an ordinary (cached) read: a stale 0 only delays the exit
+        // what a span visit needs of the block's geometry: read per visit, not held across the kernel
+        P1Status *const stp = COLD(st);
+        const uint8_t *const v_in = COLD(in);
+        const uint64_t v_lo = COLD(lo), v_hi = COLD(hi), v_span0 = COLD(span0);
+        const uint32_t v_nspans = COLD(nspans), v_shift = COLD(span_shift);
+        if (uniform32(*reinterpret_cast<volatile const uint32_t *>(&stp->overflow))) break;      // an ordinary (cached) read: a stale 0 only delays the exit
         if (new_entries >= 128) {        // publish this wave's inserts in bulk; stop everybody once the table is half full
             uint32_t seen_total = 0;
-            if (lane == 0) seen_total = atomicAdd(&a.st->entries, new_entries) + new_entries;
+            if (lane == 0) seen_total = atomicAdd(&stp->entries, new_entries) + new_entries;
             seen_total = lane_value(seen_total, 0);          // (a readlane: wave-uniform for the compiler too, unlike a shuffle)
             new_entries = 0;
-            if (seen_total >= a.max_entries) { a.st->overflow = 1; break; }          // (every lane stores: a branch on the lane number next to a break makes the loop's exit divergent for the compiler)
+            if (seen_total >= COLD(max_entries)) { stp->overflow = 1; break; }          // (every lane stores: a branch on the lane number next to a break makes the loop's exit divergent for the compiler)
         }
         uint32_t rowbase, rows_here;
         if (fold) {
             // (nothing between taking a span and publishing its count may leave the loop: the spans behind it wait for that count)
             uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(&a.st->next_span, 1u);
+            if (lane == 0) t = atomicAdd(&stp->next_span, 1u);
             si = lane_value(t, 0);
-            if (si >= a.nspans) break;
-            const uint64_t f0 = (a.span0 + si) << a.span_shift;
-            const uint64_t fs0 = f0 > a.lo ? f0 : a.lo, fe0 = f0 + (1ull << a.span_shift) < a.hi ? f0 + (1ull << a.span_shift) : a.hi;
+            if (si >= v_nspans) break;
+            uint64_t *const span_state = COLD(span_state);
+            const uint64_t f0 = (v_span0 + si) << v_shift;
+            const uint64_t fs0 = f0 > v_lo ? f0 : v_lo, fe0 = f0 + (1ull << v_shift) < v_hi ? f0 + (1ull << v_shift) : v_hi;
             uint32_t nul = 0;
-            const uint32_t mine = count_row_starts(a.in, a.n, a.lo, fs0, fe0, lane, nul);
+            const uint32_t mine = count_row_starts(v_in, COLD(n), v_lo, fs0, fe0, lane, nul);
             (void)wave_excl_sum(mine, lane, rows_here);
             rows_here = uniform32(rows_here);
-            if (__ballot(nul != 0)) a.st->nul_seen = 1;
+            if (__ballot(nul != 0)) stp->nul_seen = 1;
             uint64_t before = 0;                             // rows that start in the spans before this one
             if (si) {
-                __hip_atomic_store(a.span_state + si, (1ull << 62) | rows_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(span_state + si, (1ull << 62) | rows_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // look back: 64 spans at a time, the nearest in lane 0; up to the nearest one that knows its total
                 int64_t j = (int64_t)si - 1;
                 uint32_t spins = 0;
                 for (;;) {
                     const int64_t idx = j - (int64_t)lane;
                     uint64_t w = 2ull << 62;                  // (before span 0: a total of 0)
-                    if (idx >= 0) w = __hip_atomic_load(a.span_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (idx >= 0) w = __hip_atomic_load(span_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t flag = (uint32_t)(w >> 62);
                     const uint64_t known = __ballot(flag == 2u), pending = __ballot(flag == 0u);
                     const int first = known ? lowest_bit(known) : 64;
                     if (pending & mask_lt(first)) {           // a nearer span has not counted yet
-                        if (++spins > (1u << 22)) { a.st->fold_abort = 1; a.st->overflow = 1; break; }
+                        if (++spins > (1u << 22)) { stp->fold_abort = 1; stp->overflow = 1; break; }
                         __builtin_amdgcn_s_sleep(2);
                         continue;
                     }
@@ -850,26 +880,27 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                     j -= 64;
                 }
             }
-            __hip_atomic_store(a.span_state + si, (2ull << 62) | (before + rows_here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (si + 1 == a.nspans) a.st->rows_total = before + rows_here + 1;
+            __hip_atomic_store(span_state + si, (2ull << 62) | (before + rows_here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (si + 1 == v_nspans) stp->rows_total = before + rows_here + 1;
             if (before >= 0xFFFFFFFFull) break;              // (reported by the host: more rows than a block may hold)
             rowbase = (uint32_t)before;
         } else {
-            if (si >= a.nspans) break;
+            if (si >= v_nspans) break;
             // (values loaded from memory count as divergent for the compiler even when the address is wave-uniform: a branch on
             // one would put the rest of the loop body under an exec mask and its bookkeeping into vector registers)
-            rowbase = uniform32(a.span_rowbase[si]);
-            rows_here = uniform32(a.span_rowbase[si + 1]) - rowbase;
+            const uint32_t *const span_rowbase = COLD(span_rowbase);
+            rowbase = uniform32(span_rowbase[si]);
+            rows_here = uniform32(span_rowbase[si + 1]) - rowbase;
         }
         if (rows_here == 0) continue;                             // no row starts in this span
         if (rowbase > a.row_limit) break;                         // later spans hold rows of later blocks only
-        const uint64_t s0 = (a.span0 + si) << a.span_shift, SPAN_BYTES = 1ull << a.span_shift;
-        const uint64_t ss = s0 > a.lo ? s0 : a.lo;
-        const uint64_t se = s0 + SPAN_BYTES < a.hi ? s0 + SPAN_BYTES : a.hi;
+        const uint64_t s0 = (v_span0 + si) << v_shift, SPAN_BYTES = 1ull << v_shift;
+        const uint64_t ss = s0 > v_lo ? s0 : v_lo;
+        const uint64_t se = s0 + SPAN_BYTES < v_hi ? s0 + SPAN_BYTES : v_hi;
         const uint64_t pos0 = ss & ~(uint64_t)(ROUND - 1);
 
         // the visit: all descriptors of the previous one were handled or dropped, the ring is empty
-        const bool at_row_start = (ss == a.lo) || uniform32(is_row_terminator(a.in, a.lo, ss - 1) ? 1u : 0u) != 0;
+        const bool at_row_start = (ss == v_lo) || uniform32(is_row_terminator(v_in, v_lo, ss - 1) ? 1u : 0u) != 0;
         ws.vbase = (pos0 - ROUND) & ~(uint64_t)(BYTE_RING - 1);            // wraps below zero for the first span: only differences matter
         ws.q_head = 0; ws.q_count = 0;
         ws.row_cur = rowbase; ws.col_cur = 0;
@@ -894,7 +925,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
             const int64_t dlt = (int64_t)(x - ws.vbase);
             return dlt < 0 ? 0u : (dlt > 0x7fffffffll ? 0x7fffffffu : (uint32_t)dlt);
         };
-        auto set_rels = [&]() { rel_ss = rel31(ss); ws.rel_se1 = rel31(se - 1); rel_hi = rel31(a.hi); };
+        auto set_rels = [&]() { rel_ss = rel31(ss); ws.rel_se1 = rel31(se - 1); rel_hi = rel31(COLD(hi)); };
         set_rels();
 
         // this lane's kept boundaries `bits` (bit i = byte pos + i) from ring slot first_slot on; `all`: every boundary of the lane's
@@ -914,12 +945,12 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         // lanes whose chunk would start at or past the end of the image re-read the last 16-byte chunk that starts
         // inside it (an aligned chunk whose first byte is inside an allocation never leaves its page; their bytes lie
         // past `hi` and are masked)
-        const uint8_t *last_chunk = a.in + ((a.n - 1) & ~15ull);
+        const uint8_t *last_chunk = v_in + ((COLD(n) - 1) & ~15ull);
         auto load_chunk = [&](const uint8_t *q) {
             q = q < last_chunk ? q : last_chunk;
             return *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(q, 16));
         };
-        const uint8_t *lane_ptr = a.in + pos0 + 16u * lane;               // this lane's 16 bytes of chunk A of the current round
+        const uint8_t *lane_ptr = v_in + pos0 + 16u * lane;               // this lane's 16 bytes of chunk A of the current round
         uint4 P = load_chunk(lane_ptr);                                   // the one chunk in flight
         uint32_t relb = (uint32_t)(pos0 - ws.vbase);                      // relative position of the current round
         uint32_t first_rel = relb;                                        // nothing below it was loaded by this visit
@@ -1042,7 +1073,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                     if (!ws.first_pending) {
                         // (a field that began further back than the new base: its start is kept as an absolute position)
                         if (ws.last_e < delta) {
-                            if (!SKIP) { if (lane == 0) a.st->nul_seen = 2; }             // a single field of 1 GiB or more
+                            if (!SKIP) { if (lane == 0) COLD(st)->nul_seen = 2; }         // a single field of 1 GiB or more
                             else if (!ws.far) { ws.far = true; ws.far_abs = ws.vbase + ws.last_e; }
                             ws.last_e = delta;
                         }
@@ -1087,28 +1118,35 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
             if (ws.done || last) break;
         }
     }
-    retire_ids(ws.ids, a.uniq_len, a.id_cap);
+    retire_ids(ws.ids, COLD(uniq_len), COLD(id_cap));
     if (DEFER) {
         const uint32_t qs = L.dqs + ws.desc / (QCAP * 4u) * 8u;
+        uint64_t *dq0 = COLD(dq);
+        const uint32_t dqc = COLD(dq_cap);
         for (uint32_t q = lds_u32(qs) + lane; q < lds_u32(qs + 4u); q += 64)
-            if (q < a.dq_cap) a.dq[2ull * q + 1] = ~0ull;
+            if (q < dqc) dq0[2ull * q + 1] = ~0ull;
     }
     __syncthreads();
     if (new_entries && lane == 0) {
-        const uint32_t total = atomicAdd(&a.st->entries, new_entries) + new_entries;
-        if (total > a.max_entries) a.st->overflow = 1;
+        P1Status *stp = COLD(st);
+        const uint32_t total = atomicAdd(&stp->entries, new_entries) + new_entries;
+        if (total > COLD(max_entries)) stp->overflow = 1;
     }
 
     if (t.cols_in_lds) {   // one flush per workgroup
+        const uint8_t *ck = COLD(col_kind);
+        const int32_t *cn = COLD(col_numidx);
+        uint8_t *cs = COLD(col_seen);
+        uint64_t *cmn = COLD(col_min), *cmx = COLD(col_max);
         for (uint32_t c = threadIdx.x; c < a.ncols; c += 64 * P1_WPB) {
-            if (a.col_kind[c] == K_TEXT) {
-                if (zdw_lds[t.seen + c]) a.col_seen[c] = 1;
+            if (ck[c] == K_TEXT) {
+                if (zdw_lds[t.seen + c]) cs[c] = 1;
             } else {
-                const uint32_t i = (uint32_t)a.col_numidx[c];
+                const uint32_t i = (uint32_t)cn[c];
                 const uint64_t mn = reinterpret_cast<const uint64_t *>(zdw_lds + t.mn)[i], mx = reinterpret_cast<const uint64_t *>(zdw_lds + t.mx)[i];
                 if (mx != 0) {
-                    atomicMin(reinterpret_cast<unsigned long long *>(&a.col_min[c]), (unsigned long long)mn);
-                    atomicMax(reinterpret_cast<unsigned long long *>(&a.col_max[c]), (unsigned long long)mx);
+                    atomicMin(reinterpret_cast<unsigned long long *>(&cmn[c]), (unsigned long long)mn);
+                    atomicMax(reinterpret_cast<unsigned long long *>(&cmx[c]), (unsigned long long)mx);
                 }
             }
         }
