@@ -73,6 +73,17 @@ def test_multi_block_stream_and_errors(dec, sandbox):
     assert rc == 6, dec.error()
     rc, _, _ = dec.decode_all(b"\x0c\x00" + z[2:])
     assert rc == 5
+    # crafted dictionary headers: sizes that would wrap a position, or that the format cannot hold, are corrupt data (9), never a fault
+    zz0 = zdw_decode.decode(z)[0]
+    at = zz0.header_len + 9                      # the first block's dictionary section: index size, then the size field
+    isz = z[at]
+    assert 1 <= isz <= 4
+    for bad in (bytes([8]) + b"\xf0" + b"\xff" * 7,            # size near 2^64: position + size wraps
+                bytes([8]) + (1 << 33).to_bytes(8, "little"),   # beyond the format's 32-bit offsets
+                bytes([9]) + b"\x01" * 9,                       # an index size no version writes
+                bytes([isz]) + (len(z) * 2).to_bytes(8, "little")[:isz]):      # longer than the stream
+        rc, _, _ = dec.decode_all(z[:at] + bad + z[at + 1 + isz:])
+        assert rc == 9, (bad, rc, dec.error())
 
 
 @pytest.mark.parametrize("ncols,group", [(70, ""), (130, ""), (190, "1"), (190, "2"), (300, ""), (500, ""), (500, "8"), (513, "")])

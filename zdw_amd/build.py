@@ -4,7 +4,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("ZDW_LIBDIR") or os.path.join(HERE, "lib")      # (ZDW_LIBDIR: the profiling tools' own build, tools/build_experiments.sh)
 LIB_HIP = os.path.join(LIBDIR, "libzdw_hip.so")
 LIB_CLI = os.path.join(LIBDIR, "libzdw_cli.so")
 CLI_EXE = os.path.join(LIBDIR, "convertDWfile")
@@ -15,7 +15,7 @@ TRIM_EXE = os.path.join(LIBDIR, "trim_spaces")
 
 def build(jobs=4, quiet=True):
     """(Re)build libzdw_hip.so, libzdw_cli.so and convertDWfile.  make decides what is stale."""
-    cmd = ["make", "-C", CSRC, "-j%d" % jobs, "all"]
+    cmd = ["make", "-C", CSRC, "-j%d" % jobs, "all", "OUT=" + LIBDIR]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL if quiet else None)
     for p in (LIB_HIP, LIB_CLI, CLI_EXE, LIB_SYNTH, DECODER_EXE, TRIM_EXE):
         if not os.path.exists(p):

@@ -702,6 +702,9 @@ ConvertToZDW::ERR_CODE ConvertToZDW::processFile(const std::vector<unsigned char
         }
         if (!tmpGz.empty()) unlink(tmpGz.c_str());
     } else if (!teeName.empty()) {
+        // (the library's feeder thread may still be inside readSource(), writing to the tee -- a failed conversion does not
+        // read its input to the end: the context goes first, which joins that thread, then the tee is closed)
+        if (guard.ctx) { zdw_ctx_destroy(guard.ctx); guard.ctx = NULL; }
         if (source.tee) { pclose(source.tee); source.tee = NULL; }
         unlink(teeName.c_str());
     }

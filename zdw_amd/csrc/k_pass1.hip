@@ -399,7 +399,7 @@ struct WaveState {
 // entries were created.  DEFER: fields that need the general form are queued for k_pass1_deferred instead of
 // being handled here (the general form costs this kernel a fifth of its registers and a wave per SIMD).
 // TRIM: convertDWfile -t -- trailing blanks are cut off every field before anything else looks at it (ConvertToZDW.cpp:295-313).
-template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP>
+template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP, bool TRACK>
 __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const DictTable &d, const P1Lds &L, WaveState &ws, uint32_t cnt,
                                             uint32_t lane)
 {
@@ -628,67 +628,37 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + (meta >> 16);
     bool is_new = false;
 
-    // ---- text-like columns, <= 24 bytes: decided by one table slot ----
+    // ---- text-like columns, <= 24 bytes: decided by one table slot.  The slot is REQUESTED here and looked at behind the integer fields
+    // ---- of the batch (other lanes), whose records are stored behind that wait too: between the request and the wait the wave issues no
+    // ---- other memory instruction, so the wait is for the probe alone (and for what was in flight long before it).
     bool ft = fast && kind == K_TEXT;
     if (ft && len > 24u) { slow = true; ft = false; }
     const uint64_t ftm = __ballot(ft);
+    uint32_t t_id = 0;
+    bool pending = false;
+    uint64_t c0 = 0, c1 = 0, c2 = 0, acc = 0, slot_i = 0;
+    SlotLoad w0;
     if (ftm) {
-        if (ft) {
-            uint32_t id = 0;
-            bool pending = false;
-            uint64_t c0 = 0, c1 = 0, c2 = 0, acc = 0, i = 0;
-            if (len) {                                                            // empty fields are skipped (:340-341)
-                if (!zdw_lds[t.seen + col]) zdw_lds[t.seen + col] = 1;
-                const uint32_t lo = L.lut + 32u * len;
-                uint32_t fw[6];
-                lds_bytes<6>(ra, fw);
-                c0 = u64_of(fw[0], fw[1]) & lds_u64(lo); c1 = u64_of(fw[2], fw[3]) & lds_u64(lo + 8); c2 = u64_of(fw[4], fw[5]) & lds_u64(lo + 16);
-                acc = nh24(c0, c1, c2);
-                i = hash_place(acc) & a.slot_mask;
-                pending = !P1_ABLATE(a, 2u);
-            }
-            // uniform over the text lanes (runs while any of them is undecided): ids are handed out at loop level
-            for (uint32_t probe = 0; probe < 4; ++probe) {
-                if (!__ballot(pending)) break;
-                uint64_t *slot = a.slots + 4 * i;
-                SlotWords w;
-                w.key = 1; w.s0 = w.s1 = w.s2 = 0;
-                if (pending) w = load_slot(slot);
-                const bool same = pending && w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len;
-                const bool wants_id = pending && !same && w.key == 0;
-                uint32_t nid = 0;
-                if (__ballot(wants_id)) nid = alloc_ids(ws.ids, wants_id, COLD(st), ID_CHUNK);          // (inserts are rare: one string in eighty of the benchmark's table)
-                if (!pending) continue;
-                if (same) {
-                    id = (uint32_t)w.key; pending = false;
-                    if (a.track_first) note_occurrence(a.uniq_pos, id - 1u, abs_start);
-                } else if (w.key == 0) {
-                    if (nid >= COLD(id_cap)) { COLD(st)->overflow = 1; }
-                    else {
-                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, a.track_first != 0);
-                        if (old == 0) { is_new = true; id = nid + 1; } else slow = true;          // lost the race: general form
-                    }
-                    pending = false;
-                } else if (w.s0 == 0) {
-                    slow = true; pending = false;                                 // claimed, inline copy not complete yet
-                } else {
-                    i = (i + 1) & a.slot_mask;
-                }
-            }
-            if (pending) slow = true;
-            if (!slow && in_block && !P1_ABLATE(a, 4u)) {
-                *reinterpret_cast<uint32_t *>(recp) = id;
-                if (SKIP && a.nz && id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
-            }
+        if (ft && len) {                                                          // empty fields are skipped (:340-341)
+            if (!zdw_lds[t.seen + col]) zdw_lds[t.seen + col] = 1;
+            const uint32_t lo = L.lut + 32u * len;
+            uint32_t fw[6];
+            lds_bytes<6>(ra, fw);
+            c0 = u64_of(fw[0], fw[1]) & lds_u64(lo); c1 = u64_of(fw[2], fw[3]) & lds_u64(lo + 8); c2 = u64_of(fw[4], fw[5]) & lds_u64(lo + 16);
+            acc = nh24(c0, c1, c2);
+            slot_i = hash_place(acc) & a.slot_mask;
+            pending = !P1_ABLATE(a, 2u);
+            if (pending) request_slot(a.slots + 4 * slot_i, w0);
         }
-        adopt_ids(ws.ids, ftm);
     }
 
     // ---- integers of <= 16 plain digits, char(1) ----
     bool fn = fast && kind != K_TEXT;
     if (fn && kind == K_INT && len > 16u) { slow = true; fn = false; }
+    bool n_store = false;                  // this lane has a numeric record to store (behind the text fields' wait)
+    uint64_t n_rec = 0;
     if (fn && len == 0u) {                 // an empty numeric field is a zero record and touches no range (sparse tables: most of them)
-        if (in_block && !P1_ABLATE(a, 4u)) *reinterpret_cast<uint64_t *>(recp) = 0ull;
+        n_store = in_block && !P1_ABLATE(a, 4u);
         fn = false;
     }
     if (__ballot(fn)) {
@@ -724,11 +694,56 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (!ok) slow = true;
             else {
                 if (v_range > 0) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
-                if (in_block && !P1_ABLATE(a, 4u)) {
-                    *reinterpret_cast<uint64_t *>(recp) = v_rec;
-                    if (SKIP && a.nz && v_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
+                if (in_block && !P1_ABLATE(a, 4u)) { n_store = true; n_rec = v_rec; }
+            }
+        }
+    }
+
+    // ---- the text fields' slots have arrived (or will have, behind the wait) ----
+    if (ftm) {
+        if (ft) {
+            // uniform over the text lanes (runs while any of them is undecided): ids are handed out at loop level
+            for (uint32_t probe = 0; probe < 4; ++probe) {
+                if (!__ballot(pending)) break;
+                uint64_t *slot = a.slots + 4 * slot_i;
+                SlotWords w;
+                if (probe == 0) w = await_slot(w0);                               // (lanes that requested nothing hold nothing: masked below)
+                else if (pending) w = load_slot(slot);
+                if (!pending) { w.key = 1; w.s0 = w.s1 = w.s2 = 0; }
+                const bool same = pending && w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len;
+                const bool wants_id = pending && !same && w.key == 0;
+                uint32_t nid = 0;
+                if (__ballot(wants_id)) nid = alloc_ids(ws.ids, wants_id, COLD(st), ID_CHUNK);          // (inserts are rare: one string in eighty of the benchmark's table)
+                if (!pending) continue;
+                if (same) {
+                    t_id = (uint32_t)w.key; pending = false;
+                    if (TRACK) note_occurrence(a.uniq_pos, t_id - 1u, abs_start);
+                } else if (w.key == 0) {
+                    if (nid >= COLD(id_cap)) { COLD(st)->overflow = 1; }
+                    else {
+                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK);
+                        if (old == 0) { is_new = true; t_id = nid + 1; } else slow = true;          // lost the race: general form
+                    }
+                    pending = false;
+                } else if (w.s0 == 0) {
+                    slow = true; pending = false;                                 // claimed, inline copy not complete yet
+                } else {
+                    slot_i = (slot_i + 1) & a.slot_mask;
                 }
             }
+            if (pending) slow = true;
+            if (!slow && in_block && !P1_ABLATE(a, 4u)) {
+                *reinterpret_cast<uint32_t *>(recp) = t_id;
+                if (SKIP && a.nz && t_id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
+            }
+        }
+        adopt_ids(ws.ids, ftm);
+    }
+    // the integer fields' records
+    if (__ballot(n_store)) {
+        if (n_store) {
+            *reinterpret_cast<uint64_t *>(recp) = n_rec;
+            if (SKIP && a.nz && n_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }
 
@@ -775,7 +790,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
 }
 // FOLD: no row scan has run -- the waves take the spans in order (a ticket each), count the rows that start in theirs and learn their
 // first row's number from the spans before (Pass1Args.span_state).
-template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP, bool FOLD>
+// TRACK: uniq_pos[id] ends up as the string's FIRST occurrence (Pass1Args.track_first: every occurrence takes part in a minimum).
+template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP, bool FOLD, bool TRACK>
 __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass1Args a)
 {
     constexpr uint32_t QM = QCAP * 4u - 1u;
@@ -818,7 +834,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     ws.ids.cur = ws.ids.end = 0;
     if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
-    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st; d.track_first = a.track_first;
+    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st; d.track_first = TRACK ? 1u : 0u;
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
     constexpr bool fold = FOLD;                     // no row scan has run: spans by ticket, their rows counted here
@@ -1110,7 +1126,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
             while (!ws.done && ws.q_count > keep) {
                 const uint32_t cnt = ws.q_count < 64u ? ws.q_count : 64u;
                 if (P1_ABLATE(a, 32u)) { if (near_end && ws.q_count <= 64u) ws.done = true; }      // profiling only: the tokeniser alone
-                else new_entries += consume<DEFER, TRIM, QCAP, SKIP>(a, t, d, L, ws, cnt, lane);
+                else new_entries += consume<DEFER, TRIM, QCAP, SKIP, TRACK>(a, t, d, L, ws, cnt, lane);
                 ws.q_head += cnt;
                 ws.q_count -= cnt;
             }
@@ -1231,11 +1247,12 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     typedef void (*P1Fn)(const Pass1Args);
-#define P1_MODES(D, T, F) {k_pass1<D, T, QCAP_SMALL, false, F>, k_pass1<D, T, QCAP_LARGE, false, F>, k_pass1<D, T, QCAP_SMALL, true, F>}
-    static const P1Fn fns[2][2][2][3] = {{{P1_MODES(false, false, false), P1_MODES(false, true, false)}, {P1_MODES(true, false, false), P1_MODES(true, true, false)}},
-                                         {{P1_MODES(false, false, true), P1_MODES(false, true, true)}, {P1_MODES(true, false, true), P1_MODES(true, true, true)}}};
+#define P1_MODES(D, T, F, K) {k_pass1<D, T, QCAP_SMALL, false, F, K>, k_pass1<D, T, QCAP_LARGE, false, F, K>, k_pass1<D, T, QCAP_SMALL, true, F, K>}
+#define P1_FORMS(F, K) {{P1_MODES(false, false, F, K), P1_MODES(false, true, F, K)}, {P1_MODES(true, false, F, K), P1_MODES(true, true, F, K)}}
+    static const P1Fn fns[2][2][2][2][3] = {{P1_FORMS(false, false), P1_FORMS(true, false)}, {P1_FORMS(false, true), P1_FORMS(true, true)}};
+#undef P1_FORMS
 #undef P1_MODES
-    const P1Fn kfn = fns[a.span_state != nullptr][defer][trim][mode];
+    const P1Fn kfn = fns[a.track_first != 0][a.span_state != nullptr][defer][trim][mode];
     const void *fn = (const void *)kfn;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
     const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules

@@ -1430,6 +1430,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     HIP_TRY(c, c->long_rows.ensure((uint64_t)long_cap * sizeof(LongRow)));
     P1Status st{};
     bool dq_grown = false;
+    int reruns = 0;                  // re-runs that reset `attempt`: bounded on their own
     for (int attempt = 0;; ++attempt) {
         {   // the table and the unique ids: the table's load limit plus what waves can leave unused in their chunks (holes)
             const uint64_t cap = std::min<uint64_t>(nslots / 8 * 5 + 64ull * 8192 + nslots / 16, 0xFFFFFFF0ull);
@@ -1444,6 +1445,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
                 while (c->rec.ensure((uint64_t)nrows * c->rec_stride + 64) != hipSuccess)
                     if (!fewer_rows()) return fail(c, ZDW_OUT_OF_MEMORY, "no room for the record matrix of a single row; split the block");
                 nslots = std::min(nslots, first_table(nrows));
+                if (++reruns > 40) return fail(c, ZDW_OUT_OF_MEMORY, "no room for this block's buffers");
                 attempt = -1;
                 continue;
             }
@@ -1569,7 +1571,12 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
         if (c->model_max_slots && nslots >= c->model_max_slots && nrows > 1) {
             // The memory-limit model ends a block long before its dictionary needs a larger table than this: these rows hold
             // more strings than any block may -- look at half of them instead of growing the table.
-            (void)fewer_rows();
+            if (!fewer_rows()) {
+                // (pass 1 was counting its own rows, so there is no row count to halve: count first, the ordinary way)
+                if (fold) { c->no_fold = true; return pass1_impl(c, hint, res); }
+                return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table of %llu slots overflows on a single row", (unsigned long long)nslots);
+            }
+            if (++reruns > 40) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
             attempt = -1;
             continue;
         }

@@ -840,7 +840,7 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
     const uint8_t *img = d->img.as<uint8_t>();
     const uint32_t ncols = (uint32_t)d->names.size();
     auto fetch = [&](uint64_t off, void *dst, uint64_t nbytes) -> bool {
-        if (off + nbytes > d->len) return false;
+        if (nbytes > d->len || off > d->len - nbytes) return false;      // (compared without adding: untrusted sizes must not wrap)
         return hipMemcpy(dst, img + off, nbytes, hipMemcpyDeviceToHost) == hipSuccess;
     };
     uint64_t pos = d->pos;
@@ -859,11 +859,14 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
     uint64_t dsize = 0, dict_off = 0;
     if (isz) {
         uint8_t sz[8] = {0};
-        if (isz > 8 || !fetch(pos, sz, isz)) return dfail(d, DEC_CORRUPT, "dictionary size field");
+        // (the format's dictionary offsets are 32-bit -- dictionary.cpp:62-73 -- so the size field of a v9-v11 stream has at most 4 bytes
+        // and the dictionary fewer than 2^32)
+        if (isz > 4 || !fetch(pos, sz, isz)) return dfail(d, DEC_CORRUPT, "dictionary size field");
         for (unsigned i = 0; i < isz; ++i) dsize |= (uint64_t)sz[i] << (8 * i);
         pos += isz;
         uint8_t lastb = 1;
-        if (dsize == 0 || pos + dsize > d->len || !fetch(pos + dsize - 1, &lastb, 1) || lastb != 0) return dfail(d, DEC_CORRUPT, "dictionary cut short");
+        if (dsize == 0 || dsize >= (1ull << 32) || dsize > d->len - pos || !fetch(pos + dsize - 1, &lastb, 1) || lastb != 0)
+            return dfail(d, DEC_CORRUPT, "dictionary cut short");
         dict_off = pos;
         pos += dsize;
     }

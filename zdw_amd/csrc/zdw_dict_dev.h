@@ -111,6 +111,25 @@ __device__ __forceinline__ SlotWords load_slot(const uint64_t *slot)
     return w;
 }
 
+// The same in two steps: the loads are requested, other work runs, then the wave waits for them.  The compiler does not know that
+// the registers fill in later: nothing may read `w` between the two calls (they are tied to the wait as in-out operands, so every
+// use stays behind it), and the wait is for everything the wave has in flight.
+struct SlotLoad { uint32_t lo __attribute__((ext_vector_type(4))); uint32_t hi __attribute__((ext_vector_type(4))); };
+__device__ __forceinline__ void request_slot(const uint64_t *slot, SlotLoad &w)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1"
+                 : "=&v"(w.lo), "=&v"(w.hi) : "v"(slot) : "memory");
+}
+__device__ __forceinline__ SlotWords await_slot(SlotLoad &l)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(l.lo), "+v"(l.hi) : : "memory");
+    SlotWords w;
+    w.key = ((uint64_t)l.lo.y << 32) | l.lo.x; w.s0 = ((uint64_t)l.lo.w << 32) | l.lo.z;
+    w.s1 = ((uint64_t)l.hi.y << 32) | l.hi.x; w.s2 = ((uint64_t)l.hi.w << 32) | l.hi.z;
+    return w;
+}
+
 // ---- unique ids -------------------------------------------------------------------------------
 struct IdAlloc { uint32_t cur, end; };     // wave-uniform: ids [cur, end) belong to this wave
 constexpr uint32_t ID_CHUNK = 64;          // ids a pass-1 wave takes beyond what it needs right now
