@@ -707,8 +707,12 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 if (!__ballot(pending)) break;
                 uint64_t *slot = a.slots + 4 * slot_i;
                 SlotWords w;
-                if (probe == 0) w = await_slot(w0);                               // (lanes that requested nothing hold nothing: masked below)
-                else if (pending) w = load_slot(slot);
+                if (probe == 0) {
+                    w = await_slot(w0);                                           // (lanes that requested nothing hold nothing: masked below)
+                    // that was an ordinary load, possibly from this CU's L1: only a complete slot can be taken at its word (request_slot)
+                    const bool again = pending && (w.key == 0 || w.s0 == 0);
+                    if (__ballot(again)) { if (again) w = load_slot(slot); }
+                } else if (pending) w = load_slot(slot);
                 if (!pending) { w.key = 1; w.s0 = w.s1 = w.s2 = 0; }
                 const bool same = pending && w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len;
                 const bool wants_id = pending && !same && w.key == 0;
@@ -964,7 +968,14 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         const uint8_t *last_chunk = v_in + ((COLD(n) - 1) & ~15ull);
         auto load_chunk = [&](const uint8_t *q) {
             q = q < last_chunk ? q : last_chunk;
+#ifdef ZDW_P1_PLAIN_STREAM
             return *reinterpret_cast<const uint4 *>(__builtin_assume_aligned(q, 16));
+#else
+            // (read once: a non-temporal load, so that the image streaming through does not push the table's hot slots out of the CU's L1)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(q, 16)));
+            return make_uint4(x.x, x.y, x.z, x.w);
+#endif
         };
         const uint8_t *lane_ptr = v_in + pos0 + 16u * lane;               // this lane's 16 bytes of chunk A of the current round
         uint4 P = load_chunk(lane_ptr);                                   // the one chunk in flight
