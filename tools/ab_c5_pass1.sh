@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the switches used here exist only in the experiments build: tools/build_experiments.sh)
+export ZDW_LIBDIR=${GRAFT_REPO_ROOT:-$PWD}/zdw_amd/lib_exp
 # What pass 1 costs on C5's table shape (4 GB, one block, no memory model): columns and id columns varied, field work ablated
 set -e
 mkdir -p gpurun_out

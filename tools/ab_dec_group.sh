@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the switches used here exist only in the experiments build: tools/build_experiments.sh)
+export ZDW_LIBDIR=${GRAFT_REPO_ROOT:-$PWD}/zdw_amd/lib_exp
 # A/B: batches of 64 columns per wave in the decoder's row kernel (ZDW_DEC_GROUP), 10 GB x 200 columns
 set -e
 mkdir -p gpurun_out

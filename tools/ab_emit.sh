@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the switches used here exist only in the experiments build: tools/build_experiments.sh)
+export ZDW_LIBDIR=${GRAFT_REPO_ROOT:-$PWD}/zdw_amd/lib_exp
 # A/B of the emit kernel's forms on the benchmark's table (stage_ms per variant)
 set -e
 mkdir -p gpurun_out

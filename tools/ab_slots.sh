@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the switches used here exist only in the experiments build: tools/build_experiments.sh)
+export ZDW_LIBDIR=${GRAFT_REPO_ROOT:-$PWD}/zdw_amd/lib_exp
 # A/B: size of the first dictionary table on the benchmark's table (10 GB): 2^25 (default cap) / 2^26 / 2^27 slots of 32 bytes
 set -e
 mkdir -p gpurun_out

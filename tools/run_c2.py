@@ -54,15 +54,17 @@ def ratios(capi):
     out = {}
     readme = {"movie_tickets": {"tsv": 32653800, "zdw": 18290691, "zdw_gz": 4365887, "zdw_xz": 2040472},
               "analytics-hits": {"tsv": 14468990, "zdw": 1303440, "zdw_gz": 312272, "zdw_xz": 227456}}
+    import shutil
     from tests import parity_util as pu
+    gzip_exe, xz_exe = shutil.which("gzip"), shutil.which("xz")          # (before the sandbox puts its `gzip` = cat in front of PATH)
     sb = pu.CliSandbox()
     try:
         for name in ("movie_tickets", "analytics-hits"):
             tsv, desc = rd(name + ".sql.xz"), rd(name + ".desc.sql")
             rc, z = sb.run(desc, tsv, args=["-q"])
             assert rc == 0
-            gz = subprocess.run(["gzip", "-6", "-c"], input=z, capture_output=True).stdout
-            xz = subprocess.run(["xz", "-6", "-c"], input=z, capture_output=True).stdout
+            gz = subprocess.run([gzip_exe, "-6", "-c"], input=z, capture_output=True).stdout
+            xz = subprocess.run([xz_exe, "-6", "-c"], input=z, capture_output=True).stdout
             r = readme[name]
             out[name] = {"tsv_bytes": len(tsv), "zdw_bytes": len(z), "zdw_gz_bytes": len(gz), "zdw_xz_bytes": len(xz),
                          "ratio_raw": round(len(tsv) / len(z), 3), "ratio_gz": round(len(tsv) / len(gz), 2), "ratio_xz": round(len(tsv) / len(xz), 2),

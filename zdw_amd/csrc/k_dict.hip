@@ -9,6 +9,7 @@
 // working set as soon as they are distinguished, so the later rounds touch only long shared
 // prefixes.  All integer work; bound by HBM traffic on (key,value) pairs.
 #include "zdw_dev.h"
+#include "zdw_knobs.h"
 #include "zdw_kernels.h"
 #include "zdw_dict_dev.h"
 
@@ -267,7 +268,7 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     uint32_t *group_next = tmp + n;
     for (uint32_t depth = 0; m > 1; ++depth) {
         ++rounds;
-        if (getenv("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] depth %u: m = %u of n = %u\n", depth, m, n);
+        if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] depth %u: m = %u of n = %u\n", depth, m, n);
         const uint32_t gb = (m + 255) / 256;
         uint64_t *keys = b.key_a, *keys_alt = b.key_b;
         uint32_t *vals = b.val_a, *vals_alt = b.val_b;

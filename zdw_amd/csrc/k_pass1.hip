@@ -29,6 +29,7 @@
 //   * pass 2 never re-reads the text: each field leaves a fixed-width record (u32 unique id + 1
 //     or u64 parsed value) in rec[row][column].
 #include "zdw_dev.h"
+#include "zdw_knobs.h"
 #include "zdw_kernels.h"
 #include "zdw_dict_dev.h"
 #include "zdw_field_dev.h"
@@ -301,7 +302,7 @@ void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_
 {
     if (!nspans) return;
     uint32_t cap = 256u * 24u;
-    if (const char *e = getenv("ZDW_SCAN_GRID")) cap = (uint32_t)atoi(e);      // tuning experiments
+    if (const char *e = experiment("ZDW_SCAN_GRID")) cap = (uint32_t)atoi(e);      // tuning experiments
     const uint32_t grid = nspans < cap ? nspans : cap;
     hipLaunchKernelGGL(k_count_row_starts, dim3(grid), dim3(64), 0, s, in, n, lo, hi, span0, nspans, span_shift, span_starts, st);
 }
@@ -393,6 +394,7 @@ struct WaveState {
     uint64_t vbase;              // visit base: absolute position = vbase + relative position (multiple of BYTE_RING)
     uint64_t row_start;          // absolute position where the row that is open at the head descriptor began (m_LongestLine candidates)
     IdAlloc ids;                 // this wave's chunk of unique ids
+    uint32_t rec_stride;         // Pass1Args.rec_stride, kept in a register (see k_pass1)
 };
 
 // Handles `cnt` (1..64) descriptors from the ring head, one per lane.  Returns how many new dictionary
@@ -625,7 +627,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         }
     }
     const bool fast = is_field && !slow;
-    uint8_t *recp = a.rec + (uint64_t)row * a.rec_stride + (meta >> 16);
+    uint8_t *recp = a.rec + (uint64_t)row * ws.rec_stride + (meta >> 16);
     bool is_new = false;
 
     // ---- text-like columns, <= 24 bytes: decided by one table slot.  The slot is REQUESTED here and looked at behind the integer fields
@@ -829,7 +831,13 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     }
     __syncthreads();
 
+    // Two arguments of the per-batch / per-round path that the compiler would otherwise read from the kernel-argument segment again
+    // wherever it is short of scalar registers (a scalar load and an lgkmcnt(0) wait -- which also waits for the wave's LDS
+    // operations -- in the middle of the loop): passed through an empty asm statement they are ordinary register values.
+    uint32_t rebase_at = a.rebase_at, hot_stride = a.rec_stride;
+    asm volatile("" : "+s"(rebase_at), "+s"(hot_stride));
     WaveState ws;
+    ws.rec_stride = hot_stride;
     ws.desc = L.desc + wv * QCAP * 4u;
     ws.bytes = L.bytes + wv * RING_STRIDE + RING_HEAD;
     ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.rel_se1 = 0; ws.first_pending = false; ws.vbase = 0;
@@ -1073,7 +1081,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                 const uint32_t ordA = ord_round + (exb2 & 0xffffu), ordB = ord_round + (totb2 & 0xffffu) + (exb2 >> 16);      // ordinals of this lane's first boundaries
                 ws.tok_ord += (totb2 & 0xffffu) + (totb2 >> 16);
                 near_end = relb + ROUND > ws.rel_se1 || relb + ROUND >= rel_hi;          // the span ends in this round or has ended: find the visit's end promptly
-                if (relb < a.rebase_at && ws.q_count + nb_total <= QCAP - 1) {
+                if (relb < rebase_at && ws.q_count + nb_total <= QCAP - 1) {
                     // the common round: everything fits
                     const uint32_t tail = ws.q_head + ws.q_count;
                     emit(mA, bA, ordA, lrel, tail + (ex2 & 0xffffu));
@@ -1087,7 +1095,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                         step = STEP_B;
                     }
                 } else {
-                    rebase = relb >= a.rebase_at;                                             // relative positions must stay below 2^31
+                    rebase = relb >= rebase_at;                                               // relative positions must stay below 2^31
                     piece = second ? (DENSE ? 4u : 0u) : 0u;                                  // (dense: the other chunk's mask is empty)
                     piece_stop = second ? 8u : 4u;
                     step = STEP_PIECE;                                                        // (first: everything that is pending)
@@ -1270,7 +1278,7 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     if ((size_t)per_cu > by_lds && by_lds >= 1) per_cu = (int)by_lds;
     if (per_cu > 16) per_cu = 16;                                               // workgroup slots per CU
     uint32_t max_blocks = (uint32_t)cus * (uint32_t)per_cu;
-    if (const char *e = getenv("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / P1_WPB;   // tuning experiments
+    if (const char *e = experiment("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / P1_WPB;   // tuning experiments
     const uint32_t want_blocks = (a.nspans + P1_WPB - 1) / P1_WPB;
     const uint32_t grid = want_blocks < max_blocks ? want_blocks : (max_blocks ? max_blocks : 1u);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * P1_WPB), lds, s, a);

@@ -19,6 +19,7 @@
 // Very narrow schemas: a row is handled by G = pow2 >= used columns adjacent lanes (64/G rows per wave):
 // flag bits come from one wave ballot, the byte position of each value from a G-lane prefix sum.
 #include "zdw_dev.h"
+#include "zdw_knobs.h"
 #include "zdw_kernels.h"
 
 #include <algorithm>
@@ -644,7 +645,7 @@ static void launch_pass2_sparse(const Pass2Args &a, hipStream_t s)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint64_t want = ((uint64_t)a.nrows + P2S_WAVES * P2S_ROWS - 1) / (P2S_WAVES * P2S_ROWS);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * 8);
-    if (a.nz_stride <= 64u * P2S_PIECES && !getenv("ZDW_P2S_NO_PRE")) hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT, true>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
+    if (a.nz_stride <= 64u * P2S_PIECES && !experiment("ZDW_P2S_NO_PRE")) hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT, true>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
     else hipLaunchKernelGGL((k_pass2_rows_sparse<EMIT, false>), dim3(grid), dim3(64 * P2S_WAVES), lds, s, a);
 }
 
@@ -659,7 +660,7 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
     // kernels: 32 columns 1.9 + 3.0 vs 0.85 + 2.1 ms (size + emit), 20: 2.9 + 4.5 vs 1.1 + 3.1, 16: 1.9 + 3.0 vs 1.4 + 3.8,
     // 9: 3.2 + 4.8 vs 2.2 + 6.3, 6: 2.7 + 3.8 vs 3.4 + 9.3.
     uint32_t min_cols = EMIT ? 17u : 8u;
-    if (const char *e = getenv("ZDW_P2_COLS_MIN")) min_cols = (uint32_t)atoi(e);      // (A/B measurements)
+    if (const char *e = test_hook("ZDW_P2_COLS_MIN")) min_cols = (uint32_t)atoi(e);      // (A/B measurements)
     // (the emit kernel's LDS image: 8 rows of output, or 4 when rows are very wide; the size kernel has none)
     const uint32_t size_tot_lds = P2_R_SIZE * p2_waves_per_batch((a.nused + 63) / 64) * ((a.nused + 63) / 64) * 2u;      // size kernel: u16 per (row, batch)
     if (a.nused >= min_cols && a.batch_pre && (EMIT ? 4u * a.out_row_max + 32u <= P2_LDS_BUDGET : size_tot_lds <= P2_LDS_BUDGET)) {
@@ -668,7 +669,7 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const uint32_t nbatch = (a.nused + 63) / 64;
-        const bool direct = getenv("ZDW_P2_DIRECT") != nullptr;      // (the variables here: A/B measurements)
+        const bool direct = test_hook("ZDW_P2_DIRECT") != nullptr;      // (the variables here: A/B measurements)
         if (!EMIT) {
             const uint32_t CR = P2_R_SIZE * p2_waves_per_batch(nbatch);          // rows per chunk
             const bool staged = !direct && p2_stage_bytes(CR, a.rec_stride) <= P2_STAGE_BUDGET;
@@ -680,7 +681,7 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
             // ... alone on the chip.  Beside the dictionary sort (second stream, ensure_dict) three leave the sort's launch-bound
             // kernels room: 10 GB, sort + sizes 3.6 + 1.6 ms with six (no better than one after the other), 3.2 + 3.9 with three
             if (a.background) per_cu = std::min(per_cu, 3u);
-            if (const char *e = getenv("ZDW_P2_SIZE_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
+            if (const char *e = experiment("ZDW_P2_SIZE_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
             if (staged) hipLaunchKernelGGL(k_pass2_size_cols<true>, dim3(grid), dim3(256), lds, s, a);
             else hipLaunchKernelGGL(k_pass2_size_cols<false>, dim3(grid), dim3(256), lds, s, a);
@@ -688,13 +689,13 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
             uint32_t R = 8;
             if (8u * a.out_row_max + 32u > P2_LDS_BUDGET) R = 4;     // very wide rows: fewer of them per chunk
             // (1000 columns, 4 GB: 8 rows straight from HBM 2.08 ms, 4 rows staged 2.78, G-lanes-per-row kernel 2.52)
-            if (const char *e = getenv("ZDW_P2_EMIT_ROWS")) R = atoi(e) == 16 ? 16u : (atoi(e) == 4 ? 4u : 8u);
+            if (const char *e = test_hook("ZDW_P2_EMIT_ROWS")) R = atoi(e) == 16 ? 16u : (atoi(e) == 4 ? 4u : 8u);
             uint32_t mode = 0, CR = R;                                  // rows per chunk
-            if (!direct && !getenv("ZDW_P2_EMIT_DIRECT") && p2_stage_bytes(R, a.rec_stride) <= P2_STAGE_BUDGET) {
+            if (!direct && !experiment("ZDW_P2_EMIT_DIRECT") && p2_stage_bytes(R, a.rec_stride) <= P2_STAGE_BUDGET) {
                 mode = 1;
                 const uint32_t CRp = R * p2_waves_per_batch(nbatch);
                 if (nbatch <= 4 && p2_stage_bytes(CRp, a.rec_stride) <= 4u * 4096u && CRp * a.out_row_max + 32u <= P2_LDS_BUDGET &&
-                    !getenv("ZDW_P2_EMIT_NOPIPE")) { mode = 2; CR = CRp; }
+                    !test_hook("ZDW_P2_EMIT_NOPIPE")) { mode = 2; CR = CRp; }
             }
             const uint64_t want = ((uint64_t)a.nrows + CR - 1) / CR;
             const uint32_t lds = ((CR * a.out_row_max + 32u + 15u) & ~15u) + (mode ? p2_stage_bytes(CR, a.rec_stride) : 0u);
@@ -706,7 +707,7 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
             // measured (10 GB x 200 columns): staged 8-row chunks 5 / 6 / 7 / 8 workgroups per CU = 5.5 / 4.9 / 4.5 / 6.7 ms
             uint32_t per_cu = std::min(mode ? 7u : 6u, (uint32_t)occ);
-            if (const char *e = getenv("ZDW_P2_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
+            if (const char *e = experiment("ZDW_P2_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a);
         }

@@ -2,6 +2,7 @@
 // gfx950 kernels for one ZDW block at a time.  Mirrors the per-block seam of
 // ConvertToZDW::processFile (cplusplus/ConvertToZDW.cpp:765-894).
 #include "../../include/zdw_hip.h"
+#include "zdw_knobs.h"
 #include "zdw_dev.h"
 #include "zdw_kernels.h"
 
@@ -30,7 +31,7 @@ struct Budget { size_t used = 0, cap = 0; };
 
 static double g_alloc_ms = 0.0;      // time inside hipMalloc / hipFree (ZDW_DEBUG_RETRY prints it)
 struct Lap {      // ZDW_DEBUG_LAPS=1: wall time between marks of one call, on stderr
-    const bool on = getenv("ZDW_DEBUG_LAPS") != nullptr;
+    const bool on = experiment("ZDW_DEBUG_LAPS") != nullptr;
     double t0 = 0, last = 0;
     std::string line;
     void mark(const char *what);
@@ -647,7 +648,7 @@ int ensure_dict(zdw_ctx *c)
     const uint64_t u = c->nids;
     // Pass 2's row lengths need the dictionary's SIZE (the width of text columns), not its order: they are computed on
     // the second stream while the strings are sorted on this one.  (A shard of a row-sharded block waits for its halo row.)
-    if (!c->have_prev && !getenv("ZDW_NO_OVERLAP")) { rc = start_pass2_size(c); if (rc) return rc; }
+    if (!c->have_prev && !experiment("ZDW_NO_OVERLAP")) { rc = start_pass2_size(c); if (rc) return rc; }
     {
         rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, c->dict_max_len);
         if (rc) return rc;
@@ -897,7 +898,7 @@ int prepare_pass2(zdw_ctx *c, Pass2Args &a, hipStream_t s = nullptr)
     if (c->nz_mode && !c->rec_dense) {
         // rows by the map of non-zero records (k_pass2_rows_sparse) when a row's candidates fit its LDS; else the whole matrix
         const size_t per_wave = (((size_t)nu * 2 + 15) & ~(size_t)15) + ((((size_t)nu + 7) / 8 + 15) & ~(size_t)15) + 16 + 1024;      // (k_pass2.hip: p2s_*_bytes)
-        if (per_wave * 4 <= 60 * 1024 && c->ncols <= 16384 && !getenv("ZDW_P2_DENSE")) {
+        if (per_wave * 4 <= 60 * 1024 && c->ncols <= 16384 && !test_hook("ZDW_P2_DENSE")) {
             // per schema column: which used column it is and that column's facts; then per used column its schema column
             std::vector<uint64_t> maps((size_t)c->ncols * 2 + (nu + 1) / 2, 0xFFFFFFull);
             uint32_t *ucol = reinterpret_cast<uint32_t *>(maps.data() + (size_t)c->ncols * 2);
@@ -1151,8 +1152,8 @@ int zdw_set_input_stream(zdw_ctx *c, zdw_read_fn read, void *user, uint64_t size
     InputStream *is = new (std::nothrow) InputStream;
     if (!is) return fail(c, ZDW_OUT_OF_MEMORY, "out of host memory");
     is->read = read; is->user = user; is->device = c->device; is->size_hint = size_hint;
-    if (const char *e = getenv("ZDW_STREAM_PIECE")) is->piece_bytes = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));      // tests
-    if (const char *e = getenv("ZDW_STREAM_CAP0")) is->first_cap = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));         // tests
+    if (const char *e = test_hook("ZDW_STREAM_PIECE")) is->piece_bytes = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));      // tests
+    if (const char *e = test_hook("ZDW_STREAM_CAP0")) is->first_cap = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));         // tests
     c->in_stream = is;
     c->d_in = nullptr; c->n = 0;
     c->input_open = true;
@@ -1175,7 +1176,7 @@ int zdw_set_input_host_async(zdw_ctx *c, const uint8_t *tsv, uint64_t len)
     is->host = tsv ? tsv : reinterpret_cast<const uint8_t *>("");
     is->device = c->device; is->size_hint = len;
     is->piece_bytes = std::min<uint64_t>(std::max<uint64_t>(len / 8, 64ull << 20), 1ull << 30);      // (a copy from pageable memory costs ~1 ms to start)
-    if (const char *e = getenv("ZDW_STREAM_PIECE")) is->piece_bytes = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));      // tests
+    if (const char *e = test_hook("ZDW_STREAM_PIECE")) is->piece_bytes = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));      // tests
     c->in_stream = is;
     c->d_in = nullptr; c->n = 0;
     c->input_open = true;
@@ -1223,7 +1224,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         c->model_max_slots = ms;
     }
     struct Unset { zdw_ctx *c; ~Unset() { c->model_max_slots = 0; } } unset{c};
-    const bool dbg = getenv("ZDW_DEBUG_RETRY") != nullptr;
+    const bool dbg = experiment("ZDW_DEBUG_RETRY") != nullptr;
     for (;;) {
         zdw_split_hint w = {window >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)window, 0};
         const double t0 = now_ms();
@@ -1242,7 +1243,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             c->model_rows_prev = row;
             // the rows beyond the end are taken back out of what pass 1 left (trim_block); ZDW_MODEL_RERUN=1 (tests) or an end
             // on the window's last row, which has no record: a second pass 1 up to exactly there instead
-            if (row < res->num_rows && !getenv("ZDW_MODEL_RERUN")) return trim_block(c, row, fields, row_start, res);
+            if (row < res->num_rows && !test_hook("ZDW_MODEL_RERUN")) return trim_block(c, row, fields, row_start, res);
             zdw_split_hint e = {row, fields};
             return pass1_impl(c, &e, res);
         }
@@ -1302,7 +1303,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     // read of the input less, -1.8 ms per 10 GB).  The record matrix is then sized from the bytes per row seen so far (the
     // input's first 64 KiB, or the block before) and a quarter more; a block that turns out to hold more rows is parsed again
     // the ordinary way.
-    bool fold = !(hint && hint->max_rows != 0xFFFFFFFFu) && !c->no_fold && !c->oom_seen && !getenv("ZDW_P1_NO_FOLD");
+    bool fold = !(hint && hint->max_rows != 0xFFFFFFFFu) && !c->no_fold && !c->oom_seen && !test_hook("ZDW_P1_NO_FOLD");
     uint64_t fold_rows_cap = 0;
     for (;;) {
     if (c->in_stream) { int rcs = stream_snapshot(c, need); if (rcs) return rcs; }
@@ -1332,7 +1333,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             const uint64_t avg_row = c->avg_row ? c->avg_row : 1;      // sampled once per input (after_input)
             while (span_shift < 20 && (1ull << span_shift) < 8 * avg_row && ((hi - lo) >> (span_shift + 1)) >= 16384) ++span_shift;
         }
-        if (const char *e = getenv("ZDW_SPAN_SHIFT")) span_shift = std::min(20u, std::max(12u, (uint32_t)atoi(e)));      // tests / tuning
+        if (const char *e = test_hook("ZDW_SPAN_SHIFT")) span_shift = std::min(20u, std::max(12u, (uint32_t)atoi(e)));      // tests / tuning
         span0 = lo >> span_shift;
         nspans = (uint32_t)(((hi + (1ull << span_shift) - 1) >> span_shift) - span0);
         if (fold) { total_rows = fold_rows_cap; break; }          // (what pass 1 may find; it says how many there were)
@@ -1389,7 +1390,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     // limit 5/8; a context remembers what its last block needed
     auto first_table = [&](uint32_t rows_in_block) {
         uint64_t ns = c->slots_opt;
-        if (const char *e = getenv("ZDW_DICT_SLOTS")) ns = strtoull(e, nullptr, 10);   // experiments
+        if (const char *e = test_hook("ZDW_DICT_SLOTS")) ns = strtoull(e, nullptr, 10);   // experiments
         if (!ns) {
             ns = 1ull << 14;
             // (the block's share of the remaining input, by rows)
@@ -1482,25 +1483,25 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 8 * 5, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
 #ifdef ZDW_EXPERIMENTS
-            if (const char *dbg = getenv("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
+            if (const char *dbg = experiment("ZDW_DEBUG_SKIP")) a.debug_skip = (uint32_t)atoi(dbg);
 #endif
             // the memory-limit model asks in which order the strings are first met: every occurrence takes part in a minimum
             a.track_first = (c->model_max_slots || c->track_first_opt) ? 1u : 0u;
-            if (const char *e = getenv("ZDW_P1_TRACK_FIRST")) a.track_first = atoi(e) != 0;      // tests
+            if (const char *e = test_hook("ZDW_P1_TRACK_FIRST")) a.track_first = atoi(e) != 0;      // tests
             if (a.track_first) HIP_TRY(c, hipMemsetAsync(c->uniq_pos.p, 0xFF, (uint64_t)c->id_cap * 8, s));
             a.dense_boundaries = c->dense_boundaries ? 1u : 0u;
-            if (const char *e = getenv("ZDW_P1_LARGE_RING")) a.dense_boundaries = atoi(e) != 0;      // tests
+            if (const char *e = test_hook("ZDW_P1_LARGE_RING")) a.dense_boundaries = atoi(e) != 0;      // tests
             a.skip_empty = c->skip_empty ? 1u : 0u;
-            if (const char *e = getenv("ZDW_P1_SKIP_EMPTY")) a.skip_empty = atoi(e) != 0;      // tests
+            if (const char *e = test_hook("ZDW_P1_SKIP_EMPTY")) a.skip_empty = atoi(e) != 0;      // tests
             a.rebase_at = a.skip_empty ? 1u << 23 : 1u << 30;              // (descriptors of that form hold 24 bits of position)
-            if (const char *e = getenv("ZDW_P1_REBASE_AT")) a.rebase_at = std::min(a.rebase_at, std::max(16384u, (uint32_t)strtoul(e, nullptr, 10)));   // tests
+            if (const char *e = test_hook("ZDW_P1_REBASE_AT")) a.rebase_at = std::min(a.rebase_at, std::max(16384u, (uint32_t)strtoul(e, nullptr, 10)));   // tests
             if ((a.dense_boundaries || a.skip_empty) && nrows) {
                 // mostly empty fields: pass 1 skips every empty field.  Either the record matrix is zeroed in one streaming write, or
                 // (the form for such tables) a map of a bit per field says where a record was written and pass 2 looks nowhere
                 // else: rows x columns / 8 bytes to clear instead of rows x ~6 x columns.
                 c->nz_stride = ((c->ncols + 31u) / 32u + 3u) & ~3u;
                 const uint64_t map_bytes = (uint64_t)nrows * c->nz_stride * 4u;
-                bool use_map = a.skip_empty && map_bytes <= (16ull << 30) && !getenv("ZDW_P1_NO_NZ");
+                bool use_map = a.skip_empty && map_bytes <= (16ull << 30) && !test_hook("ZDW_P1_NO_NZ");
                 if (use_map && c->nz.ensure(map_bytes + 64) != hipSuccess) use_map = false;
                 if (use_map) {
                     HIP_TRY(c, hipMemsetAsync(c->nz.p, 0, map_bytes, s));
@@ -1518,10 +1519,10 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             // remembers), up to one queue byte per input byte -- beyond that, or with a schema whose tables do
             // not fit LDS, the all-in-one kernel runs instead.  (10 GB x 200 columns with words of 4..32 / 4..96
             // characters: queue 19 / 27 ms, all-in-one 34 / 42 ms.)
-            const bool defer = lds_ranges && !c->p1_all_in_one && !getenv("ZDW_P1_ALL_IN_ONE");
+            const bool defer = lds_ranges && !c->p1_all_in_one && !test_hook("ZDW_P1_ALL_IN_ONE");
             if (defer) {
                 uint64_t dq_div = 256;
-                if (const char *e = getenv("ZDW_DQ_DIV")) dq_div = std::max<uint64_t>(8, strtoull(e, nullptr, 10));      // experiments
+                if (const char *e = experiment("ZDW_DQ_DIV")) dq_div = std::max<uint64_t>(8, strtoull(e, nullptr, 10));      // experiments
                 // (what earlier passes of this context queued per input byte, with a quarter to spare, when that is more)
                 const uint64_t by_rate = (uint64_t)((double)(hi - lo) * c->dq_rate * 1.25);
                 const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(std::max<uint64_t>((hi - lo) / dq_div + 65536, by_rate), c->dq_learned), 1ull << 31);
@@ -1535,7 +1536,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
                 HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
                 HIP_TRY(c, hipStreamSynchronize(s));
                 if (st.deferred_lost) {
-                    if (getenv("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] deferred queue of %u entries lost fields (%u queued): again\n", a.dq_cap, st.deferred);
+                    if (experiment("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] deferred queue of %u entries lost fields (%u queued): again\n", a.dq_cap, st.deferred);
                     const uint64_t need = (uint64_t)st.deferred + st.deferred / 8 + 65536;       // (a re-run hands out its chunks differently)
                     if (!dq_grown && need * 16 <= (hi - lo) + (64ull << 20) && need > a.dq_cap && need < (1ull << 31) && !st.overflow) {
                         c->dq_learned = need;
@@ -1560,14 +1561,14 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             if (st.nul_seen == 1) return fail(c, ZDW_UNKNOWN_ERROR, "input contains a NUL byte: not representable in ZDW (C strings)");
             if (st.fold_abort || (!st.overflow && (st.rows_total == 0 || st.rows_total - 1 > fold_rows_cap))) {
                 // more rows than the estimate left room for (or the count never came together): the ordinary way
-                if (getenv("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] %llu rows where %llu were expected: again, counting first\n", (unsigned long long)(st.rows_total ? st.rows_total - 1 : 0), (unsigned long long)fold_rows_cap);
+                if (experiment("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] %llu rows where %llu were expected: again, counting first\n", (unsigned long long)(st.rows_total ? st.rows_total - 1 : 0), (unsigned long long)fold_rows_cap);
                 c->no_fold = true;
                 return pass1_impl(c, hint, res);
             }
             if (!st.overflow) { total_rows = st.rows_total - 1; nrows = (uint32_t)total_rows; }
         }
         if (!st.overflow) break;
-        if (getenv("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] table of %llu slots overflowed (%u entries, %u ids of %u): again\n", (unsigned long long)nslots, st.entries, st.id_next, c->id_cap);
+        if (experiment("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] table of %llu slots overflowed (%u entries, %u ids of %u): again\n", (unsigned long long)nslots, st.entries, st.id_next, c->id_cap);
         if (c->model_max_slots && nslots >= c->model_max_slots && nrows > 1) {
             // The memory-limit model ends a block long before its dictionary needs a larger table than this: these rows hold
             // more strings than any block may -- look at half of them instead of growing the table.
@@ -1584,7 +1585,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
         if (c->model_max_slots && nslots > c->model_max_slots) nslots = c->model_max_slots;
         if (attempt > 12) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
     }
-    if (getenv("ZDW_DEBUG_RETRY")) { fprintf(stderr, "[pass1] %u rows, table %llu slots, %u entries; hipMalloc/hipFree so far %.1f ms\n", nrows, (unsigned long long)nslots, st.entries, g_alloc_ms); }
+    if (experiment("ZDW_DEBUG_RETRY")) { fprintf(stderr, "[pass1] %u rows, table %llu slots, %u entries; hipMalloc/hipFree so far %.1f ms\n", nrows, (unsigned long long)nslots, st.entries, g_alloc_ms); }
     c->nrows = nrows;
     if (c->nz_mode) c->nrows_written = nrows;      // (rows beyond the block's were not written)
     c->is_last = !tripped;
@@ -1932,7 +1933,7 @@ int zdw_shard_sort_uniques(zdw_ctx *c, uint64_t *count)
     HIP_TRY(c, hipStreamSynchronize(s));
     if (st.id_next > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", st.id_next, c->id_cap);
     const uint64_t u = st.id_next;
-    c->presorted = getenv("ZDW_SHARD_PRESORT") != nullptr;      // the first form of this path (A/B measurements): full sort of the own uniques
+    c->presorted = experiment("ZDW_SHARD_PRESORT") != nullptr;      // the first form of this path (A/B measurements): full sort of the own uniques
     if (!c->presorted) {
         // The owners sort; a shard only has to know which range each of its strings falls in (zdw_shard_partition).
         if (st.entries > u) return fail(c, ZDW_UNKNOWN_ERROR, "more dictionary entries (%u) than unique ids (%u)", st.entries, st.id_next);

@@ -18,6 +18,7 @@
 // "before" each tile of 64 rows per column (last flagged value per tile, carried across tiles in three small passes), text
 // lengths per row, prefix sum, text.
 #include "../../include/zdw_hip.h"
+#include "zdw_knobs.h"
 #include "zdw_dev.h"
 #include "zdw_kernels.h"
 
@@ -1017,11 +1018,11 @@ int zdw_dec_next_block(zdw_dec *d, zdw_dec_block *blk)
     if (text_bytes) {
         a.out = d->text.as<uint8_t>();
         const size_t shm = 4 * DEC_ROWBUF;
-        if (cbatch <= 8 && !getenv("ZDW_DEC_DIRECT")) {
+        if (cbatch <= 8 && !experiment("ZDW_DEC_DIRECT")) {
             // batches per wave: 10 GB x 200 columns, 1 / 2 / 4 per wave: 21.8 / 21.4 / 20.9 ms (the walk is not short of waves);
             // schemas of 5..8 batches take two groups of 4 (8 in one wave: 207 registers, 2 waves per SIMD)
             uint32_t nb = cbatch <= 1 ? 1u : cbatch <= 2 ? 2u : 4u;
-            if (const char *e = getenv("ZDW_DEC_GROUP")) { const int v = atoi(e); nb = v >= 8 ? 8u : v >= 4 ? 4u : v >= 2 ? 2u : 1u; }      // (A/B measurements)
+            if (const char *e = test_hook("ZDW_DEC_GROUP")) { const int v = atoi(e); nb = v >= 8 ? 8u : v >= 4 ? 4u : v >= 2 ? 2u : 1u; }      // (A/B measurements)
             while (nb > 1 && nb / 2 >= cbatch) nb /= 2;
             const uint32_t ngroups = (cbatch + nb - 1) / nb;
             const uint32_t g = grid_for(ntiles * ngroups);

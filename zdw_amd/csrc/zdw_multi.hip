@@ -15,6 +15,7 @@
 // Transport: RCCL (ncclCommInitAll, grouped point-to-point) when the devices are distinct; when the same device is
 // listed more than once (tests on a one-GPU box) the same exchange runs as device-to-device copies.
 #include "../../include/zdw_hip.h"
+#include "zdw_knobs.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and prototypes only: the library is loaded on first use (below)
@@ -236,7 +237,7 @@ int zdw_multi_create(const uint8_t *col_types, uint32_t ncols, const zdw_opts *o
     m->ncols = ncols;
     m->sh.resize(ndev);
     std::set<int> distinct(devices, devices + ndev);
-    const char *tr = getenv("ZDW_MULTI_TRANSPORT");      // "copy": device-to-device copies even between distinct devices (A/B measurements)
+    const char *tr = zdw::experiment("ZDW_MULTI_TRANSPORT");      // "copy": device-to-device copies even between distinct devices (A/B measurements)
     m->use_rccl = distinct.size() == ndev && !(tr && !strcmp(tr, "copy"));
     for (uint32_t i = 0; i < ndev; ++i) {
         Shard &s = m->sh[i];
