@@ -121,6 +121,21 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
     if (!EMIT && row_ok && sub == 0) a.row_len[row] = nflag + running;
 }
 
+// Records stream through once and the rows leave once: non-temporal loads and stores, so that they do not push the dictionary offsets
+// (id_off: the emit kernel's gather, a few KB of it hot) out of the CU's vector L1.
+typedef uint32_t p2_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 stream_load16(const uint8_t *p)
+{
+    const p2_u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const p2_u32x4 *>(p));
+    return make_uint4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ void stream_store16(uint8_t *p, const uint4 &v)
+{
+    p2_u32x4 x;
+    x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    __builtin_nontemporal_store(x, reinterpret_cast<p2_u32x4 *>(p));
+}
+
 // ------------------------------------------------------------------------------------------
 // column kernels: a wave owns 64 columns of (its share of) a chunk of rows
 // ------------------------------------------------------------------------------------------
@@ -177,7 +192,7 @@ __device__ __forceinline__ uint32_t stage_chunk(const Pass2Args &a, uint8_t *sta
     const uint32_t nbytes = mis + (row0 + rows - first) * a.rec_stride;        // from the aligned start
     const uint8_t *src16 = src - mis;
     for (uint32_t o = threadIdx.x * 16u; o < nbytes; o += 256u * 16u)
-        *reinterpret_cast<uint4 *>(stage + o) = *reinterpret_cast<const uint4 *>(src16 + o);     // may run up to 15 bytes past the piece: the matrix has slack
+        *reinterpret_cast<uint4 *>(stage + o) = stream_load16(src16 + o);     // may run up to 15 bytes past the piece: the matrix has slack
     return mis + (row0 - first) * a.rec_stride;
 }
 // a record field from the staged copy (fields sit at multiples of 4)
@@ -309,7 +324,7 @@ __device__ __forceinline__ void copy_image_out(const Pass2Args &a, const uint8_t
     const uint32_t endb = shift + nbytes;
     for (uint32_t o = threadIdx.x * 16u; o < endb; o += 256u * 16u) {
         if (o >= shift && o + 16u <= endb) {
-            *reinterpret_cast<uint4 *>(gdst + o) = *reinterpret_cast<const uint4 *>(img + o);
+            stream_store16(gdst + o, *reinterpret_cast<const uint4 *>(img + o));
         } else {
             const uint32_t lo = o > shift ? o : shift, hi = o + 16u < endb ? o + 16u : endb;
             for (uint32_t k = lo; k < hi; ++k) gdst[k] = img[k];
@@ -418,10 +433,10 @@ __global__ __launch_bounds__(256, P2_R <= 8 ? 7 : 4) void k_pass2_emit_cols_pipe
         const uint8_t *src16 = src - mis;
         uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0;
         const uint32_t o0 = threadIdx.x * 16u;
-        if (o0 < sbytes) g0 = *reinterpret_cast<const uint4 *>(src16 + o0);
-        if (o0 + 4096u < sbytes) g1 = *reinterpret_cast<const uint4 *>(src16 + o0 + 4096u);
-        if (o0 + 8192u < sbytes) g2 = *reinterpret_cast<const uint4 *>(src16 + o0 + 8192u);
-        if (o0 + 12288u < sbytes) g3 = *reinterpret_cast<const uint4 *>(src16 + o0 + 12288u);
+        if (o0 < sbytes) g0 = stream_load16(src16 + o0);
+        if (o0 + 4096u < sbytes) g1 = stream_load16(src16 + o0 + 4096u);
+        if (o0 + 8192u < sbytes) g2 = stream_load16(src16 + o0 + 8192u);
+        if (o0 + 12288u < sbytes) g3 = stream_load16(src16 + o0 + 12288u);
         ro = more ? load_ro(ncrow0, ncrows, nrows_w) : 0ull;
         pre = (more && have && lane < nrows_w) ? a.batch_pre[(uint64_t)(ncrow0 + r0 + lane) * nbatch + b] : 0u;
 
