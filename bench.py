@@ -457,7 +457,8 @@ def main():
         res = {
             "metric": "TSV->ZDW encode throughput (input bytes / wall time, input resident in HBM, raw .zdw left in HBM)",
             "value": round(total_in / 1e6 / (dt / args.steps), 1), "unit": "MB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "n_gpus": world, "comm_ranks": (dist.get_world_size() if (world > 1 or force_dist) else 1),      # ranks of the RCCL communicator the step ran on
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
             "config": {"workload": "synthetic TSV %.1f GB x %d cols %s, mixed VARCHAR/LONG, Zipf(1.1) strings over 2^20 words, 25%% empty, 30%% repeat (BASELINE configs[3])"
                                    % ((total_in if args.scaling == "strong" else nbytes) / 1e9, args.cols,

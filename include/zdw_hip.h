@@ -290,6 +290,9 @@ void zdw_multi_destroy(zdw_multi *m);
 const char *zdw_multi_last_error(const zdw_multi *m);   /* m may be NULL: last zdw_multi_create error */
 /* cuts the image into ndev pieces at row boundaries and copies piece i to device i; tsv must stay valid until zdw_multi_encode returns */
 int zdw_multi_set_input_host(zdw_multi *m, const uint8_t *tsv, uint64_t len);
+/* the same for pieces that already lie on the devices: piece i (whole rows, 16-byte aligned, lens[i] bytes) on device i, in row order;
+ * nothing is copied and the buffers must stay valid until the next input or zdw_multi_destroy */
+int zdw_multi_set_input_device(zdw_multi *m, const void *const *d_pieces, const uint64_t *lens);
 /* the next block of the input.  With zdw_opts.mem_limit_mb the input's blocks end where the reference's end (the model of its memory
  * limit walked over the node-wide dictionary, see zdw_shard_model_walk); is_last_block = 0 then says that zdw_multi_next + another
  * zdw_multi_encode give the block behind it.  num_rows = 0 with is_last_block = 1: the input holds no (more) rows. */

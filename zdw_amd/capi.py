@@ -121,6 +121,7 @@ def lib():
         L.zdw_multi_last_error.argtypes = [vp]
         L.zdw_multi_last_error.restype = C.c_char_p
         L.zdw_multi_set_input_host.argtypes = [vp, vp, C.c_uint64]
+        L.zdw_multi_set_input_device.argtypes = [vp, C.POINTER(vp), u64p]
         L.zdw_multi_encode.argtypes = [vp, C.POINTER(MultiBlock)]
         L.zdw_multi_stats.argtypes = [vp, u8p, u64p, u32p]
         L.zdw_dec_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -180,6 +181,16 @@ class MultiEncoder:
         else:
             self._keep = data
             rc = self.L.zdw_multi_set_input_host(self.h, C.c_void_p(data.ctypes.data), data.size)
+        if rc:
+            raise ZdwError(rc, self.error())
+
+    def set_input_device(self, pieces, keepalive=None):
+        """pieces: [(device pointer, bytes)] -- piece i lies on device i (whole rows, 16-byte aligned), in row order; nothing is copied"""
+        n = len(pieces)
+        ptrs = (C.c_void_p * n)(*[p for p, _ in pieces])
+        lens = (C.c_uint64 * n)(*[l for _, l in pieces])
+        self._keep = keepalive
+        rc = self.L.zdw_multi_set_input_device(self.h, ptrs, lens)
         if rc:
             raise ZdwError(rc, self.error())
 

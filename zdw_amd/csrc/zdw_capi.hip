@@ -1256,13 +1256,78 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     }
 }
 
-static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *res)
+// One pass 1 over the current block, in four steps (a job per call; what the steps share are its members):
+//   window_and_rows   which bytes of the image the block may take, and how many rows start in them (the row scan -- or, for a block
+//                     that takes all that is left, an estimate: pass 1 then counts its own rows)
+//   buffers           the block's row limit; record matrix, first dictionary table, list of long rows
+//   parse             the kernels, run again with a larger table / queue / fewer rows until the block fits
+//   results           what the block is: rows, end, line buffer, column ranges
+// P1_COUNT_FIRST: a pass that counted its own rows cannot go on (more rows than estimated, no room for its matrix): the job is run
+// again with a row scan in front (c->no_fold is set).
+constexpr int P1_COUNT_FIRST = -1;
+
+struct Pass1Job {
+    zdw_ctx *c;
+    const zdw_split_hint *hint;
+    zdw_pass1_result *res;
+    hipStream_t s = nullptr;
+    Lap lap;
+    uint64_t lo = 0, hi = 0, total_rows = 0, span0 = 0, fold_rows_cap = 0, nslots = 0;
+    uint32_t nspans = 0, span_shift = SPAN_SHIFT_MIN, row_limit = 0xFFFFFFFFu, partial = 0, nrows = 0, long_cap = 0;
+    bool fold = false, tripped = false, lds_ranges = false;
+    P1Status st{};
+
+    int window_and_rows();
+    int buffers();
+    int parse();
+    int results();
+    bool fewer_rows();
+    uint64_t first_table(uint32_t rows_in_block);
+};
+
+// Buffers that grow with the block's rows (records, dictionary table): when the device (or zdw_opts.max_device_bytes)
+// cannot hold them the block ends earlier -- half the rows, again if need be -- instead of failing; the reference ends
+// a block for the same reason, memory, at a point that depends on the machine (Q9).
+bool Pass1Job::fewer_rows()
+{
+    if (fold) return false;      // (a matrix sized from an estimate did not fit: count the rows first after all)
+    if (nrows < 2) return false;
+    nrows /= 2; tripped = true; row_limit = nrows; partial = 0;
+    return true;
+}
+
+// dictionary table (32-byte slots): one slot per 32 input bytes, within [2^14, 2^25] (1 GiB); load factor
+// limit 5/8; a context remembers what its last block needed
+uint64_t Pass1Job::first_table(uint32_t rows_in_block)
+{
+    uint64_t ns = c->slots_opt;
+    if (const char *e = test_hook("ZDW_DICT_SLOTS")) ns = strtoull(e, nullptr, 10);   // experiments
+    if (!ns) {
+        ns = 1ull << 14;
+        // (the block's share of the remaining input, by rows)
+        const uint64_t bytes = total_rows ? (uint64_t)((double)(hi > lo ? hi - lo : 0) * rows_in_block / (double)total_rows) : 0;
+        // (a window of the memory-limit model that holds 2 GB of slots' worth of input: a table of 2^26 -- blocks of id-like
+        // columns reach the limit at tens of millions of strings, and a table that overflows is a second pass 1 over the window;
+        // the larger table costs the benchmark's table 0.1 ms: tools/ab_slots.sh)
+        const uint64_t cap = (c->model_max_slots && bytes / 32 >= (1ull << 26)) ? (1ull << 26) : (1ull << 25);
+        while (ns < bytes / 32 && ns < cap) ns <<= 1;
+        if (c->slots_learned > ns && rows_in_block >= c->rows_learned) ns = c->slots_learned;
+        // what the rows of this input have held so far, per row (load limit 5/8, 15 % to spare)
+        const double est = (double)rows_in_block * c->entries_per_row * 1.6 * 1.15;
+        while ((double)ns < est && ns < (1ull << 31)) ns <<= 1;
+        if (c->model_max_slots && ns > c->model_max_slots) ns = c->model_max_slots;
+    }
+    uint64_t p2 = 1;
+    while (p2 < ns) p2 <<= 1;
+    return p2;
+}
+
+int Pass1Job::window_and_rows()
 {
     memset(res, 0, sizeof *res);
     if (!c->have_input) return fail(c, ZDW_UNKNOWN_ERROR, "no input set");
     (void)hipSetDevice(c->device);
-    hipStream_t s = c->stream;
-    Lap lap;
+    s = c->stream;
     lap.mark("start");
     reset_block(c);
     if (c->oom_seen) {
@@ -1273,8 +1338,8 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             if (b != &c->in_owned && b != &c->d_kind && b != &c->d_recoff && b != &c->d_numidx) b->release();
         c->oom_seen = false;
     }
-    const uint64_t lo = c->lo;
-    uint64_t hi = 0;
+    lo = c->lo;
+    hi = 0;
     // a block that is run again (smaller split hint after an oversized dictionary) starts from the line buffer the block
     // began with: rows that move to the next block must not have grown it
     if (c->row_cap_block_lo == lo) c->row_cap = c->row_cap_block;
@@ -1287,9 +1352,9 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     HIP_TRY(c, c->d_scalar.ensure(64));
     if (c->in_stream && c->n == 0) { int rc0 = stream_snapshot(c, 1); if (rc0) return rc0; }      // (the row length below comes from the first bytes)
 
-    uint64_t total_rows = 0;
-    uint32_t nspans = 0, span_shift = SPAN_SHIFT_MIN;
-    uint64_t span0 = 0;
+    total_rows = 0;
+    nspans = 0; span_shift = SPAN_SHIFT_MIN;
+    span0 = 0;
     // A caller that wants max_rows rows does not need the rows of everything that is left counted (a file of many blocks: the
     // sum over its blocks of what is left): the image is looked at as far as those rows should reach, by the bytes per row seen so
     // far and a quarter more, and twice as far again while that turns out too short.
@@ -1303,8 +1368,8 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     // read of the input less, -1.8 ms per 10 GB).  The record matrix is then sized from the bytes per row seen so far (the
     // input's first 64 KiB, or the block before) and a quarter more; a block that turns out to hold more rows is parsed again
     // the ordinary way.
-    bool fold = !(hint && hint->max_rows != 0xFFFFFFFFu) && !c->no_fold && !c->oom_seen && !test_hook("ZDW_P1_NO_FOLD");
-    uint64_t fold_rows_cap = 0;
+    fold = !(hint && hint->max_rows != 0xFFFFFFFFu) && !c->no_fold && !c->oom_seen && !test_hook("ZDW_P1_NO_FOLD");
+    fold_rows_cap = 0;
     for (;;) {
     if (c->in_stream) { int rcs = stream_snapshot(c, need); if (rcs) return rcs; }
     hi = c->hi;
@@ -1361,56 +1426,27 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     }
     break;
     }
+    return ZDW_OK;
+}
+
+int Pass1Job::buffers()
+{
     c->next_lo = c->n;
     if (total_rows >= 0xFFFFFFFFull) return fail(c, ZDW_UNKNOWN_ERROR, "more than 2^32-2 rows in one block");
     lap.mark("scan");
 
-    uint32_t row_limit = 0xFFFFFFFFu, partial = 0;
-    bool tripped = false;
+    row_limit = 0xFFFFFFFFu; partial = 0;
+    tripped = false;
     if (hint && hint->max_rows != 0xFFFFFFFFu && hint->max_rows < total_rows) {
         tripped = true; row_limit = hint->max_rows; partial = hint->partial_fields;
     }
-    uint32_t nrows = tripped ? row_limit : (uint32_t)total_rows;
-    // Buffers that grow with the block's rows (records, dictionary table): when the device (or zdw_opts.max_device_bytes)
-    // cannot hold them the block ends earlier -- half the rows, again if need be -- instead of failing; the reference ends
-    // a block for the same reason, memory, at a point that depends on the machine (Q9).
-    bool fold_gave_up = false;      // (a matrix sized from an estimate did not fit: count the rows first after all)
-    auto fewer_rows = [&]() {
-        if (fold) { fold_gave_up = true; return false; }
-        if (nrows < 2) return false;
-        nrows /= 2; tripped = true; row_limit = nrows; partial = 0;
-        return true;
-    };
+    nrows = tripped ? row_limit : (uint32_t)total_rows;
 
     // ---- pass 1 proper (also runs for zero rows when a partial row pollutes the block) ----
     // column facts and ranges live in per-wave LDS when they fit there (and in the packed 14 + 16 bit form)
-    const bool lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) - pass1_lds_bytes(c->ncols, c->nnum, false) <= 40 * 1024 &&
+    lds_ranges = pass1_lds_bytes(c->ncols, c->nnum, true) - pass1_lds_bytes(c->ncols, c->nnum, false) <= 40 * 1024 &&
                             c->nnum < 16384 && c->rec_stride < 65536;
-    // dictionary table (32-byte slots): one slot per 32 input bytes, within [2^14, 2^25] (1 GiB); load factor
-    // limit 5/8; a context remembers what its last block needed
-    auto first_table = [&](uint32_t rows_in_block) {
-        uint64_t ns = c->slots_opt;
-        if (const char *e = test_hook("ZDW_DICT_SLOTS")) ns = strtoull(e, nullptr, 10);   // experiments
-        if (!ns) {
-            ns = 1ull << 14;
-            // (the block's share of the remaining input, by rows)
-            const uint64_t bytes = total_rows ? (uint64_t)((double)(hi > lo ? hi - lo : 0) * rows_in_block / (double)total_rows) : 0;
-            // (a window of the memory-limit model that holds 2 GB of slots' worth of input: a table of 2^26 -- blocks of id-like
-            // columns reach the limit at tens of millions of strings, and a table that overflows is a second pass 1 over the window;
-            // the larger table costs the benchmark's table 0.1 ms: tools/ab_slots.sh)
-            const uint64_t cap = (c->model_max_slots && bytes / 32 >= (1ull << 26)) ? (1ull << 26) : (1ull << 25);
-            while (ns < bytes / 32 && ns < cap) ns <<= 1;
-            if (c->slots_learned > ns && rows_in_block >= c->rows_learned) ns = c->slots_learned;
-            // what the rows of this input have held so far, per row (load limit 5/8, 15 % to spare)
-            const double est = (double)rows_in_block * c->entries_per_row * 1.6 * 1.15;
-            while ((double)ns < est && ns < (1ull << 31)) ns <<= 1;
-            if (c->model_max_slots && ns > c->model_max_slots) ns = c->model_max_slots;
-        }
-        uint64_t p2 = 1;
-        while (p2 < ns) p2 <<= 1;
-        return p2;
-    };
-    uint64_t nslots = first_table(nrows);
+    nslots = first_table(nrows);
     HIP_TRY(c, c->col_min.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_max.ensure(c->ncols * 8 + 8)); HIP_TRY(c, c->col_seen.ensure(c->ncols + 8));
     if (c->model_max_slots && !c->model_rows_prev && tripped) {
         // The first window of an input whose blocks the memory-limit model ends: the next block's window is a quarter larger (room for that and some more).
@@ -1420,16 +1456,21 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     for (;;) {
         const hipError_t e = c->rec.ensure((uint64_t)nrows * c->rec_stride + 64);      // slack: 8-byte reads of 4-byte fields, 16-byte staging reads
         if (e == hipSuccess) break;
-        if (e == hipErrorOutOfMemory && fold) { c->no_fold = true; return pass1_impl(c, hint, res); }
+        if (e == hipErrorOutOfMemory && fold) { c->no_fold = true; return P1_COUNT_FIRST; }
         if (e != hipErrorOutOfMemory || !fewer_rows())
             return fail(c, e == hipErrorOutOfMemory ? ZDW_OUT_OF_MEMORY : ZDW_UNKNOWN_ERROR, "record matrix of %llu bytes: %s",
                         (unsigned long long)nrows * c->rec_stride, hipGetErrorString(e));
     }
     lap.mark("rec_alloc");
     const uint64_t blk_bytes = hi > lo ? hi - lo : 0;
-    const uint32_t long_cap = (uint32_t)std::min<uint64_t>(blk_bytes / (FIRST_ROW_CAP - 1) + 2, 1u << 26);
+    long_cap = (uint32_t)std::min<uint64_t>(blk_bytes / (FIRST_ROW_CAP - 1) + 2, 1u << 26);
     HIP_TRY(c, c->long_rows.ensure((uint64_t)long_cap * sizeof(LongRow)));
-    P1Status st{};
+    return ZDW_OK;
+}
+
+int Pass1Job::parse()
+{
+    st = P1Status{};
     bool dq_grown = false;
     int reruns = 0;                  // re-runs that reset `attempt`: bounded on their own
     for (int attempt = 0;; ++attempt) {
@@ -1438,7 +1479,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             hipError_t e = nslots > (1ull << 31) ? hipErrorOutOfMemory : c->slots.ensure(nslots * 32);
             if (e == hipSuccess) e = c->uniq_pos.ensure(cap * 8);
             if (e == hipSuccess) e = c->uniq_len.ensure(cap * 4);
-            if (e == hipErrorOutOfMemory && fold) { c->no_fold = true; return pass1_impl(c, hint, res); }
+            if (e == hipErrorOutOfMemory && fold) { c->no_fold = true; return P1_COUNT_FIRST; }
             if (e == hipErrorOutOfMemory) {
                 // no room for a table of this block's uniques: fewer rows, fewer uniques (and a smaller record matrix)
                 if (!fewer_rows()) return fail(c, ZDW_OUT_OF_MEMORY, "no room for a dictionary table of %llu slots; split the block", (unsigned long long)nslots);
@@ -1563,7 +1604,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
                 // more rows than the estimate left room for (or the count never came together): the ordinary way
                 if (experiment("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] %llu rows where %llu were expected: again, counting first\n", (unsigned long long)(st.rows_total ? st.rows_total - 1 : 0), (unsigned long long)fold_rows_cap);
                 c->no_fold = true;
-                return pass1_impl(c, hint, res);
+                return P1_COUNT_FIRST;
             }
             if (!st.overflow) { total_rows = st.rows_total - 1; nrows = (uint32_t)total_rows; }
         }
@@ -1574,7 +1615,7 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
             // more strings than any block may -- look at half of them instead of growing the table.
             if (!fewer_rows()) {
                 // (pass 1 was counting its own rows, so there is no row count to halve: count first, the ordinary way)
-                if (fold) { c->no_fold = true; return pass1_impl(c, hint, res); }
+                if (fold) { c->no_fold = true; return P1_COUNT_FIRST; }
                 return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table of %llu slots overflows on a single row", (unsigned long long)nslots);
             }
             if (++reruns > 40) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
@@ -1586,6 +1627,11 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
         if (attempt > 12) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table keeps overflowing");
     }
     if (experiment("ZDW_DEBUG_RETRY")) { fprintf(stderr, "[pass1] %u rows, table %llu slots, %u entries; hipMalloc/hipFree so far %.1f ms\n", nrows, (unsigned long long)nslots, st.entries, g_alloc_ms); }
+    return ZDW_OK;
+}
+
+int Pass1Job::results()
+{
     c->nrows = nrows;
     if (c->nz_mode) c->nrows_written = nrows;      // (rows beyond the block's were not written)
     c->is_last = !tripped;
@@ -1634,6 +1680,20 @@ static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *
     lap.done("pass1_impl");
     if (tripped && nrows == 0) return fail(c, ZDW_OUT_OF_MEMORY, "block limit leaves no room for a single row");
     return ZDW_OK;
+}
+
+static int pass1_impl(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *res)
+{
+    for (int round = 0; round < 3; ++round) {
+        Pass1Job job{c, hint, res};
+        int rc = job.window_and_rows();
+        if (rc == ZDW_OK) rc = job.buffers();
+        if (rc == ZDW_OK) rc = job.parse();
+        if (rc == ZDW_OK) rc = job.results();
+        if (rc != P1_COUNT_FIRST) return rc;
+        c->no_fold = true;          // again, with the rows counted first
+    }
+    return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 keeps asking for a row count");
 }
 
 int zdw_block_dict_device(zdw_ctx *c, const void **d_section, uint64_t *section_len, uint8_t *index_size)

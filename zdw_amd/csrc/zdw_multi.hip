@@ -295,6 +295,27 @@ int zdw_multi_set_input_host(zdw_multi *m, const uint8_t *tsv, uint64_t len)
     return first_failure(m, "loading the input");
 }
 
+// The same for pieces that already lie on the devices (piece i on device i, 16-byte aligned, whole rows, in row order): nothing is
+// copied, the contexts borrow the buffers until the next input.
+int zdw_multi_set_input_device(zdw_multi *m, const void *const *d_pieces, const uint64_t *lens)
+{
+    if (!m || !d_pieces || !lens) return m ? mfail(m, ZDW_UNKNOWN_ERROR, "zdw_multi_set_input_device: bad arguments") : ZDW_UNKNOWN_ERROR;
+    const size_t n = m->sh.size();
+    m->image = nullptr; m->image_len = 0; m->encoded = false; m->finished = false; m->first = 0; m->longest_line = 16384;
+    uint64_t at = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Shard &s = m->sh[i];
+        s.p1_valid = false;
+        s.in_off = at; s.in_len = lens[i];
+        at += lens[i];
+        (void)hipSetDevice(s.device);
+        s.rc = zdw_set_input_device(s.ctx, d_pieces[i], lens[i]);
+        if (s.rc) s.err = zdw_last_error(s.ctx);
+    }
+    m->image_len = at;
+    return first_failure(m, "taking the input");
+}
+
 // One block of the input (ConvertToZDW.cpp:765-894 is the reference's loop over them).  The shards that still hold rows take part as
 // requesters; every shard owns a key range of the block's dictionary.  Under a memory limit the dictionary exchange pauses in the
 // middle: the owners say which occurrence of every string is the first node-wide, the shards walk the reference's arenas over
@@ -310,14 +331,30 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     const size_t n = m->sh.size();
     const uint32_t nc = m->ncols;
     const bool limited = m->mem_limit_mb > 0.0;
-    const size_t first = m->first, last = n - 1;            // the requesters: shards that still hold rows
+    const size_t first = m->first;                          // the requesters: shards first .. last (those that still hold rows, as far as
+    size_t last = n - 1;                                    // the block can reach)
     int rc = ZDW_OK;
+    // Under a memory limit not every shard that still holds rows has to take part: the block ends where the dictionary has grown to the
+    // limit, so the shards are taken in row order until their strings -- counted as if none were shared: an upper bound of what the
+    // block's dictionary holds -- reach twice the limit.  If the limit then does not trip among them (they share more than
+    // expected), twice as many take part in a second attempt; the shards' pass 1 is kept either way.
+    size_t window = limited ? 1 : n;
+    bool tripped = false;
+    size_t end_shard = 0, bad_shard = n;
+    uint64_t rows_before_bad = 0;
+    uint32_t trip_row = 0, trip_fields = 0;
+    uint64_t trip_row_start = 0, trip_gpos = ~0ull;
+    std::vector<std::vector<uint64_t>> cnt, back;
+    std::vector<uint64_t> sent;
+    bool maybe = false;
+    for (;; window *= 2) {
+    last = std::min(n - 1, first + window - 1);
 
     // ---- pass 1 on every requester that has none yet for the rows it still holds ----
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
         s.rc = 0;
-        if (i < first || s.p1_valid) return;
+        if (i < first || i > last || s.p1_valid) return;
         s.rc = zdw_block_pass1(s.ctx, nullptr, &s.p1);
         if (s.rc) s.err = zdw_last_error(s.ctx); else s.p1_valid = true;
     });
@@ -326,15 +363,15 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     for (size_t i = first; i <= last; ++i)
         if (!m->sh[i].p1.is_last_block) return mfail(m, ZDW_OUT_OF_MEMORY, "shard %zu does not fit its device as one block: use more devices or the one-GPU path", i);
     // the first row with a wrong field count, if any (the shards do not fail on one: the block may end before it)
-    size_t bad_shard = n;
-    uint64_t rows_before_bad = 0;
+    bad_shard = n;
+    rows_before_bad = 0;
     for (size_t i = first; i <= last; ++i) {
         if (m->sh[i].p1.bad_row) { bad_shard = i; break; }
         rows_before_bad += m->sh[i].p1.num_rows;
     }
 
     // ---- can the limit trip at all?  (all shards' strings as if none were shared: an upper bound) ----
-    bool maybe = false;
+    maybe = false;
     if (limited) {
         uint64_t entries = 0, bytes = 0;
         uint32_t max_len = 0;
@@ -345,7 +382,9 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
             if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
             entries += e; bytes += b; max_len = std::max(max_len, ml);
         }
-        maybe = zdw_model_upper_bound_mb(entries, bytes, max_len) >= m->mem_limit_mb;
+        const double ub = zdw_model_upper_bound_mb(entries, bytes, max_len);
+        maybe = ub >= m->mem_limit_mb;
+        if (last < n - 1 && ub < 2.0 * m->mem_limit_mb) continue;      // too few strings to be sure the block ends among these shards: more of them
     }
 
     // ---- dictionary, range-partitioned: the strings travel to the owners of their key ranges ----
@@ -370,13 +409,14 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
             splitters.push_back(k.first); splitters.push_back(k.second);
         }
     }
-    std::vector<std::vector<uint64_t>> cnt(n, std::vector<uint64_t>(n, 0)), nby(n, std::vector<uint64_t>(n, 0));
+    cnt.assign(n, std::vector<uint64_t>(n, 0));
+    std::vector<std::vector<uint64_t>> nby(n, std::vector<uint64_t>(n, 0));
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
         s.counts.assign(n, 0); s.nbytes.assign(n, 0);
         s.d_lens = s.d_bytes = s.d_pos = nullptr;
         s.rc = 0;
-        if (i < first) return;                  // no rows left here: sends nothing
+        if (i < first || i > last) return;      // no rows left here, or rows the block cannot reach: sends nothing
         s.rc = zdw_shard_partition(s.ctx, (uint32_t)n, splitters.data(), s.counts.data(), s.nbytes.data(), &s.d_lens, &s.d_bytes);
         if (!s.rc && maybe) s.rc = zdw_shard_positions(s.ctx, s.in_off, &s.d_pos);
         if (s.rc) s.err = zdw_last_error(s.ctx);
@@ -384,7 +424,8 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     rc = first_failure(m, "partitioning the dictionary");
     if (rc) return rc;
     for (size_t q = 0; q < n; ++q) for (size_t r = 0; r < n; ++r) { cnt[q][r] = m->sh[q].counts[r]; nby[q][r] = m->sh[q].nbytes[r]; }
-    std::vector<uint64_t> rc_cnt(n, 0), rc_by(n, 0), sent(n, 0);      // what every owner receives, what every requester sent
+    std::vector<uint64_t> rc_cnt(n, 0), rc_by(n, 0);                  // what every owner receives, what every requester sent
+    sent.assign(n, 0);
     for (size_t r = 0; r < n; ++r) for (size_t q = 0; q < n; ++q) { rc_cnt[r] += cnt[q][r]; rc_by[r] += nby[q][r]; sent[q] += cnt[q][r]; }
     {
         std::vector<const void *> src_l(n), src_b(n), src_p(n);
@@ -408,7 +449,7 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     rc = first_failure(m, "building a dictionary range");
     if (rc) return rc;
     // what travels back to the requesters, owner r -> requester q: cnt[q][r] words in the order q sent its strings (range by range)
-    std::vector<std::vector<uint64_t>> back(n, std::vector<uint64_t>(n));
+    back.assign(n, std::vector<uint64_t>(n));
     for (size_t r = 0; r < n; ++r) for (size_t q = 0; q < n; ++q) back[r][q] = cnt[q][r];
     auto words_back = [&](const std::vector<const void *> &src) -> int {
         std::vector<void *> dst(n);
@@ -422,10 +463,8 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     };
 
     // ---- where does the block end? ----
-    size_t end_shard = last;                    // the shard that holds the block's last row
-    bool tripped = false;
-    uint32_t trip_row = 0, trip_fields = 0;
-    uint64_t trip_row_start = 0, trip_gpos = ~0ull;
+    end_shard = last;                           // the shard that holds the block's last row
+    tripped = false;
     if (maybe) {
         std::vector<const void *> src(n);
         for_shards(m, [&](size_t i) {
@@ -450,6 +489,18 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
             if (found) { tripped = true; end_shard = i; trip_gpos = s.in_off + pos; }
         }
     }
+    if (tripped || last == n - 1) break;       // the block ends among these shards, or takes all the rows that are left
+    }                                           // (else: the limit does not trip among them: twice as many shards)
+    auto words_back = [&](const std::vector<const void *> &src) -> int {
+        std::vector<void *> dst(n);
+        for (size_t i = 0; i < n; ++i) {
+            Shard &s = m->sh[i];
+            const int r2 = grow(m, s.device, &s.d_back, &s.cap_back, sent[i] * 4 + 16);
+            if (r2) return r2;
+            dst[i] = s.d_back;
+        }
+        return all_to_all_v(m, src, dst, back, 4);
+    };
     if (bad_shard < n) {
         // the reference meets the rows in order: it reports the bad row unless the block ends before it (ConvertToZDW.cpp:336-338)
         const uint32_t bad0 = m->sh[bad_shard].p1.bad_row - 1;

@@ -675,49 +675,67 @@ def encode_blocks_dist(port, rank, world, nbytes, mem_limit_mb, group=None, devi
             raise capi.ZdwError(rc or max(a[0] for a in info), "pass 1 failed on a rank")
         rows_of = [a[1] for a in info]
         bad_rank = next((r for r in range(first, world) if info[r][2]), None)
-        maybe = bool(mem_limit_mb) and capi.model_upper_bound_mb(sum(a[3] for a in info), sum(a[4] for a in info), max(a[5] for a in info)) >= mem_limit_mb
-
-        # ---- the strings travel to the owners of their key ranges ----
-        mine = _guarded(lambda: port.sample_keys(SAMPLES_PER_SHARD) if rank >= first else [], device, group, "sampling the dictionary")
-        flat = [_u64_to_i64(w) for k in mine for w in k] + [0] * (2 * SAMPLES_PER_SHARD - 2 * len(mine))
-        allk = allgather_i64([len(mine)] + flat, device, group=group)
-        samples = [(_i64_to_u64(a[1 + 2 * i]), _i64_to_u64(a[2 + 2 * i])) for a in allk for i in range(a[0])]
-        splitters = pick_splitters(samples, world)
-        if rank >= first:
-            counts, nb, lens, byts, pos = _guarded(lambda: port.partition(splitters, bases[rank], maybe), device, group, "partitioning the dictionary")
-        else:
-            _guarded(lambda: None, device, group, "partitioning the dictionary")
-            counts, nb = [0] * world, [0] * world
-            lens, byts = torch.empty(0, dtype=torch.int32, device=device), torch.empty(0, dtype=torch.uint8, device=device)
-            pos = torch.empty(0, dtype=torch.int64, device=device) if maybe else None
-        rcounts, rbytes = exchange_counts(counts, device, group, nb)
-        got_lens = alltoallv(lens, counts, rcounts, group=group)
-        got_byts = alltoallv(byts, nb, rbytes, group=group)
-        got_pos = alltoallv(pos, counts, rcounts, group=group) if maybe else None
-        _guarded(lambda: port.owner_import(got_lens, got_byts, got_pos), device, group, "building a dictionary range")
-
-        # ---- where does the block end? ----
-        end, trip = world - 1, None
-        if maybe:
-            flags = _guarded(port.owner_first_flags, device, group, "first occurrences")
-            my_flags = alltoallv(flags, rcounts, counts, group=group)
-            state = (0, 0, 0)
-            for i in range(first, world):                      # in row order: the state goes from rank to rank
-                msg = [0] * 9
-                if rank == i:
-                    try:
-                        state, hit = port.model_walk(my_flags, mem_limit_mb, state)
-                        msg = [0] + list(state) + ([1] + list(hit) if hit else [0, 0, 0, 0, 0])
-                    except capi.ZdwError as e:
-                        msg[0] = e.code or 20
-                msg = broadcast_i64(msg, i, device, group=group)
-                if msg[0]:
-                    raise capi.ZdwError(msg[0], "the block-limit walk failed on rank %d" % i)
-                state = tuple(msg[1:4])
-                if msg[4]:
-                    trip = (msg[5], msg[6], msg[7], bases[i] + msg[8])      # row, fields, row_start (in rank i's image), position in the input
-                    end = i
+        # Not every rank that still holds rows has to send its strings: the block ends where the dictionary has grown to the limit, so
+        # the ranks are taken in row order until their strings -- counted as if none were shared, an upper bound -- reach twice the
+        # limit; if the limit then does not trip among them, twice as many take part in a second attempt (csrc/zdw_multi.hip does
+        # the same).  Every rank computes the same window from the gathered counts.
+        window = 1 if mem_limit_mb else world
+        while True:
+            while True:
+                last = min(world - 1, first + window - 1)
+                ub = capi.model_upper_bound_mb(sum(a[3] for a in info[first:last + 1]), sum(a[4] for a in info[first:last + 1]),
+                                               max(a[5] for a in info[first:last + 1])) if mem_limit_mb else 0.0
+                if not mem_limit_mb or last == world - 1 or ub >= 2.0 * mem_limit_mb:
                     break
+                window *= 2
+            maybe = bool(mem_limit_mb) and ub >= mem_limit_mb
+            sends = first <= rank <= last
+            bad_rank = next((r for r in range(first, last + 1) if info[r][2]), None)
+
+            # ---- the strings travel to the owners of their key ranges ----
+            mine = _guarded(lambda: port.sample_keys(SAMPLES_PER_SHARD) if sends else [], device, group, "sampling the dictionary")
+            flat = [_u64_to_i64(w) for k in mine for w in k] + [0] * (2 * SAMPLES_PER_SHARD - 2 * len(mine))
+            allk = allgather_i64([len(mine)] + flat, device, group=group)
+            samples = [(_i64_to_u64(a[1 + 2 * i]), _i64_to_u64(a[2 + 2 * i])) for a in allk for i in range(a[0])]
+            splitters = pick_splitters(samples, world)
+            if sends:
+                counts, nb, lens, byts, pos = _guarded(lambda: port.partition(splitters, bases[rank], maybe), device, group, "partitioning the dictionary")
+            else:
+                _guarded(lambda: None, device, group, "partitioning the dictionary")
+                counts, nb = [0] * world, [0] * world
+                lens, byts = torch.empty(0, dtype=torch.int32, device=device), torch.empty(0, dtype=torch.uint8, device=device)
+                pos = torch.empty(0, dtype=torch.int64, device=device) if maybe else None
+            rcounts, rbytes = exchange_counts(counts, device, group, nb)
+            got_lens = alltoallv(lens, counts, rcounts, group=group)
+            got_byts = alltoallv(byts, nb, rbytes, group=group)
+            got_pos = alltoallv(pos, counts, rcounts, group=group) if maybe else None
+            _guarded(lambda: port.owner_import(got_lens, got_byts, got_pos), device, group, "building a dictionary range")
+
+            # ---- where does the block end? ----
+            end, trip = last, None
+            if maybe:
+                flags = _guarded(port.owner_first_flags, device, group, "first occurrences")
+                my_flags = alltoallv(flags, rcounts, counts, group=group)
+                state = (0, 0, 0)
+                for i in range(first, last + 1):                   # in row order: the state goes from rank to rank
+                    msg = [0] * 9
+                    if rank == i:
+                        try:
+                            state, hit = port.model_walk(my_flags, mem_limit_mb, state)
+                            msg = [0] + list(state) + ([1] + list(hit) if hit else [0, 0, 0, 0, 0])
+                        except capi.ZdwError as e:
+                            msg[0] = e.code or 20
+                    msg = broadcast_i64(msg, i, device, group=group)
+                    if msg[0]:
+                        raise capi.ZdwError(msg[0], "the block-limit walk failed on rank %d" % i)
+                    state = tuple(msg[1:4])
+                    if msg[4]:
+                        trip = (msg[5], msg[6], msg[7], bases[i] + msg[8])      # row, fields, row_start (in rank i's image), position in the input
+                        end = i
+                        break
+            if trip is not None or last == world - 1:
+                break                                          # the block ends among these ranks, or takes all the rows that are left
+            window *= 2                                        # (else: the limit does not trip among them: twice as many ranks)
         if bad_rank is not None:
             # the reference meets the rows in order: it reports the bad row unless the block ends before it (ConvertToZDW.cpp:336-338)
             bad0 = info[bad_rank][2] - 1
