@@ -75,7 +75,15 @@ constexpr uint32_t LUT_ROWS = 25;                 // byte masks "first L bytes" 
 // tables of mostly empty fields (a round of such data holds 1000+), whose boundaries are then emitted chunk by chunk
 // (~540 each).  What still does not fit is emitted in 16-lane pieces (<= 256 boundaries each), the ring drained in between.
 constexpr uint32_t QCAP_SMALL = 512, QCAP_LARGE = 1024;
-constexpr uint32_t DESC_POS = 0xffffffu;          // a descriptor's position bits (relative to the visit; the visit moves its base before they run out)
+constexpr uint32_t DESC_POS = 0xffffffu;
+// descriptors that may stay pending behind a chunk A / behind a round (the fields of what stays are handled a step later, while the
+// next chunk travels)
+#ifndef P1_KEEP_AFTER_A
+#define P1_KEEP_AFTER_A 63u
+#endif
+#ifndef P1_KEEP_AFTER_B
+#define P1_KEEP_AFTER_B 127u
+#endif          // a descriptor's position bits (relative to the visit; the visit moves its base before they run out)
 
 // ------------------------------------------------------------------------------------------
 // per-lane byte classes of 16 bytes
@@ -1054,7 +1062,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                 else ws.ring_lo = relb > ROUND + first_rel ? relb - ROUND : first_rel;                                         // ... now [relb - 2048, relb + 2048)
                 if (!second && !DENSE) {
                     mA = mN; bA = bN;
-                    keep = 63;
+                    keep = P1_KEEP_AFTER_A;
                     step = STEP_B;
                 } else {
                 if (second) { mB = mN; bB = bN; if (DENSE) { mA = 0; bA = 0; } } else { mA = mN; bA = bN; mB = 0; bB = 0; }
@@ -1087,7 +1095,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                     emit(mA, bA, ordA, lrel, tail + (ex2 & 0xffffu));
                     emit(mB, bB, ordB, lrel + WROUND, tail + totA + (ex2 >> 16));
                     ws.q_count += nb_total;
-                    keep = near_end ? 0u : 127u;
+                    keep = near_end ? 0u : P1_KEEP_AFTER_B;
                     if (second) {
                         relb += ROUND; lane_ptr += ROUND;
                         step = relb < rel_hi ? STEP_A : STEP_END;
@@ -1130,7 +1138,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
                      inB ? lrel + WROUND : lrel, ws.q_head + ws.q_count + ex - piece_base);
                 ws.q_count += piece_end - piece_base;
                 if (++piece == piece_stop) {
-                    keep = near_end ? 0u : 127u;
+                    keep = near_end ? 0u : P1_KEEP_AFTER_B;
                     if (piece_stop == 8u) {
                         relb += ROUND; lane_ptr += ROUND;
                         step = relb < rel_hi ? STEP_A : STEP_END;
