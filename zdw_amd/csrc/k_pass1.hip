@@ -413,8 +413,13 @@ template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP, bool TRACK>
 __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables &t, const DictTable &d, const P1Lds &L, WaveState &ws, uint32_t cnt,
                                             uint32_t lane)
 {
+    // How this function is written.  What a lane IS (a line end, a field, a text field still looking for its slot ...) is kept as
+    // a 64-bit LANE MASK in scalar registers, not as a bool per lane: masks come from ballots of single comparisons (a v_cmp that
+    // writes the scalar pair directly), are combined on the scalar unit, and become the exec mask of a block with lane_in().
+    // A bool that is changed inside a branch and looked at behind it costs a v_cndmask and a v_cmp per use instead (it lives in a
+    // vector register as 0 / 1), and this kernel is bound by the vector ALU's issue rate (profiles/r03_valu_issue_rate.txt).
     constexpr uint32_t QM = QCAP * 4u - 1u;
-    const bool live = lane < cnt;
+    const uint64_t livem = mask_lt((int)cnt);
     const uint32_t di = ws.q_head + lane;
     // a descriptor: position of the boundary (24 bits, relative to the visit) | its ordinal among the visit's boundaries (8 bits).
     // Tabs that directly follow a boundary -- empty fields -- have no descriptor (the tokeniser drops them): the ordinals of two
@@ -426,58 +431,56 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // the boundary before mine: my left neighbour's, lane 0: the last one of the batch before (one DPP move, no second LDS read)
     uint32_t pdsc = (uint32_t)__builtin_amdgcn_update_dpp((int)(SKIP ? ws.last_e | (ws.last_ord << 24) : ws.last_e), (int)dsc, DPP_WAVE_SHR1, 0xf, 0xf, false);
     uint32_t pe_pos = SKIP ? pdsc & DESC_POS : pdsc;
-    uint32_t n_prev = (SKIP && live) ? ((dsc >> 24) - (pdsc >> 24) - 1u) & 0xffu : 0u;      // empty fields skipped between that boundary and my field
-    bool far_me = SKIP && ws.far && lane == 0;                           // my field begins behind a boundary too far back for a descriptor
+    uint32_t n_prev = 0u;                                               // empty fields skipped between that boundary and my field
+    if (SKIP) n_prev = lane_in(livem) ? ((dsc >> 24) - (pdsc >> 24) - 1u) & 0xffu : 0u;
+    uint64_t farm = (SKIP && ws.far) ? 1ull : 0ull;                     // lanes whose field begins behind a boundary too far back for a descriptor
     const uint32_t d_last = lane_value(dsc, (int)cnt - 1);
     const uint32_t e_last = SKIP ? d_last & DESC_POS : d_last;
     // ---- what kind of boundary is mine?  The tokeniser only said "a tab or a newline": the byte itself and the one
     // ---- before it (a backslash?) come from the byte ring
     const uint32_t ea = ws.bytes + (e_pos & (BYTE_RING - 1u));
     const uint32_t be = zdw_lds[ea], bp = zdw_lds[ea - 1u];
-    // (predicates are combined with & and |: no short-circuit branches around loads in this path)
-    const bool at_sentinel = ws.first_pending & (lane == 0);           // (its byte may lie before anything the visit loaded)
-    bool e_nl = live & ((be == '\n') | at_sentinel);
-    bool dead = !live;                   // takes no part: beyond cnt, escaped, foreign, past the end of the visit
-    uint32_t sent_lane = ws.first_pending ? 0u : 64u;                   // the lane whose line end precedes the visit's first row
+    uint64_t sentm = ws.first_pending ? 1ull : 0ull;                    // the lane whose line end precedes the visit's first row (its byte may lie before anything the visit loaded)
+    uint64_t nlm = (BAL(be == '\n') | sentm) & livem;                   // line ends that count
+    uint64_t deadm = ~livem;             // takes no part: beyond cnt, escaped, foreign, past the end of the visit
     uint64_t vm = 0;                     // escaped separators of this batch
     // Anything out of the ordinary in this batch?  A backslash in front of a boundary, a boundary whose bytes the ring no
     // longer holds, a visit that has not found its first row yet, the end of the span: all rare, all in one branch.
-    const bool odd = live & !at_sentinel & ((bp == '\\') | (e_pos <= ws.ring_lo));
-    const uint64_t oddm = __ballot(odd);
+    const uint64_t oddm = (BAL(bp == '\\') | BAL(e_pos <= ws.ring_lo)) & livem & ~sentm;
     if ((oddm != 0) | ws.ignoring | (e_last >= ws.rel_se1)) {
         if (oddm) {
             // exact: the byte and the parity of the backslash run before it, from the image (Q1, Q4: special iff an even
             // number of backslashes precedes)
-            bool esc = false;
-            if (odd) {
+            uint32_t esc = 0, nl = 0;
+            if (lane_in(oddm)) {
                 const uint64_t p = ws.vbase + e_pos;
                 const uint8_t *img = COLD(in);
-                const bool nl = img[p] == '\n';
-                esc = (backslashes_before(img, COLD(lo), p) & 1u) != 0;
-                e_nl = nl && !esc;
-                if (esc) dead = true;
+                nl = img[p] == '\n' ? 1u : 0u;
+                esc = backslashes_before(img, COLD(lo), p) & 1u;
             }
-            vm = __ballot(esc);           // (the loads have landed before anything below looks at their values)
+            vm = BAL(esc != 0u);          // (the loads have landed before anything below looks at their values)
+            nlm = (nlm & ~oddm) | (BAL(nl != 0u) & ~vm);
+            deadm |= vm;
         }
         // a visit that began inside a row of the span before: that row's end is the line end before our first row
         if (ws.ignoring) {
-            const uint64_t nl0 = __ballot(e_nl);
-            if (!nl0) { ws.last_e = e_last; ws.last_ord = d_last >> 24; ws.far = false; return 0; }                 // all of it foreign
-            sent_lane = (uint32_t)lowest_bit(nl0);
-            if (lane < sent_lane) { dead = true; e_nl = false; }
+            if (!nlm) { ws.last_e = e_last; ws.last_ord = d_last >> 24; ws.far = false; return 0; }                 // all of it foreign
+            const int s = lowest_bit(nlm);
+            sentm = 1ull << s;
+            deadm |= mask_lt(s);
             ws.ignoring = false;
         }
         // the visit ends with the first line end at or past the last byte of its span
-        const uint64_t endm = __ballot(e_nl && lane != sent_lane && e_pos >= ws.rel_se1);
+        const uint64_t endm = nlm & ~sentm & BAL(e_pos >= ws.rel_se1);
         if (endm) {
-            if (lane > (uint32_t)lowest_bit(endm)) { dead = true; e_nl = false; }
+            const uint64_t after = ~mask_le(lowest_bit(endm));
+            deadm |= after; nlm &= ~after;
             ws.done = true;
         }
     }
-    const uint64_t nlm = __ballot(e_nl);                               // line ends that count
     uint32_t fs = pe_pos + 1u + n_prev;                                 // a field begins one byte after the boundary before it and the tabs dropped behind that
     uint32_t raw_len, len, row, col;
-    bool in_block, is_field;
+    uint64_t fieldm, inblkm;             // lanes that hold a field of the table / whose row belongs to the block
     if (nlm == 0 && vm == 0 && !ws.first_pending) {
         // The common batch: 64 fields of one row, nothing out of the ordinary -- no line end, so no row ends, no blank line, no
         // sentinel: the row is the wave's, the column counts on.  (Seven in ten batches of the benchmark's table, nineteen in
@@ -485,27 +488,29 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         raw_len = len = e_pos - fs;
         row = ws.row_cur;
         if (SKIP) {
-            const uint32_t incl = wave_incl_sum(dead ? 0u : n_prev + 1u);      // columns: one per field, skipped ones included
+            const uint32_t incl = wave_incl_sum(lane_in(deadm) ? 0u : n_prev + 1u);      // columns: one per field, skipped ones included
             col = ws.col_cur + incl - 1u;
             ws.col_cur += lane_value(incl, 63);
         } else {
             col = ws.col_cur + lane;
             ws.col_cur += cnt;
         }
-        in_block = row < a.row_limit;
-        is_field = !dead & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) & !P1_ABLATE(a, 1u);
+        const bool in_block = ws.row_cur < a.row_limit;                 // (one row: the same for every lane)
+        inblkm = in_block ? ~0ull : 0ull;
+        fieldm = ~deadm & BAL(col < a.ncols);
+        if (!in_block) fieldm = ws.row_cur == a.row_limit ? fieldm & BAL(col < a.partial_fields) : 0ull;
         ws.prev_nl = false;
         ws.last_e = e_last; ws.last_ord = d_last >> 24;
         ws.far = false;
     } else {
-    const bool sentinel = lane == sent_lane;
-    uint32_t pnl = wave_shr1(e_nl ? 1u : 0u);                           // the boundary before mine is a line end?
-    if (lane == 0) pnl = ws.prev_nl ? 1u : 0u;
+    uint64_t pnlm = (nlm << 1) | (ws.prev_nl ? 1ull : 0ull);            // the boundary before mine is a line end
     uint64_t realm = 0;                                                 // (vm != 0 only) boundaries that count
     if (vm) {
         // rare: separators of this batch are escaped -- my field begins after the last boundary that counts
-        realm = __ballot(!dead);
+        realm = ~deadm;
+        uint32_t pnl = lane_in(pnlm) ? 1u : 0u, farv = lane_in(farm) ? 1u : 0u;
         const uint64_t before = realm & mask_lt((int)lane);
+        const bool dead = lane_in(deadm);
         if (!dead && before) {
             const int p = highest_bit(before);
             if ((uint32_t)p + 1u != lane) {
@@ -515,30 +520,31 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 if (SKIP) n_prev = ((dsc >> 24) - (pdsc >> 24) - 1u - (lane - (uint32_t)p - 1u)) & 0xffu;
                 fs = pe_pos + 1u + n_prev;
                 pnl = (uint32_t)(nlm >> p) & 1u;
-                far_me = false;
+                farv = 0u;
             }
         } else if (!dead && lane > 0) {                                 // none in this batch: the one before the batch
             pe_pos = ws.last_e;
             if (SKIP) n_prev = ((dsc >> 24) - ws.last_ord - 1u - lane) & 0xffu;
             fs = pe_pos + 1u + n_prev;
             pnl = ws.prev_nl ? 1u : 0u;
-            far_me = SKIP && ws.far;
+            farv = (SKIP && ws.far) ? 1u : 0u;
         }
+        pnlm = BAL(pnl != 0u);
+        if (SKIP) farm = BAL(farv != 0u);
     }
-    if (sentinel) n_prev = 0u;
+    if (SKIP) { if (lane_in(sentm)) n_prev = 0u; }
     raw_len = len = e_pos - fs;
-    const bool blank = e_nl & (pnl != 0) & (len == 0) & (n_prev == 0u) & !sentinel;    // line end right after a line end: no row (getnextrow.cpp:38-43)
-    const bool ends_row = e_nl & !blank & !sentinel;
+    uint64_t blankm = nlm & pnlm & ~sentm & BAL(len == 0u);             // line end right after a line end: no row (getnextrow.cpp:38-43)
+    if (SKIP) blankm &= BAL(n_prev == 0u);
+    const uint64_t rm = nlm & ~blankm & ~sentm;                         // line ends that end a row
     // columns: every boundary that counts ends a field, and n_prev more (empty ones) lie in front of it; a line end starts over
     uint32_t incl = 0, incl_all = 0, incl_at_last_nl = 0;
     if (SKIP) {
-        incl = wave_incl_sum((dead | sentinel) ? 0u : n_prev + 1u);
+        incl = wave_incl_sum(lane_in(deadm | sentm) ? 0u : n_prev + 1u);
         incl_all = lane_value(incl, 63);
     }
     row = ws.row_cur; col = SKIP ? ws.col_cur + incl - 1u : ws.col_cur + lane;
-    uint64_t rm = 0;
     if (nlm) {
-        rm = __ballot(ends_row);
         row += mbcnt64(rm);
         const uint64_t prev = nlm & mask_lt((int)lane);
         if (SKIP) {
@@ -556,9 +562,11 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             const uint32_t e_prev = (uint32_t)__shfl((int)e_pos, prev ? highest_bit(prev) : 0, 64);      // (every lane takes part in the exchange)
             const uint64_t start = prev ? ws.vbase + e_prev + 1 : ws.row_start;
             const uint64_t rl = ws.vbase + e_pos + 1 - start;
-            if (e_nl && !sentinel && rl >= FIRST_ROW_CAP - 1) {
-                const uint32_t li = atomicAdd(&COLD(st)->long_count, 1u);
-                if (li < COLD(long_cap)) { LongRow *lr = COLD(long_rows); lr[li].start = start; lr[li].len = rl; }
+            if (lane_in(nlm & ~sentm)) {
+                if (rl >= FIRST_ROW_CAP - 1) {
+                    const uint32_t li = atomicAdd(&COLD(st)->long_count, 1u);
+                    if (li < COLD(long_cap)) { LongRow *lr = COLD(long_rows); lr[li].start = start; lr[li].len = rl; }
+                }
             }
         }
         ws.row_start = abs_h + 1;
@@ -569,14 +577,15 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         col = prev ? popc64(before & ~mask_le(highest_bit(prev))) : ws.col_cur + popc64(before);
     }
     if (rm) {
-        if (ends_row && row <= a.row_limit) {
-            if (col + 1 != a.ncols) atomicMin(&COLD(st)->bad_row, row);          // ConvertToZDW.cpp:336-337
-            if (row + 1 == a.row_limit) COLD(st)->split_pos = ws.vbase + e_pos + 1;  // the next block starts after this row
+        if (lane_in(rm)) {
+            if (row <= a.row_limit) {
+                if (col + 1 != a.ncols) atomicMin(&COLD(st)->bad_row, row);          // ConvertToZDW.cpp:336-337
+                if (row + 1 == a.row_limit) COLD(st)->split_pos = ws.vbase + e_pos + 1;  // the next block starts after this row
+            }
         }
     }
-    in_block = row < a.row_limit;
-    is_field = !dead & !sentinel & !blank & (col < a.ncols) & (in_block | ((row == a.row_limit) & (col < a.partial_fields))) &
-               !P1_ABLATE(a, 1u);
+    inblkm = BAL(row < a.row_limit);
+    fieldm = ~deadm & ~sentm & ~blankm & BAL(col < a.ncols) & (inblkm | (BAL(row == a.row_limit) & BAL(col < a.partial_fields)));
     // state for the next call
     ws.row_cur += popc64(rm);
     if (SKIP) ws.col_cur = nlm ? incl_all - incl_at_last_nl : ws.col_cur + incl_all;
@@ -597,16 +606,17 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     }
     ws.first_pending = false;
     }
+    if (P1_ABLATE(a, 1u)) fieldm = 0;
 
     // tables of mostly empty fields: the record matrix was zeroed beforehand (one streaming write instead of a scattered 4- or
     // 8-byte store per empty field), so an empty field -- no record but zero, no range, no string (ConvertToZDW.cpp:340-341) -- is done
     // (SKIP: the empty fields in front of mine have no descriptor of their own; the record matrix was zeroed before the launch)
     constexpr bool MAY_BE_ZEROED = SKIP || QCAP == QCAP_LARGE;      // (only the forms for tables of mostly empty fields run on a zeroed matrix: launch_pass1)
-    if (MAY_BE_ZEROED && a.rec_zeroed) is_field = is_field & (raw_len != 0);
+    if (MAY_BE_ZEROED && a.rec_zeroed) fieldm &= BAL(raw_len != 0u);
     // a field that begins further back than a descriptor can say (the visit moved its base past its start): the general form
     uint64_t abs_start = ws.vbase + fs;
-    if (SKIP && __ballot(far_me)) {
-        if (far_me) {
+    if (SKIP && farm) {
+        if (lane_in(farm)) {
             abs_start = ws.far_abs + 1u + n_prev;
             const uint64_t l64 = ws.vbase + e_pos - abs_start;
             if (l64 >= (1ull << 30)) { COLD(st)->nul_seen = 2; }            // a single field of 1 GiB or more
@@ -614,13 +624,15 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         }
     }
     uint32_t meta = 0;
-    if (is_field && t.cols_in_lds) meta = lds_u32(t.meta + 4u * col);
+    if (t.cols_in_lds) { if (lane_in(fieldm)) meta = lds_u32(t.meta + 4u * col); }
     const uint32_t kind = meta & 3u;
-    bool slow = is_field && (!t.cols_in_lds || fs < ws.ring_lo || far_me);      // (a.trim == TRIM: launch_pass1 picks the kernel by it)
+    // fields for the general form (a.trim == TRIM: launch_pass1 picks the kernel by it)
+    uint64_t slowm = t.cols_in_lds ? fieldm & (BAL(fs < ws.ring_lo) | farm) : fieldm;
     const uint32_t ra = ws.bytes + (fs & (BYTE_RING - 1u));
     if (TRIM) {
-        if (is_field && !slow && len) {
-            if (len > 32u) slow = true;                   // beyond what the byte ring's tail copy lets this path read in one piece
+        uint32_t general = 0;
+        if (lane_in(fieldm & ~slowm & BAL(len != 0u))) {
+            if (len > 32u) general = 1u;                  // beyond what the byte ring's tail copy lets this path read in one piece
             else {
                 // blanks at the end of the field: its last 8 bytes (or what precedes it, never counted: k <= len)
                 uint32_t tw[2];
@@ -629,27 +641,32 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 const uint64_t f = (((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & 0x8080808080808080ull;      // bit 7 of a byte: it is no blank
                 uint32_t k = f ? (uint32_t)__builtin_clzll(f) >> 3 : 8u;
                 if (k > len) k = len;
-                if (k == 8u && len > 8u) slow = true;       // there may be more of them: general form
+                if (k == 8u && len > 8u) general = 1u;      // there may be more of them: general form
                 else len -= k;
             }
         }
+        slowm |= BAL(general != 0u);
     }
-    const bool fast = is_field && !slow;
+    const uint64_t fastm = fieldm & ~slowm;
     uint8_t *recp = a.rec + (uint64_t)row * ws.rec_stride + (meta >> 16);
-    bool is_new = false;
+    uint64_t newm = 0;                   // lanes whose string was new to the dictionary
 
     // ---- text-like columns, <= 24 bytes: decided by one table slot.  The slot is REQUESTED here and looked at behind the integer fields
     // ---- of the batch (other lanes), whose records are stored behind that wait too: between the request and the wait the wave issues no
     // ---- other memory instruction, so the wait is for the probe alone (and for what was in flight long before it).
-    bool ft = fast && kind == K_TEXT;
-    if (ft && len > 24u) { slow = true; ft = false; }
-    const uint64_t ftm = __ballot(ft);
+    const uint64_t textm = BAL(kind == K_TEXT);
+    uint64_t ftm = fastm & textm;
+    {
+        const uint64_t longm = ftm & BAL(len > 24u);
+        slowm |= longm; ftm &= ~longm;
+    }
     uint32_t t_id = 0;
-    bool pending = false;
+    uint64_t pendm = 0;                  // text fields that have not found their slot yet
     uint64_t c0 = 0, c1 = 0, c2 = 0, acc = 0, slot_i = 0;
     SlotLoad w0;
     if (ftm) {
-        if (ft && len) {                                                          // empty fields are skipped (:340-341)
+        const uint64_t wantm = ftm & BAL(len != 0u);                              // empty fields are skipped (:340-341)
+        if (lane_in(wantm)) {
             if (!zdw_lds[t.seen + col]) zdw_lds[t.seen + col] = 1;
             const uint32_t lo = L.lut + 32u * len;
             uint32_t fw[6];
@@ -657,24 +674,28 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             c0 = u64_of(fw[0], fw[1]) & lds_u64(lo); c1 = u64_of(fw[2], fw[3]) & lds_u64(lo + 8); c2 = u64_of(fw[4], fw[5]) & lds_u64(lo + 16);
             acc = nh24(c0, c1, c2);
             slot_i = hash_place(acc) & a.slot_mask;
-            pending = !P1_ABLATE(a, 2u);
-            if (pending) request_slot(a.slots + 4 * slot_i, w0);
+            if (!P1_ABLATE(a, 2u)) request_slot(a.slots + 4 * slot_i, w0);
         }
+        if (!P1_ABLATE(a, 2u)) pendm = wantm;
     }
 
     // ---- integers of <= 16 plain digits, char(1) ----
-    bool fn = fast && kind != K_TEXT;
-    if (fn && kind == K_INT && len > 16u) { slow = true; fn = false; }
-    bool n_store = false;                  // this lane has a numeric record to store (behind the text fields' wait)
-    uint64_t n_rec = 0;
-    if (fn && len == 0u) {                 // an empty numeric field is a zero record and touches no range (sparse tables: most of them)
-        n_store = in_block && !P1_ABLATE(a, 4u);
-        fn = false;
+    uint64_t fnm = fastm & ~textm;
+    {
+        const uint64_t bigm = fnm & BAL(kind == K_INT) & BAL(len > 16u);
+        slowm |= bigm; fnm &= ~bigm;
     }
-    if (__ballot(fn)) {
-        if (fn) {
+    uint64_t nstorem;                      // lanes with a numeric record to store (behind the text fields' wait)
+    uint64_t n_rec = 0;
+    {
+        const uint64_t emptym = fnm & BAL(len == 0u);     // an empty numeric field is a zero record and touches no range (sparse tables: most of them)
+        nstorem = emptym & inblkm;
+        fnm &= ~emptym;
+    }
+    if (fnm) {
+        uint32_t junk = 0;
+        if (lane_in(fnm)) {
             uint64_t v_rec = 0, v_range = 0;
-            bool ok = true;
             if (kind == K_INT) {
                 // the last min(len, 8) characters and the (len - 8) before them, each right-aligned in 8 with '0' in front
                 const uint32_t k = len > 8u ? len - 8u : 0u;
@@ -687,7 +708,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 const uint64_t w1 = (u64_of(nw[0], nw[1]) & ~m1) | (Z & m1);
                 const uint32_t r0 = (uint32_t)w1, r1 = (uint32_t)(w1 >> 32), r2 = (uint32_t)w2, r3 = (uint32_t)(w2 >> 32);
                 const uint32_t t0 = r0 - 0x30303030u, t1 = r1 - 0x30303030u, t2 = r2 - 0x30303030u, t3 = r3 - 0x30303030u;
-                ok = (nondigit_bits(r0, t0) | nondigit_bits(r1, t1) | nondigit_bits(r2, t2) | nondigit_bits(r3, t3)) == 0u;
+                junk = nondigit_bits(r0, t0) | nondigit_bits(r1, t1) | nondigit_bits(r2, t2) | nondigit_bits(r3, t3);
                 const uint32_t lo8 = __umul24(four_digits(t2), 10000u) + four_digits(t3);
                 const uint32_t hi8 = __umul24(four_digits(t0), 10000u) + four_digits(t1);
                 v_rec = v_range = (uint64_t)hi8 * 100000000ull + lo8;
@@ -701,68 +722,71 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 v_range = (uint64_t)(b0 == '\\' ? c0 + hi8 : c0);
                 v_rec = (uint64_t)(c0 + hi8);
             }
-            if (!ok) slow = true;
-            else {
-                if (v_range > 0) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
-                if (in_block && !P1_ABLATE(a, 4u)) { n_store = true; n_rec = v_rec; }
-            }
+            if ((junk == 0u) & (v_range > 0)) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
+            n_rec = v_rec;
         }
+        const uint64_t junkm = BAL(junk != 0u);           // signs, blanks, letters: the general form
+        slowm |= junkm;
+        nstorem |= fnm & ~junkm & inblkm;
     }
+    if (P1_ABLATE(a, 4u)) nstorem = 0;
 
     // ---- the text fields' slots have arrived (or will have, behind the wait) ----
     if (ftm) {
-        if (ft) {
-            // uniform over the text lanes (runs while any of them is undecided): ids are handed out at loop level
-            for (uint32_t probe = 0; probe < 4; ++probe) {
-                if (!__ballot(pending)) break;
-                uint64_t *slot = a.slots + 4 * slot_i;
-                SlotWords w;
-                if (probe == 0) {
-                    w = await_slot(w0);                                           // (lanes that requested nothing hold nothing: masked below)
-                    // that was an ordinary load, possibly from this CU's L1: only a complete slot can be taken at its word (request_slot)
-                    const bool again = pending && (w.key == 0 || w.s0 == 0);
-                    if (__ballot(again)) { if (again) w = load_slot(slot); }
-                } else if (pending) w = load_slot(slot);
-                if (!pending) { w.key = 1; w.s0 = w.s1 = w.s2 = 0; }
-                const bool same = pending && w.s0 == c0 && w.s1 == c1 && w.s2 == c2 && (((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len;
-                const bool wants_id = pending && !same && w.key == 0;
-                uint32_t nid = 0;
-                if (__ballot(wants_id)) nid = alloc_ids(ws.ids, wants_id, COLD(st), ID_CHUNK);          // (inserts are rare: one string in eighty of the benchmark's table)
-                if (!pending) continue;
-                if (same) {
-                    t_id = (uint32_t)w.key; pending = false;
-                    if (TRACK) note_occurrence(a.uniq_pos, t_id - 1u, abs_start);
-                } else if (w.key == 0) {
+        // runs while any text lane is undecided; every lane of the wave passes through (ids are handed out at this level)
+        for (uint32_t probe = 0; probe < 4; ++probe) {
+            if (!pendm) break;
+            uint64_t *slot = a.slots + 4 * slot_i;
+            SlotWords w;
+            if (probe == 0) {
+                w = await_slot(w0);                                               // (lanes that requested nothing hold nothing: every mask below lies within pendm)
+                // that was an ordinary load, possibly from this CU's L1: only a complete slot can be taken at its word (request_slot)
+                const uint64_t againm = pendm & (BAL(w.key == 0) | BAL(w.s0 == 0));
+                if (againm) { if (lane_in(againm)) w = load_slot(slot); }
+            } else if (lane_in(pendm)) w = load_slot(slot);
+            const uint64_t samem = pendm & BAL(w.s0 == c0) & BAL(w.s1 == c1) & BAL(w.s2 == c2) & BAL((((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len);
+            if (lane_in(samem)) {
+                t_id = (uint32_t)w.key;
+                if (TRACK) note_occurrence(a.uniq_pos, t_id - 1u, abs_start);
+            }
+            pendm &= ~samem;
+            const uint64_t freem = pendm & BAL(w.key == 0);                       // an empty slot: the string is new (inserts are rare: one string in eighty of the benchmark's table)
+            if (freem) {
+                const uint32_t nid = alloc_ids(ws.ids, freem, COLD(st), ID_CHUNK);
+                uint32_t won = 0;                                                 // 1: the slot is ours, 2: another wave took it first
+                if (lane_in(freem)) {
                     if (nid >= COLD(id_cap)) { COLD(st)->overflow = 1; }
                     else {
                         const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK);
-                        if (old == 0) { is_new = true; t_id = nid + 1; } else slow = true;          // lost the race: general form
+                        if (old == 0) { won = 1u; t_id = nid + 1; } else won = 2u;
                     }
-                    pending = false;
-                } else if (w.s0 == 0) {
-                    slow = true; pending = false;                                 // claimed, inline copy not complete yet
-                } else {
-                    slot_i = (slot_i + 1) & a.slot_mask;
                 }
+                newm |= BAL(won == 1u);
+                slowm |= BAL(won == 2u);                                          // lost the race: general form
+                pendm &= ~freem;
             }
-            if (pending) slow = true;
-            if (!slow && in_block && !P1_ABLATE(a, 4u)) {
-                *reinterpret_cast<uint32_t *>(recp) = t_id;
-                if (SKIP && a.nz && t_id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
-            }
+            const uint64_t halfm = pendm & BAL(w.s0 == 0);                        // claimed, inline copy not complete yet: general form
+            slowm |= halfm; pendm &= ~halfm;
+            if (lane_in(pendm)) slot_i = (slot_i + 1) & a.slot_mask;              // somebody else's: the next slot
         }
-        adopt_ids(ws.ids, ftm);
+        slowm |= pendm;
+        uint64_t tstorem = ftm & ~slowm & inblkm;
+        if (P1_ABLATE(a, 4u)) tstorem = 0;
+        if (lane_in(tstorem)) {
+            *reinterpret_cast<uint32_t *>(recp) = t_id;
+            if (SKIP && a.nz && t_id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
+        }
     }
     // the integer fields' records
-    if (__ballot(n_store)) {
-        if (n_store) {
+    if (nstorem) {
+        if (lane_in(nstorem)) {
             *reinterpret_cast<uint64_t *>(recp) = n_rec;
             if (SKIP && a.nz && n_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }
 
     // ---- everything else: the general form, from global memory ----
-    const uint64_t sm = __ballot(slow);
+    const uint64_t sm = slowm;
     if (sm) {
         if (DEFER) {
             // Queue entries come from the wave's chunk (one returning atomic on the queue counter per call would bound a
@@ -786,7 +810,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             {
                 uint64_t *dq0 = COLD(dq);
                 const uint32_t dqc = COLD(dq_cap);
-                if (slow) {
+                if (lane_in(sm)) {
                     if (qb < dqc) {
                         dq0[2ull * qb] = abs_start | ((uint64_t)col << 40);
                         dq0[2ull * qb + 1] = (uint64_t)raw_len | ((uint64_t)row << 32);
@@ -796,11 +820,13 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 }
             }
         } else {
-            if (slow) process_field_general(a, t, d, ws.ids, abs_start, raw_len, col, row, in_block, is_new);
+            bool is_new = false;
+            if (lane_in(sm)) process_field_general(a, t, d, ws.ids, abs_start, raw_len, col, row, lane_in(inblkm), is_new);
             adopt_ids(ws.ids, sm);
+            newm |= __ballot(is_new);
         }
     }
-    return popc64(__ballot(is_new));
+    return popc64(newm);
 }
 // FOLD: no row scan has run -- the waves take the spans in order (a ticket each), count the rows that start in theirs and learn their
 // first row's number from the spans before (Pass1Args.span_state).

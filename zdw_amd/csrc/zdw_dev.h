@@ -48,6 +48,12 @@ __device__ __forceinline__ uint64_t mask_lt(int b) { return b <= 0 ? 0ull : (b >
 __device__ __forceinline__ int highest_bit(uint64_t m) { return m ? 63 - __clzll((long long)m) : -1; }
 __device__ __forceinline__ int lowest_bit(uint64_t m) { return m ? __ffsll((long long)m) - 1 : -1; }
 __device__ __forceinline__ uint32_t popc64(uint64_t m) { return (uint32_t)__popcll(m); }
+// Lane masks.  BAL(one comparison) is a v_cmp that writes its scalar register pair; a mask built from several of them on the scalar
+// unit costs the vector ALU nothing more, whereas the ballot of a bool that was combined or changed in a branch first goes through a
+// vector register as 0 / 1 (v_cndmask + v_cmp).  lane_in(m): is the calling lane's bit set -- as a branch condition it is
+// s_and_saveexec on m itself.  m must be wave-uniform.
+#define BAL(cmp) __builtin_amdgcn_ballot_w64(cmp)
+__device__ __forceinline__ bool lane_in(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 __device__ __forceinline__ uint32_t bcast32(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
 __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane)

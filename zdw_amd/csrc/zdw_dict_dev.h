@@ -144,9 +144,11 @@ constexpr uint32_t ID_CHUNK = 64;          // ids a pass-1 wave takes beyond wha
 // One id for every active lane with `need` (call it with all lanes of the surrounding control flow).  Ids
 // come from the wave's chunk; when that runs out the wave takes what is missing plus `extra` more from
 // the global counter with one atomic.
-__device__ __forceinline__ uint32_t alloc_ids(IdAlloc &al, bool need, P1Status *st, uint32_t extra)
+__device__ __forceinline__ uint32_t alloc_ids(IdAlloc &al, uint64_t m, P1Status *st, uint32_t extra);
+__device__ __forceinline__ uint32_t alloc_ids(IdAlloc &al, bool need, P1Status *st, uint32_t extra) { return alloc_ids(al, (uint64_t)__ballot(need), st, extra); }
+// ... for the lanes of mask m (wave-uniform)
+__device__ __forceinline__ uint32_t alloc_ids(IdAlloc &al, uint64_t m, P1Status *st, uint32_t extra)
 {
-    const uint64_t m = __ballot(need);
     if (!m) return 0;
     const uint32_t k = popc64(m), rank = mbcnt64(m), have = al.end - al.cur;
     uint32_t id = al.cur + rank;
