@@ -382,6 +382,8 @@ __device__ __forceinline__ uint32_t tab_or_nl7(uint32_t w)
 __device__ __forceinline__ uint32_t boundaries16(const uint4 &v) { return pack16(tab_or_nl7(v.x), tab_or_nl7(v.y), tab_or_nl7(v.z), tab_or_nl7(v.w)); }
 
 // wave-uniform state of one worker wave
+// (measured: as 32-bit 0 / 1 values instead of bools these six cost pass 1 0.6 ms of 11 -- six more scalar registers in a kernel that is short of them)
+typedef bool P1_FLAG;
 struct WaveState {
     uint32_t desc, bytes;        // LDS offsets of this wave's rings (bytes: position 0 of the byte ring)
     uint32_t q_head, q_count;    // pending descriptors: ring indices q_head .. q_head + q_count - 1 (mod QCAP)
@@ -392,13 +394,13 @@ struct WaveState {
     uint32_t last_ord;           // ... and its ordinal among the visit's boundaries (mod 256)
     uint32_t tok_ord;            // tokeniser: boundaries of the visit so far (descriptors carry it mod 256)
     uint32_t tok_prevb;          // tokeniser: the byte before the next chunk is a boundary
-    bool tok_bs;                 // tokeniser: the chunk before held a backslash
-    bool far;                    // the boundary at last_e lies further back than a descriptor can say: far_abs is its position
+    P1_FLAG tok_bs;                 // tokeniser: the chunk before held a backslash
+    P1_FLAG far;                    // the boundary at last_e lies further back than a descriptor can say: far_abs is its position
     uint64_t far_abs;
-    bool first_pending;          // the head descriptor is the visit's sentinel: the line end before the first owned row
-    bool ignoring;               // the visit began inside a row of the span before: everything up to that row's end is not ours
-    bool prev_nl;                // the boundary before the head descriptor is a line end
-    bool done;                   // the visit's last row has been handled
+    P1_FLAG first_pending;          // the head descriptor is the visit's sentinel: the line end before the first owned row
+    P1_FLAG ignoring;               // the visit began inside a row of the span before: everything up to that row's end is not ours
+    P1_FLAG prev_nl;                // the boundary before the head descriptor is a line end
+    P1_FLAG done;                   // the visit's last row has been handled
     uint64_t vbase;              // visit base: absolute position = vbase + relative position (multiple of BYTE_RING)
     uint64_t row_start;          // absolute position where the row that is open at the head descriptor began (m_LongestLine candidates)
     IdAlloc ids;                 // this wave's chunk of unique ids
@@ -479,7 +481,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         }
     }
     uint32_t fs = pe_pos + 1u + n_prev;                                 // a field begins one byte after the boundary before it and the tabs dropped behind that
-    uint32_t raw_len, len, row, col;
+    uint32_t raw_len, len, row, col, rowd = 0;   // (rowd: rows that end in this batch before my field)
+    const uint32_t row_first = ws.row_cur;
     uint64_t fieldm, inblkm;             // lanes that hold a field of the table / whose row belongs to the block
     if (nlm == 0 && vm == 0 && !ws.first_pending) {
         // The common batch: 64 fields of one row, nothing out of the ordinary -- no line end, so no row ends, no blank line, no
@@ -505,7 +508,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     } else {
     uint64_t pnlm = (nlm << 1) | (ws.prev_nl ? 1ull : 0ull);            // the boundary before mine is a line end
     uint64_t realm = 0;                                                 // (vm != 0 only) boundaries that count
-    if (vm) {
+    if (any_lane(vm)) {
         // rare: separators of this batch are escaped -- my field begins after the last boundary that counts
         realm = ~deadm;
         uint32_t pnl = lane_in(pnlm) ? 1u : 0u, farv = lane_in(farm) ? 1u : 0u;
@@ -544,8 +547,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         incl_all = lane_value(incl, 63);
     }
     row = ws.row_cur; col = SKIP ? ws.col_cur + incl - 1u : ws.col_cur + lane;
-    if (nlm) {
-        row += mbcnt64(rm);
+    if (any_lane(nlm)) {
+        rowd = mbcnt64(rm);
+        row += rowd;
         const uint64_t prev = nlm & mask_lt((int)lane);
         if (SKIP) {
             const uint32_t incl_prev_nl = (uint32_t)__shfl((int)incl, prev ? highest_bit(prev) : 0, 64);      // (every lane takes part in the exchange)
@@ -571,12 +575,12 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         }
         ws.row_start = abs_h + 1;
     }
-    if (!SKIP && vm) {
+    if (!SKIP && any_lane(vm)) {
         // columns count the boundaries that count
         const uint64_t before = realm & mask_lt((int)lane), prev = nlm & mask_lt((int)lane);
         col = prev ? popc64(before & ~mask_le(highest_bit(prev))) : ws.col_cur + popc64(before);
     }
-    if (rm) {
+    if (any_lane(rm)) {
         if (lane_in(rm)) {
             if (row <= a.row_limit) {
                 if (col + 1 != a.ncols) atomicMin(&COLD(st)->bad_row, row);          // ConvertToZDW.cpp:336-337
@@ -589,9 +593,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // state for the next call
     ws.row_cur += popc64(rm);
     if (SKIP) ws.col_cur = nlm ? incl_all - incl_at_last_nl : ws.col_cur + incl_all;
-    else if (vm) ws.col_cur = nlm ? popc64(realm & ~mask_le(highest_bit(nlm))) : ws.col_cur + popc64(realm);
-    else ws.col_cur = nlm ? cnt - 1u - (uint32_t)highest_bit(nlm) : ws.col_cur + cnt;
-    if (vm) {
+    else if (any_lane(vm)) ws.col_cur = any_lane(nlm) ? popc64(realm & ~mask_le(highest_bit(nlm))) : ws.col_cur + popc64(realm);
+    else ws.col_cur = any_lane(nlm) ? cnt - 1u - (uint32_t)highest_bit(nlm) : ws.col_cur + cnt;
+    if (any_lane(vm)) {
         if (realm) {                     // the next batch's first field begins behind the last boundary that counted
             const int h = highest_bit(realm);
             ws.prev_nl = ((nlm >> h) & 1ull) != 0;
@@ -614,15 +618,17 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     constexpr bool MAY_BE_ZEROED = SKIP || QCAP == QCAP_LARGE;      // (only the forms for tables of mostly empty fields run on a zeroed matrix: launch_pass1)
     if (MAY_BE_ZEROED && a.rec_zeroed) fieldm &= BAL(raw_len != 0u);
     // a field that begins further back than a descriptor can say (the visit moved its base past its start): the general form
-    uint64_t abs_start = ws.vbase + fs;
+    // (its absolute position is needed by new strings and general-form fields only: computed where they are handled)
+    uint64_t far_start = 0;
     if (SKIP && farm) {
         if (lane_in(farm)) {
-            abs_start = ws.far_abs + 1u + n_prev;
-            const uint64_t l64 = ws.vbase + e_pos - abs_start;
+            far_start = ws.far_abs + 1u + n_prev;
+            const uint64_t l64 = ws.vbase + e_pos - far_start;
             if (l64 >= (1ull << 30)) { COLD(st)->nul_seen = 2; }            // a single field of 1 GiB or more
             raw_len = len = (uint32_t)l64;
         }
     }
+    auto abs_start_of = [&]() -> uint64_t { return (SKIP && lane_in(farm)) ? far_start : ws.vbase + fs; };
     uint32_t meta = 0;
     if (t.cols_in_lds) { if (lane_in(fieldm)) meta = lds_u32(t.meta + 4u * col); }
     const uint32_t kind = meta & 3u;
@@ -648,7 +654,12 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         slowm |= BAL(general != 0u);
     }
     const uint64_t fastm = fieldm & ~slowm;
-    uint8_t *recp = a.rec + (uint64_t)row * ws.rec_stride + (meta >> 16);
+    // my field's record: the batch's first row (wave-uniform: scalar arithmetic) + a 32-bit offset, so the stores take the base from
+    // scalar registers.  (The kernel that queues its general-form fields only runs with the column tables in LDS, which bounds the
+    // stride far below 2^24; the other one serves tables of any width.)
+    uint8_t *const rec_first = a.rec + (uint64_t)row_first * ws.rec_stride;
+    const uint32_t rec_off = DEFER ? __umul24(rowd, ws.rec_stride & 0xffffffu) + (meta >> 16) : 0u;
+    auto recp_of = [&]() -> uint8_t * { return DEFER ? rec_first + rec_off : a.rec + (uint64_t)row * ws.rec_stride + (meta >> 16); };
     uint64_t newm = 0;                   // lanes whose string was new to the dictionary
 
     // ---- text-like columns, <= 24 bytes: decided by one table slot.  The slot is REQUESTED here and looked at behind the integer fields
@@ -662,7 +673,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     }
     uint32_t t_id = 0;
     uint64_t pendm = 0;                  // text fields that have not found their slot yet
-    uint64_t c0 = 0, c1 = 0, c2 = 0, acc = 0, slot_i = 0;
+    // (set and read by the lanes of wantm only: no zeroes moved into ten registers for the others)
+    uint64_t c0, c1, c2, acc, slot_i;
     SlotLoad w0;
     if (ftm) {
         const uint64_t wantm = ftm & BAL(len != 0u);                              // empty fields are skipped (:340-341)
@@ -686,7 +698,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         slowm |= bigm; fnm &= ~bigm;
     }
     uint64_t nstorem;                      // lanes with a numeric record to store (behind the text fields' wait)
-    uint64_t n_rec = 0;
+    uint64_t n_rec = 0;                    // (an empty field's record)
     {
         const uint64_t emptym = fnm & BAL(len == 0u);     // an empty numeric field is a zero record and touches no range (sparse tables: most of them)
         nstorem = emptym & inblkm;
@@ -747,7 +759,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             const uint64_t samem = pendm & BAL(w.s0 == c0) & BAL(w.s1 == c1) & BAL(w.s2 == c2) & BAL((((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len);
             if (lane_in(samem)) {
                 t_id = (uint32_t)w.key;
-                if (TRACK) note_occurrence(a.uniq_pos, t_id - 1u, abs_start);
+                if (TRACK) note_occurrence(a.uniq_pos, t_id - 1u, abs_start_of());
             }
             pendm &= ~samem;
             const uint64_t freem = pendm & BAL(w.key == 0);                       // an empty slot: the string is new (inserts are rare: one string in eighty of the benchmark's table)
@@ -757,7 +769,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 if (lane_in(freem)) {
                     if (nid >= COLD(id_cap)) { COLD(st)->overflow = 1; }
                     else {
-                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start, len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK);
+                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start_of(), len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK);
                         if (old == 0) { won = 1u; t_id = nid + 1; } else won = 2u;
                     }
                 }
@@ -773,14 +785,14 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         uint64_t tstorem = ftm & ~slowm & inblkm;
         if (P1_ABLATE(a, 4u)) tstorem = 0;
         if (lane_in(tstorem)) {
-            *reinterpret_cast<uint32_t *>(recp) = t_id;
+            *reinterpret_cast<uint32_t *>(recp_of()) = t_id;
             if (SKIP && a.nz && t_id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }
     // the integer fields' records
     if (nstorem) {
         if (lane_in(nstorem)) {
-            *reinterpret_cast<uint64_t *>(recp) = n_rec;
+            *reinterpret_cast<uint64_t *>(recp_of()) = n_rec;
             if (SKIP && a.nz && n_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }
@@ -812,7 +824,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 const uint32_t dqc = COLD(dq_cap);
                 if (lane_in(sm)) {
                     if (qb < dqc) {
-                        dq0[2ull * qb] = abs_start | ((uint64_t)col << 40);
+                        dq0[2ull * qb] = abs_start_of() | ((uint64_t)col << 40);
                         dq0[2ull * qb + 1] = (uint64_t)raw_len | ((uint64_t)row << 32);
                     } else {
                         COLD(st)->deferred_lost = 1;
@@ -821,7 +833,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             }
         } else {
             bool is_new = false;
-            if (lane_in(sm)) process_field_general(a, t, d, ws.ids, abs_start, raw_len, col, row, lane_in(inblkm), is_new);
+            if (lane_in(sm)) process_field_general(a, t, d, ws.ids, abs_start_of(), raw_len, col, row, lane_in(inblkm), is_new);
             adopt_ids(ws.ids, sm);
             newm |= __ballot(is_new);
         }

@@ -54,6 +54,9 @@ __device__ __forceinline__ uint32_t popc64(uint64_t m) { return (uint32_t)__popc
 // s_and_saveexec on m itself.  m must be wave-uniform.
 #define BAL(cmp) __builtin_amdgcn_ballot_w64(cmp)
 __device__ __forceinline__ bool lane_in(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// m != 0, evaluated HERE: the compiler otherwise computes the comparison once and carries the answer from block to block -- which, for
+// a wave-uniform bool, it does in a vector register (v_cndmask to set, v_cmp to test).  The empty asm makes m a new value each time.
+__device__ __forceinline__ bool any_lane(uint64_t m) { asm volatile("" : "+s"(m)); return m != 0; }
 
 __device__ __forceinline__ uint32_t bcast32(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
 __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src_lane)

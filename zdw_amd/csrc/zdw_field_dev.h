@@ -43,11 +43,12 @@ __device__ inline uint64_t parse_u64_general(const uint8_t *p, uint32_t len)
     return neg ? (uint64_t)0 - v : v;
 }
 
-// four ASCII digits, most significant in the low byte, already reduced by 0x30303030 -> value (24-bit multiplies)
+// four ASCII digits, most significant in the low byte, already reduced by 0x30303030 -> value: two byte-wise dot products
+// (v_dot4_u32_u8: weights 10, 1 on bytes 0, 1, then on bytes 2, 3 with 100 x the first sum as the addend) and one 24-bit multiply
 __device__ __forceinline__ uint32_t four_digits(uint32_t t)
 {
-    const uint32_t s = (t << 3) + (t << 1) + (t >> 8);          // byte 0 = 10 d0 + d1, byte 2 = 10 d2 + d3 (no carries: < 100)
-    return __umul24(s & 0xffu, 100u) + ((s >> 16) & 0xffu);
+    const uint32_t hi = __builtin_amdgcn_udot4(t, 0x0000010au, 0u, false);          // 10 d0 + d1
+    return __builtin_amdgcn_udot4(t, 0x010a0000u, __umul24(hi, 100u), false);       // + 10 d2 + d3
 }
 // bit 7 of a byte set where the byte of r is not an ASCII digit (t = r - 0x30303030); exact for the lowest bad byte
 __device__ __forceinline__ uint32_t nondigit_bits(uint32_t r, uint32_t t) { return ((r + 0x46464646u) | t) & 0x80808080u; }
