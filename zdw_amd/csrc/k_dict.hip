@@ -190,12 +190,19 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ i
                                                     const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
                                                     const uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     uint32_t m, uint32_t depth, uint64_t *__restrict__ keys,
-                                                    uint32_t *__restrict__ vals)
+                                                    uint32_t *__restrict__ vals, const uint64_t *__restrict__ uniq_key)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t u = order ? order[active[j]] : j;          // first round: everything is in place (order = active = identity)
     const uint32_t len = uniq_len[u];
+    if (uniq_key && depth < 3) {
+        // the first 24 bytes were kept by id when the string entered the table: in the first round a streaming read
+        // instead of a visit to the image per string
+        keys[j] = len ? __builtin_bswap64(uniq_key[3ull * u + depth]) : (uint64_t)u;
+        vals[j] = j;
+        return;
+    }
     // a hole (length 0) sorts before every string (first byte >= 1) and apart from every other hole
     const uint64_t pos = uniq_pos[u];
     const uint8_t *p = string_at(in, extra, pos);
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256) void k_sort_compact(const uint32_t *__restrict
 
 // Sort n unique strings.  Buffers: see SortBuffers.  Returns 0 or a hipError_t.
 int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n64,
-              SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len)
+              SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len, const uint64_t *uniq_key)
 {
     const uint32_t n = (uint32_t)n64;
     uint32_t rounds = 0;
@@ -258,7 +265,7 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     uint32_t *active = b.active_a, *active_alt = b.active_b;
     // group labels per active index live in val-sized scratch: group (current) and flags-derived next
     uint32_t *group = b.group;
-    uint32_t m = n;
+    uint32_t m = n, max_label = 0;                 // max_label: the largest tie-group label of the round (0 in the first: one group)
     // scratch carved from flags: head[m], still[m], head_scan[m+1], still_scan[m+1], tmp[m], group_next[m]
     uint32_t *head = b.flags;
     uint32_t *still = head + n;
@@ -273,12 +280,13 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
         uint64_t *keys = b.key_a, *keys_alt = b.key_b;
         uint32_t *vals = b.val_a, *vals_alt = b.val_b;
         const uint32_t *order_in = depth ? b.order : nullptr;      // identity in the first round
-        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active, m, depth, keys, vals);
+        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active, m, depth, keys, vals, uniq_key);
         radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, 64, b.hist, b.scan_tmp, s);
         if (depth > 0) {
             // stable, more significant key: the tie group of the element's old position (labels are < m + 1)
+            // (labels are 1 .. the number of runs that stayed in the working set: read back with the round's count)
             uint32_t bits = 1;
-            while (bits < 32 && (1ull << bits) <= (uint64_t)m + 1) ++bits;
+            while (bits < 32 && (1ull << bits) <= (uint64_t)max_label) ++bits;
             radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
         }
         hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active, vals, m, tmp);
@@ -289,6 +297,7 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
                            group_next);
         uint32_t m_next = 0;
         HIPCHK(hipMemcpyAsync(&m_next, still_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&max_label, head_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         uint32_t *t = active; active = active_alt; active_alt = t;
         t = group; group = group_next; group_next = t;
@@ -320,7 +329,8 @@ void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64
 __global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
                                                     const uint32_t *__restrict__ order, const uint64_t *__restrict__ uniq_pos,
                                                     const uint32_t *__restrict__ uniq_len, const uint64_t *__restrict__ off_excl, uint32_t n,
-                                                    uint8_t *__restrict__ blob, uint32_t *__restrict__ id_off)
+                                                    uint8_t *__restrict__ blob, uint32_t *__restrict__ id_off,
+                                                    const uint64_t *__restrict__ uniq_key)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r == 0) blob[0] = 0;                                     // origin byte (dictionary.cpp:96)
@@ -329,10 +339,24 @@ __global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ i
     const uint32_t len = uniq_len[u];
     if (!len) return;                                            // hole
     const uint64_t off = 1 + off_excl[r];
+    uint8_t *q = blob + off;
+    id_off[u] = (uint32_t)off;
+    if (uniq_key && len <= 24u) {
+        // the whole string was kept by id when it entered the table (three words, zero beyond its end)
+        const uint64_t *k = uniq_key + 3ull * u;
+        uint64_t w = k[0];
+        uint32_t i = 0;
+        for (; i + 8 <= len; i += 8) {
+            reinterpret_cast<PackedU64 *>(q + i)->v = w;
+            w = i + 8 < len ? k[i / 8 + 1] : 0ull;
+        }
+        for (; i < len; ++i) { q[i] = (uint8_t)w; w >>= 8; }
+        q[len] = 0;
+        return;
+    }
     const uint64_t pos = uniq_pos[u];
     const uint8_t *p = string_at(in, extra, pos);
     const uint8_t *end = pos >= EXTRA_BASE ? p + len + 16 : in + in_bytes;       // imported strings carry slack
-    uint8_t *q = blob + off;
     uint32_t i = 0;
     for (; i + 8 <= len; i += 8) reinterpret_cast<PackedU64 *>(q + i)->v = load_upto8(p + i, 8, end);     // unaligned 8-byte moves
     if (i < len) {
@@ -340,14 +364,14 @@ __global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ i
         for (; i < len; ++i) { q[i] = (uint8_t)w; w >>= 8; }
     }
     q[len] = 0;
-    id_off[u] = (uint32_t)off;
 }
 
 void launch_dict_emit(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
-                      const uint32_t *uniq_len, const uint64_t *off_excl, uint64_t n, uint8_t *blob, uint32_t *id_off, hipStream_t s)
+                      const uint32_t *uniq_len, const uint64_t *off_excl, uint64_t n, uint8_t *blob, uint32_t *id_off, hipStream_t s,
+                      const uint64_t *uniq_key)
 {
     const uint32_t grid = n ? (uint32_t)((n + 255) / 256) : 1u;
-    hipLaunchKernelGGL(k_dict_emit, dim3(grid), dim3(256), 0, s, in, in_bytes, extra, order, uniq_pos, uniq_len, off_excl, (uint32_t)n, blob, id_off);
+    hipLaunchKernelGGL(k_dict_emit, dim3(grid), dim3(256), 0, s, in, in_bytes, extra, order, uniq_pos, uniq_len, off_excl, (uint32_t)n, blob, id_off, uniq_key);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -806,11 +830,11 @@ __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint6
 
 void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
                            uint64_t *slots, uint64_t slot_mask, uint32_t max_entries, uint64_t *uniq_pos, uint32_t *uniq_len, uint32_t id_cap,
-                           uint32_t trim, uint64_t hi, P1Status *st, uint32_t *ids_out, hipStream_t s)
+                           uint32_t trim, uint64_t hi, P1Status *st, uint32_t *ids_out, hipStream_t s, uint64_t *uniq_key)
 {
     if (!count) return;
     DictTable d;
-    d.slots = slots; d.slot_mask = slot_mask; d.uniq_pos = uniq_pos; d.uniq_len = uniq_len; d.id_cap = id_cap; d.st = st; d.track_first = 0;
+    d.slots = slots; d.slot_mask = slot_mask; d.uniq_pos = uniq_pos; d.uniq_len = uniq_len; d.id_cap = id_cap; d.uniq_key = uniq_key; d.st = st; d.track_first = 0;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

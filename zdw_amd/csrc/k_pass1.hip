@@ -769,7 +769,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 if (lane_in(freem)) {
                     if (nid >= COLD(id_cap)) { COLD(st)->overflow = 1; }
                     else {
-                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start_of(), len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK);
+                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start_of(), len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK, COLD(uniq_key));
                         if (old == 0) { won = 1u; t_id = nid + 1; } else won = 2u;
                     }
                 }
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
     ws.ids.cur = ws.ids.end = 0;
     if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
-    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st; d.track_first = TRACK ? 1u : 0u;
+    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.uniq_key = a.uniq_key; d.st = a.st; d.track_first = TRACK ? 1u : 0u;
     uint32_t new_entries = 0;          // dictionary inserts of this wave not yet added to st->entries
 
     constexpr bool fold = FOLD;                     // no row scan has run: spans by ticket, their rows counted here
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_pass1_deferred(const Pass1Args a, uint3
     ColTables t;
     t.meta = t.mn = t.mx = t.seen = 0; t.cols_in_lds = false;
     DictTable d;
-    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.st = a.st; d.track_first = a.track_first;
+    d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.uniq_key = a.uniq_key; d.st = a.st; d.track_first = a.track_first;
     IdAlloc al;
     al.cur = al.end = 0;
     uint32_t created = 0;

@@ -183,6 +183,7 @@ struct zdw_ctx {
     std::vector<uint64_t> h_min, h_max;
     std::vector<uint8_t> h_seen;
     // dictionary
+    DevBuf uniq_key;              // the strings' first 24 bytes by id (Pass1Args.uniq_key); left out when memory is short
     DevBuf uniq_pos, uniq_len, key_a, key_b, val_a, val_b, order, group, active_a, active_b, flags, hist, lenp1, off_excl,
         slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
     uint64_t nuniq = 0, dict_size = 0, extra_bytes = 0;
@@ -587,14 +588,14 @@ int sort_buffers(zdw_ctx *c, uint64_t u, SortBuffers &b)
 
 // exact string sort of u strings (by id: pos / len, length 0 = hole) into c->order (holes first)
 int sort_strings(zdw_ctx *c, const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *upos, const uint32_t *ulen, uint64_t u,
-                 uint32_t max_len)
+                 uint32_t max_len, const uint64_t *ukey = nullptr)
 {
     hipStream_t s = c->stream;
     StageScope ts(c, ZDW_STAGE_DICT_SORT);
     SortBuffers b{};
     int rcb = sort_buffers(c, u, b);
     if (rcb) return rcb;
-    const int e = dict_sort(in, in_bytes, extra, upos, ulen, u, b, s, &c->sort_rounds, max_len);
+    const int e = dict_sort(in, in_bytes, extra, upos, ulen, u, b, s, &c->sort_rounds, max_len, ukey);
     if (e) return fail(c, ZDW_UNKNOWN_ERROR, "dictionary sort: %s", hipGetErrorString((hipError_t)e));
     return ZDW_OK;
 }
@@ -650,7 +651,8 @@ int ensure_dict(zdw_ctx *c)
     // the second stream while the strings are sorted on this one.  (A shard of a row-sharded block waits for its halo row.)
     if (!c->have_prev && !experiment("ZDW_NO_OVERLAP")) { rc = start_pass2_size(c); if (rc) return rc; }
     {
-        rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, c->dict_max_len);
+        rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u, c->dict_max_len,
+                          c->uniq_key.as<uint64_t>());
         if (rc) return rc;
     }
     {
@@ -660,7 +662,7 @@ int ensure_dict(zdw_ctx *c)
         HIP_TRY(c, c->dict_sec.ensure(16 + c->dict_size));
         uint8_t *blob = c->dict_sec.as<uint8_t>() + 8;
         launch_dict_emit(c->d_in, c->n, c->extra.as<uint8_t>(), c->order.as<uint32_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(),
-                         c->off_excl.as<uint64_t>(), u, blob, c->slot_off.as<uint32_t>(), s);
+                         c->off_excl.as<uint64_t>(), u, blob, c->slot_off.as<uint32_t>(), s, c->uniq_key.as<uint64_t>());
         if (c->nuniq == 0) {                                   // empty set: a single 00 (dictionary.cpp:80-84)
             c->dict_sec_off = 8; c->dict_sec_len = 1;
         } else {
@@ -993,7 +995,7 @@ std::vector<DevBuf *> all_device_buffers(zdw_ctx *c)
                       &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
                       &c->own_upos, &c->own_ulen, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
                       &c->own_out, &c->own_pos, &c->own_minpos, &c->own_flags, &c->model_len, &c->exp_pos, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
-                      &c->uniq_pos, &c->uniq_len, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
+                      &c->uniq_pos, &c->uniq_len, &c->uniq_key, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
                       &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
                       &c->extra_lens, &c->extra_offs, &c->exp_bytes, &c->d_used_recoff, &c->d_used_kind, &c->d_used_size,
                       &c->d_used_base, &c->d_prev0, &c->d_last, &c->row_len, &c->row_off, &c->rows_out, &c->batch_pre};
@@ -1479,11 +1481,12 @@ int Pass1Job::parse()
             hipError_t e = nslots > (1ull << 31) ? hipErrorOutOfMemory : c->slots.ensure(nslots * 32);
             if (e == hipSuccess) e = c->uniq_pos.ensure(cap * 8);
             if (e == hipSuccess) e = c->uniq_len.ensure(cap * 4);
+            if (e == hipSuccess && c->uniq_key.ensure(cap * 24) != hipSuccess) c->uniq_key.release();      // optional: without it the sort reads the image
             if (e == hipErrorOutOfMemory && fold) { c->no_fold = true; return P1_COUNT_FIRST; }
             if (e == hipErrorOutOfMemory) {
                 // no room for a table of this block's uniques: fewer rows, fewer uniques (and a smaller record matrix)
                 if (!fewer_rows()) return fail(c, ZDW_OUT_OF_MEMORY, "no room for a dictionary table of %llu slots; split the block", (unsigned long long)nslots);
-                c->slots.release(); c->uniq_pos.release(); c->uniq_len.release(); c->rec.release();
+                c->slots.release(); c->uniq_pos.release(); c->uniq_len.release(); c->uniq_key.release(); c->rec.release();
                 while (c->rec.ensure((uint64_t)nrows * c->rec_stride + 64) != hipSuccess)
                     if (!fewer_rows()) return fail(c, ZDW_OUT_OF_MEMORY, "no room for the record matrix of a single row; split the block");
                 nslots = std::min(nslots, first_table(nrows));
@@ -1520,7 +1523,7 @@ int Pass1Job::parse()
                 a.row_limit = (uint32_t)std::min<uint64_t>(fold_rows_cap, 0xFFFFFFFEull);      // rows the matrix has room for
             }
             a.slots = c->slots.as<uint64_t>(); a.slot_mask = nslots - 1;
-            a.uniq_pos = c->uniq_pos.as<uint64_t>(); a.uniq_len = c->uniq_len.as<uint32_t>(); a.id_cap = c->id_cap;
+            a.uniq_pos = c->uniq_pos.as<uint64_t>(); a.uniq_len = c->uniq_len.as<uint32_t>(); a.id_cap = c->id_cap; a.uniq_key = c->uniq_key.as<uint64_t>();
             a.max_entries = (uint32_t)std::min<uint64_t>(nslots / 8 * 5, 0xFFFFFFF0ull);
             a.col_min = c->col_min.as<uint64_t>(); a.col_max = c->col_max.as<uint64_t>(); a.col_seen = c->col_seen.as<uint8_t>();
 #ifdef ZDW_EXPERIMENTS
@@ -1917,7 +1920,7 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
     launch_import_strings(c->d_in, c->n, c->extra.as<uint8_t>(), c->extra_lens.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count,
                           c->slots.as<uint64_t>(), c->nslots - 1,
                           (uint32_t)std::min<uint64_t>(c->nslots - c->nslots / 8, 0xFFFFFFF0ull), c->uniq_pos.as<uint64_t>(),
-                          c->uniq_len.as<uint32_t>(), c->id_cap, c->trim ? 1u : 0u, c->hi, c->status.as<P1Status>(), nullptr, s);
+                          c->uniq_len.as<uint32_t>(), c->id_cap, c->trim ? 1u : 0u, c->hi, c->status.as<P1Status>(), nullptr, s, c->uniq_key.as<uint64_t>());
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -2005,7 +2008,7 @@ int zdw_shard_sort_uniques(zdw_ctx *c, uint64_t *count)
         return ZDW_OK;
     }
     int rc = sort_strings(c, c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), u,
-                          std::max<uint32_t>(24, st.max_len));
+                          std::max<uint32_t>(24, st.max_len), c->uniq_key.as<uint64_t>());
     if (rc) return rc;
     // keep the order: the owner-side sort reuses the sort buffers.  Holes (length 0) sort first.
     HIP_TRY(c, c->my_order.ensure((u + 1) * 4));

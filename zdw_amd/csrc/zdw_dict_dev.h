@@ -186,8 +186,11 @@ __device__ __forceinline__ void retire_ids(const IdAlloc &al, uint32_t *uniq_len
 // (0 = claimed).  A lost race leaves the id a hole.
 template <bool FACTS_AT_AGENT_SCOPE>
 __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uint32_t id, uint64_t pos, uint32_t len, uint64_t *uniq_pos,
-                                               uint32_t *uniq_len, uint64_t c0, uint64_t c1, uint64_t c2, bool track_first = false)
+                                               uint32_t *uniq_len, uint64_t c0, uint64_t c1, uint64_t c2, bool track_first = false,
+                                               uint64_t *uniq_key = nullptr)
 {
+    // (read after the kernel only, and only for ids that stay: ordinary stores)
+    if (uniq_key) { uint64_t *k = uniq_key + 3ull * id; k[0] = c0; k[1] = c1; k[2] = c2; }
     // Only strings of more than 24 bytes are ever compared against their first occurrence while the pass
     // runs; for the others the facts are read after the kernel, so ordinary (write-back) stores do.
     if (track_first) {
@@ -239,6 +242,7 @@ __device__ inline bool stored_ends_here(const uint8_t *in, uint64_t pos, uint32_
 struct DictTable {
     uint64_t *slots; uint64_t slot_mask;
     uint64_t *uniq_pos; uint32_t *uniq_len; uint32_t id_cap;
+    uint64_t *uniq_key;        // optional (Pass1Args.uniq_key)
     P1Status *st;
     uint32_t track_first;      // uniq_pos[id] must end up as the string's FIRST occurrence in the image (the memory-limit model needs the
                                // order in which the reference meets the strings): every occurrence takes part in a minimum.  The
@@ -301,7 +305,7 @@ __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, con
         if (!searching) continue;
         if (w.key == 0) {
             if (nid >= d.id_cap) { d.st->overflow = 1; searching = false; continue; }
-            const uint64_t old = claim_slot<true>(slot, make_slot_key(tag, len, nid), nid, pos, len, d.uniq_pos, d.uniq_len, c0, c1, c2, d.track_first != 0);
+            const uint64_t old = claim_slot<true>(slot, make_slot_key(tag, len, nid), nid, pos, len, d.uniq_pos, d.uniq_len, c0, c1, c2, d.track_first != 0, d.uniq_key);
             if (old == 0) { is_new = true; result = nid + 1; searching = false; continue; }
             w.key = old; w.s0 = 0;                        // somebody else just claimed it
         }

@@ -60,6 +60,9 @@ struct Pass1Args {
     uint32_t trim;
     uint64_t *slots; uint64_t slot_mask; uint32_t max_entries;
     uint64_t *uniq_pos; uint32_t *uniq_len; uint32_t id_cap;   // per unique id: first occurrence and length (0 = hole)
+    uint64_t *uniq_key;                   // optional: the string's first 24 bytes by id (three words each: uniq_key[3 * id + k]),
+                                          // little-endian and zero beyond the string's end like the table slot's copy -- what the dictionary sort and the blob
+                                          // read instead of going back to the image for every string
     uint64_t *col_min; uint64_t *col_max; uint8_t *col_seen;
     P1Status *st;
     LongRow *long_rows; uint32_t long_cap;
@@ -132,14 +135,16 @@ struct SortBuffers {   // all sized for n elements unless noted
 uint32_t sort_blocks(uint64_t n);
 // sorts unique strings into strcmp order; returns through `order`.  Host-driven loop (synchronises on s).
 int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n,
-              SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len);
+              SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len, const uint64_t *uniq_key = nullptr);
 void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s);
 void launch_dict_emit(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
                       const uint32_t *uniq_len, const uint64_t *off_excl, uint64_t n,
-                      uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *id_off, hipStream_t s);
+                      uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *id_off, hipStream_t s,
+                      const uint64_t *uniq_key = nullptr);
 void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, const uint32_t *lens, const uint64_t *offs, uint64_t count,
                            uint64_t *slots, uint64_t slot_mask, uint32_t max_entries, uint64_t *uniq_pos, uint32_t *uniq_len,
-                           uint32_t id_cap, uint32_t trim, uint64_t hi, P1Status *st, uint32_t *ids_out /* optional */, hipStream_t s);
+                           uint32_t id_cap, uint32_t trim, uint64_t hi, P1Status *st, uint32_t *ids_out /* optional */, hipStream_t s,
+                           uint64_t *uniq_key = nullptr);
 void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                            const uint32_t *order /* optional */, const uint64_t *off_excl, uint64_t n, uint8_t *bytes,
                            uint32_t *lens_out /* optional */, hipStream_t s);
