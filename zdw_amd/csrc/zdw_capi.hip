@@ -1481,7 +1481,11 @@ int Pass1Job::parse()
             hipError_t e = nslots > (1ull << 31) ? hipErrorOutOfMemory : c->slots.ensure(nslots * 32);
             if (e == hipSuccess) e = c->uniq_pos.ensure(cap * 8);
             if (e == hipSuccess) e = c->uniq_len.ensure(cap * 4);
-            if (e == hipSuccess && c->uniq_key.ensure(cap * 24) != hipSuccess) c->uniq_key.release();      // optional: without it the sort reads the image
+            if (e == hipSuccess) {
+                // optional (without it the sort and the blob go back to the image for every string): not under a memory budget
+                // (zdw_opts.max_device_bytes), where every byte decides how many rows a block can hold
+                if (c->budget.cap || c->uniq_key.ensure(cap * 24) != hipSuccess) c->uniq_key.release();
+            }
             if (e == hipErrorOutOfMemory && fold) { c->no_fold = true; return P1_COUNT_FIRST; }
             if (e == hipErrorOutOfMemory) {
                 // no room for a table of this block's uniques: fewer rows, fewer uniques (and a smaller record matrix)
