@@ -364,8 +364,35 @@ def _i64_to_u64(v):
     return v + (1 << 64) if v < 0 else v
 
 
+class _Laps:
+    """ZDW_DIST_LAPS=1: wall time of the phases of a distributed step on stderr (rank 0; each mark waits for the device)."""
+
+    def __init__(self, rank):
+        import os
+        self.on = rank == 0 and os.environ.get("ZDW_DIST_LAPS") == "1"
+        self.t, self.out = None, []
+        self.mark(None)
+
+    def mark(self, name):
+        if not self.on:
+            return
+        import time
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        if name is not None:
+            self.out.append("%s %.2f" % (name, (now - self.t) * 1e3))
+        self.t = now
+
+    def done(self):
+        if self.on:
+            import sys
+            print("[dist laps, ms] " + " | ".join(self.out), file=sys.stderr)
+
+
 def partitioned_dictionary(enc, rank, world, device, group=None):
     """The dictionary steps of one rank with the range-partitioned dictionary (after the range exchange)."""
+    laps = _Laps(rank)
+
     def _sample():
         enc.sort_uniques()
         return enc.sample_keys(SAMPLES_PER_SHARD)
@@ -374,7 +401,9 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
     allk = allgather_i64(flat, device, group=group)
     samples = [(_i64_to_u64(a[2 * i]), _i64_to_u64(a[2 * i + 1])) for a in allk for i in range(len(a) // 2)]
     splitters = pick_splitters(samples, world)
+    laps.mark("sample+splitters")
     counts, nb, d_lens, d_bytes = _guarded(lambda: enc.partition(splitters), device, group, "partitioning the dictionary")
+    laps.mark("partition")
     lens = _wrap(d_lens, sum(counts) * 4, "<i4", device).clone()      # torch-owned copies: the collectives work on memory torch allocated
     byts = _wrap(d_bytes, sum(nb), "|u1", device).clone()
     _torch_done()
@@ -382,6 +411,7 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
     got_lens = alltoallv(lens, counts, rcounts, group=group)
     got_byts = alltoallv(byts, nb, rbytes, group=group)
     _torch_done()
+    laps.mark("strings all-to-all")
     # (an owner whose build fails still reports: the size all-gather carries its code, so nobody waits for it in vain)
     from . import capi
     rc_own, slice_bytes = 0, 0
@@ -394,13 +424,17 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
     if any(a[1] for a in gathered):
         raise capi.ZdwError(rc_own or max(a[1] for a in gathered), "building a dictionary range failed on a rank")
     slices = [a[0] for a in gathered]
+    laps.mark("owner build")
     bases, total = range_bases(slices)
     d_offs = _guarded(lambda: enc.owner_offsets(bases[rank]), device, group, "dictionary offsets")
     offs = _wrap(d_offs, sum(rcounts) * 4, "<i4", device).clone()
     _torch_done()
     back = alltoallv(offs, rcounts, counts, group=group)
     _torch_done()
+    laps.mark("offsets back")
     _guarded(lambda: enc.set_offsets(back.data_ptr() if back.numel() else 0, back.numel(), total, rank == 0), device, group, "dictionary offsets")
+    laps.mark("set offsets")
+    laps.done()
 
 
 def allreduce_ranges(mn, mx, seen, device, group=None, status=None):
