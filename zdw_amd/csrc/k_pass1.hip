@@ -69,7 +69,12 @@ constexpr uint32_t BYTE_RING = 4096;              // two rounds of input bytes p
 constexpr uint32_t RING_TAIL = 32;                // copy of the byte ring's first bytes behind its end: 24-byte reads never wrap
 constexpr uint32_t RING_HEAD = 16;                // copy of its last bytes in front of it: the byte before position 0 of the ring
 constexpr uint32_t RING_STRIDE = RING_HEAD + BYTE_RING + RING_TAIL;
-constexpr uint32_t P1_WPB = 8;                    // independent waves per workgroup; they share the column tables
+#ifndef P1_MIN_WAVES
+#define P1_MIN_WAVES 6          // waves per SIMD the register allocation of the main kernel aims at
+#endif
+constexpr uint32_t P1_WPB = 8;                    // independent waves per workgroup (they share the column tables): the default; launch_pass1 takes the
+                                                  // number that leaves the most waves resident for the schema's tables (blockDim.x / 64 in the kernel)
+constexpr uint32_t P1_WPB_MAX = 16;
 constexpr uint32_t LUT_ROWS = 25;                 // byte masks "first L bytes" for L = 0..24, 32 bytes per row
 // Descriptor ring entries per wave (u32 each): 512 for ordinary tables (a 2 KiB round holds ~220 boundaries); 1024 for
 // tables of mostly empty fields (a round of such data holds 1000+), whose boundaries are then emitted chunk by chunk
@@ -325,14 +330,14 @@ void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_
 //   meta / mn / mx / seen   column tables shared by the waves of the workgroup (cols_in_lds)
 struct P1Lds { uint32_t desc, bytes, lut, dqs, meta, mn, mx, seen, total; };
 
-__host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool cols_in_lds, uint32_t qcap)
+__host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool cols_in_lds, uint32_t qcap, uint32_t wpb = P1_WPB)
 {
     P1Lds L;
     L.desc = 0;
-    L.bytes = P1_WPB * qcap * 4u;
-    L.lut = L.bytes + P1_WPB * RING_STRIDE;
+    L.bytes = wpb * qcap * 4u;
+    L.lut = L.bytes + wpb * RING_STRIDE;
     L.dqs = L.lut + LUT_ROWS * 32u;              // P1_WPB x {cur, end}: kept here, not in registers (the main loop has none to spare)
-    L.meta = L.dqs + P1_WPB * 8u;
+    L.meta = L.dqs + wpb * 8u;
     uint32_t end = L.meta;
     L.mn = L.mx = L.seen = end;
     if (cols_in_lds) {
@@ -844,33 +849,34 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
 // first row's number from the spans before (Pass1Args.span_state).
 // TRACK: uniq_pos[id] ends up as the string's FIRST occurrence (Pass1Args.track_first: every occurrence takes part in a minimum).
 template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP, bool FOLD, bool TRACK>
-__global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass1Args a)
+__global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_pass1(const Pass1Args a)
 {
     constexpr uint32_t QM = QCAP * 4u - 1u;
     // (the compiler cannot prove threadIdx.x >> 6 wave-uniform: without the readfirstlane everything derived from the wave's
     // number -- spans, positions, the whole visit bookkeeping -- lives in vector registers and every branch on it saves and
     // restores the exec mask)
     const uint32_t wv = uniform32(threadIdx.x >> 6);
-    const uint32_t wave_id = blockIdx.x * P1_WPB + wv, wave_count = gridDim.x * P1_WPB;
+    const uint32_t wpb = blockDim.x >> 6;                                        // waves of this workgroup (launch_pass1)
+    const uint32_t wave_id = blockIdx.x * wpb + wv, wave_count = gridDim.x * wpb;
     const uint32_t lane = lane_id();
     // (the kernel that queues its general-form fields is only launched with the column tables in LDS: zdw_capi.hip)
     const bool cols_in_lds = DEFER ? true : a.use_lds_ranges != 0;
-    const P1Lds L = p1_layout(a.ncols, a.nnum, cols_in_lds, QCAP);
+    const P1Lds L = p1_layout(a.ncols, a.nnum, cols_in_lds, QCAP, wpb);
     ColTables t;
     t.meta = L.meta; t.mn = L.mn; t.mx = L.mx; t.seen = L.seen; t.cols_in_lds = cols_in_lds;
 
     // workgroup tables
-    for (uint32_t i = threadIdx.x; i < LUT_ROWS * 8u; i += 64 * P1_WPB) {
+    for (uint32_t i = threadIdx.x; i < LUT_ROWS * 8u; i += blockDim.x) {
         const uint32_t row = i >> 3, b0 = (i & 7u) * 4u;          // dword (i & 7) of row `row`: bytes b0 .. b0 + 3
         const uint32_t nb = row > b0 ? (row - b0 < 4u ? row - b0 : 4u) : 0u;
         *reinterpret_cast<uint32_t *>(zdw_lds + L.lut + 4u * i) = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
     }
     if (t.cols_in_lds) {
-        for (uint32_t c = threadIdx.x; c < a.ncols; c += 64 * P1_WPB) {
+        for (uint32_t c = threadIdx.x; c < a.ncols; c += blockDim.x) {
             *reinterpret_cast<uint32_t *>(zdw_lds + t.meta + 4 * c) = pack_col_meta(COLD(col_kind)[c], (uint32_t)COLD(col_numidx)[c] & 0x3fffu, COLD(col_recoff)[c]);
             zdw_lds[t.seen + c] = 0;
         }
-        for (uint32_t i = threadIdx.x; i < a.nnum; i += 64 * P1_WPB) {
+        for (uint32_t i = threadIdx.x; i < a.nnum; i += blockDim.x) {
             reinterpret_cast<uint64_t *>(zdw_lds + t.mn)[i] = ~0ull;
             reinterpret_cast<uint64_t *>(zdw_lds + t.mx)[i] = 0;
         }
@@ -1219,7 +1225,7 @@ __global__ __launch_bounds__(64 * P1_WPB, DEFER ? 6 : 1) void k_pass1(const Pass
         const int32_t *cn = COLD(col_numidx);
         uint8_t *cs = COLD(col_seen);
         uint64_t *cmn = COLD(col_min), *cmx = COLD(col_max);
-        for (uint32_t c = threadIdx.x; c < a.ncols; c += 64 * P1_WPB) {
+        for (uint32_t c = threadIdx.x; c < a.ncols; c += blockDim.x) {
             if (ck[c] == K_TEXT) {
                 if (zdw_lds[t.seen + c]) cs[c] = 1;
             } else {
@@ -1305,10 +1311,10 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     // three forms of the kernel: the ordinary one; a descriptor ring of 1024 for inputs with many boundaries per round; and, for
     // tables of mostly empty fields, the one whose tokeniser gives the tabs of empty fields no descriptors (few are left: the small ring)
     const uint32_t mode = a.skip_empty ? 2u : (a.dense_boundaries ? 1u : 0u);
-    const size_t lds = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, mode == 1u ? QCAP_LARGE : QCAP_SMALL).total;
+    const uint32_t qcap = mode == 1u ? QCAP_LARGE : QCAP_SMALL;
     // Waves walk the spans with a grid stride, so every wave carries the same share of the block: the grid
     // must not exceed what is resident at once, or the surplus waves run alone after the others finish.
-    int per_cu = 0, dev = 0, cus = 256;
+    int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     typedef void (*P1Fn)(const Pass1Args);
@@ -1319,15 +1325,43 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
 #undef P1_MODES
     const P1Fn kfn = fns[a.track_first != 0][a.span_state != nullptr][defer][trim][mode];
     const void *fn = (const void *)kfn;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * P1_WPB, lds) != hipSuccess || per_cu < 1) per_cu = 2;
-    const size_t by_lds = (160u * 1024u) / (((lds + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules
-    if ((size_t)per_cu > by_lds && by_lds >= 1) per_cu = (int)by_lds;
-    if (per_cu > 16) per_cu = 16;                                               // workgroup slots per CU
-    uint32_t max_blocks = (uint32_t)cus * (uint32_t)per_cu;
-    if (const char *e = experiment("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / P1_WPB;   // tuning experiments
-    const uint32_t want_blocks = (a.nspans + P1_WPB - 1) / P1_WPB;
+    // How many waves share a workgroup's column tables: the rings take ~6 KiB of LDS per wave and the tables their size once per
+    // workgroup, so the number of waves a CU holds depends on how they are grouped -- 8 per workgroup for the benchmark's 200 columns
+    // (3 workgroups: 24 waves, which is also what the registers allow), 10 for a schema of 1000 columns (2 x 10 instead of 2 x 8).
+    // The choice is remembered per kernel and LDS layout.
+    struct Choice { const void *fn; uint32_t ncols, nnum, lds_tables; uint32_t wpb, per_cu; };
+    static thread_local Choice cache[8];
+    static thread_local uint32_t cache_n = 0;
+    uint32_t wpb = 0, per_cu = 0;
+    for (uint32_t i = 0; i < cache_n && i < 8; ++i)
+        if (cache[i].fn == fn && cache[i].ncols == a.ncols && cache[i].nnum == a.nnum && cache[i].lds_tables == a.use_lds_ranges) { wpb = cache[i].wpb; per_cu = cache[i].per_cu; }
+    if (!wpb) {
+        uint32_t best_waves = 0;
+        for (uint32_t w = 4; w <= P1_WPB_MAX; ++w) {
+            const size_t l = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, qcap, w).total;
+            if (l > 160u * 1024u) break;
+            int pc = 0;
+            // (more than 64 KiB of dynamic LDS per workgroup has to be asked for)
+            if (l > 64u * 1024u && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, 64 * (int)w, l) != hipSuccess || pc < 1) { (void)hipGetLastError(); continue; }
+            const size_t by_lds = (160u * 1024u) / (((l + 1279) / 1280) * 1280);     // LDS is granted in 1280-byte granules
+            if ((size_t)pc > by_lds) pc = (int)by_lds;
+            if (pc > 16) pc = 16;                                                     // workgroup slots per CU
+            if (pc < 1) continue;
+            const uint32_t waves = (uint32_t)pc * w;
+            // (more waves; at equal numbers the default grouping, then the smaller workgroup)
+            if (waves > best_waves || (waves == best_waves && w == P1_WPB)) { best_waves = waves; wpb = w; per_cu = (uint32_t)pc; }
+        }
+        if (!wpb) { wpb = P1_WPB; per_cu = 1; }
+        if (const char *e = test_hook("ZDW_P1_WPB")) { wpb = (uint32_t)atoi(e); if (wpb < 1 || wpb > P1_WPB_MAX) wpb = P1_WPB; per_cu = 1; }      // tests: every grouping
+        cache[cache_n++ & 7u] = Choice{fn, a.ncols, a.nnum, a.use_lds_ranges, wpb, per_cu};
+    }
+    const size_t lds = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, qcap, wpb).total;
+    uint32_t max_blocks = (uint32_t)cus * per_cu;
+    if (const char *e = experiment("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / wpb;   // tuning experiments
+    const uint32_t want_blocks = (a.nspans + wpb - 1) / wpb;
     const uint32_t grid = want_blocks < max_blocks ? want_blocks : (max_blocks ? max_blocks : 1u);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * P1_WPB), lds, s, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * wpb), lds, s, a);
 }
 
 }  // namespace zdw
