@@ -80,6 +80,12 @@ constexpr uint32_t LUT_ROWS = 25;                 // byte masks "first L bytes" 
 // tables of mostly empty fields (a round of such data holds 1000+), whose boundaries are then emitted chunk by chunk
 // (~540 each).  What still does not fit is emitted in 16-lane pieces (<= 256 boundaries each), the ring drained in between.
 constexpr uint32_t QCAP_SMALL = 512, QCAP_LARGE = 1024;
+// A descriptor is the boundary's position relative to the visit.  Kept as its low 16 bits where nothing else rides on it: every pending
+// boundary lies less than 64 KiB below the end of what the tokeniser has emitted (WaveState.pos_hi; a round is only emitted into a ring
+// that still holds something when the boundary before the ring's head is that close -- otherwise the ring is drained first), so the
+// consumer rebuilds the position from the low bits.  Half the ring: 5 KiB of LDS per wave instead of 6, which is what decides how
+// many waves a CU holds.  (Tables of mostly empty fields: 24 bits of position and 8 of ordinal, four bytes.)
+__host__ __device__ constexpr uint32_t desc_bytes(bool skip) { return skip ? 4u : 2u; }
 constexpr uint32_t DESC_POS = 0xffffffu;
 // descriptors that may stay pending behind a chunk A / behind a round (the fields of what stays are handled a step later, while the
 // next chunk travels)
@@ -324,17 +330,18 @@ void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_
 // pass 1
 // ------------------------------------------------------------------------------------------
 // LDS of one workgroup (byte offsets into zdw_lds):
-//   desc   P1_WPB x QCAP x 4   descriptor rings (size-aligned: ring addressing is one and-or)
+//   desc   P1_WPB x QCAP x 2 or 4   descriptor rings (size-aligned: ring addressing is one and-or); 16-bit descriptors except in the
+//          form for tables of mostly empty fields (desc_bytes)
 //   bytes  P1_WPB x (16 + 4 KiB + 32)   byte rings, each between a copy of its last 16 and of its first 32 bytes
 //   lut    25 x 32 B        byte masks "first L bytes are 0xff" for L = 0..24
 //   meta / mn / mx / seen   column tables shared by the waves of the workgroup (cols_in_lds)
 struct P1Lds { uint32_t desc, bytes, lut, dqs, meta, mn, mx, seen, total; };
 
-__host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool cols_in_lds, uint32_t qcap, uint32_t wpb = P1_WPB)
+__host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool cols_in_lds, uint32_t ring_bytes /* of one descriptor ring */, uint32_t wpb = P1_WPB)
 {
     P1Lds L;
     L.desc = 0;
-    L.bytes = wpb * qcap * 4u;
+    L.bytes = wpb * ring_bytes;
     L.lut = L.bytes + wpb * RING_STRIDE;
     L.dqs = L.lut + LUT_ROWS * 32u;              // P1_WPB x {cur, end}: kept here, not in registers (the main loop has none to spare)
     L.meta = L.dqs + wpb * 8u;
@@ -350,9 +357,12 @@ __host__ __device__ inline P1Lds p1_layout(uint32_t ncols, uint32_t nnum, bool c
     return L;
 }
 
-size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds) { return p1_layout(ncols, nnum, use_lds, QCAP_SMALL).total; }
+size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds) { return p1_layout(ncols, nnum, use_lds, QCAP_SMALL * 4u).total; }
 
 __device__ __forceinline__ uint32_t lds_u32(uint32_t off) { return *reinterpret_cast<const uint32_t *>(zdw_lds + off); }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t off) { return *reinterpret_cast<const uint16_t *>(zdw_lds + off); }
+// the value in [ref - 65536, ref) whose low 16 bits are d16
+__device__ __forceinline__ uint32_t near_below(uint32_t ref, uint32_t d16) { return ref - 1u - ((ref - 1u - d16) & 0xffffu); }
 __device__ __forceinline__ uint64_t lds_u64(uint32_t off) { return *reinterpret_cast<const uint64_t *>(zdw_lds + off); }     // 8-byte aligned offsets only
 // Field bytes sit at any byte offset of the ring.  A ds_read_b64 / _b128 off its natural alignment is replayed at ~64
 // cycles per wave-instruction (SQ_LDS_UNALIGNED_STALL: 59 % of this kernel's LDS cycles before), so bytes are read
@@ -410,6 +420,7 @@ struct WaveState {
     uint64_t row_start;          // absolute position where the row that is open at the head descriptor began (m_LongestLine candidates)
     IdAlloc ids;                 // this wave's chunk of unique ids
     uint32_t rec_stride;         // Pass1Args.rec_stride, kept in a register (see k_pass1)
+    uint32_t pos_hi;             // 16-bit descriptors: every pending boundary lies in [pos_hi - 65536, pos_hi) (desc_bytes)
 };
 
 // Handles `cnt` (1..64) descriptors from the ring head, one per lane.  Returns how many new dictionary
@@ -425,7 +436,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // writes the scalar pair directly), are combined on the scalar unit, and become the exec mask of a block with lane_in().
     // A bool that is changed inside a branch and looked at behind it costs a v_cndmask and a v_cmp per use instead (it lives in a
     // vector register as 0 / 1), and this kernel is bound by the vector ALU's issue rate (profiles/r03_valu_issue_rate.txt).
-    constexpr uint32_t QM = QCAP * 4u - 1u;
+    constexpr uint32_t DB = desc_bytes(SKIP), QM = QCAP * DB - 1u;
     const uint64_t livem = mask_lt((int)cnt);
     const uint32_t di = ws.q_head + lane;
     // a descriptor: position of the boundary (24 bits, relative to the visit) | its ordinal among the visit's boundaries (8 bits).
@@ -433,7 +444,9 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // neighbours tell how many were skipped between them.
     // (SKIP: the kernel for tables of mostly empty fields.  Without it a descriptor is the position alone, every boundary has one,
     // and everything about ordinals below folds away.)
-    const uint32_t dsc = lds_u32(ws.desc | ((di << 2) & QM));
+    uint32_t dsc;
+    if (SKIP) dsc = lds_u32(ws.desc | ((di << 2) & QM));
+    else dsc = near_below(ws.pos_hi, lds_u16(ws.desc | ((di << 1) & QM)));      // (the position itself)
     const uint32_t e_pos = SKIP ? dsc & DESC_POS : dsc;
     // the boundary before mine: my left neighbour's, lane 0: the last one of the batch before (one DPP move, no second LDS read)
     uint32_t pdsc = (uint32_t)__builtin_amdgcn_update_dpp((int)(SKIP ? ws.last_e | (ws.last_ord << 24) : ws.last_e), (int)dsc, DPP_WAVE_SHR1, 0xf, 0xf, false);
@@ -522,7 +535,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         if (!dead && before) {
             const int p = highest_bit(before);
             if ((uint32_t)p + 1u != lane) {
-                pdsc = lds_u32(ws.desc | (((ws.q_head + (uint32_t)p) << 2) & QM));
+                if (SKIP) pdsc = lds_u32(ws.desc | (((ws.q_head + (uint32_t)p) << 2) & QM));
+                else pdsc = near_below(ws.pos_hi, lds_u16(ws.desc | (((ws.q_head + (uint32_t)p) << 1) & QM)));
                 pe_pos = SKIP ? pdsc & DESC_POS : pdsc;
                 // (the descriptors between that one and mine are escaped separators: kept, no fields)
                 if (SKIP) n_prev = ((dsc >> 24) - (pdsc >> 24) - 1u - (lane - (uint32_t)p - 1u)) & 0xffu;
@@ -810,7 +824,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             // block full of such fields: a single address takes about 30 M of them a second).  What is left of a chunk
             // that cannot take this call's fields is filled with blanks (length field all ones), which the second kernel skips.
             const uint32_t k = popc64(sm);
-            const uint32_t qs = L.dqs + ws.desc / (QCAP * 4u) * 8u;          // ws.desc = wave index x ring size
+            const uint32_t qs = L.dqs + ws.desc / (QCAP * DB) * 8u;          // ws.desc = wave index x ring size
             uint32_t cur = lds_u32(qs), end = lds_u32(qs + 4u);
             if (end - cur < k) {
                 const uint32_t left = end - cur;
@@ -851,7 +865,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
 template <bool DEFER, bool TRIM, uint32_t QCAP, bool SKIP, bool FOLD, bool TRACK>
 __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_pass1(const Pass1Args a)
 {
-    constexpr uint32_t QM = QCAP * 4u - 1u;
+    constexpr uint32_t DB = desc_bytes(SKIP), QM = QCAP * DB - 1u;
     // (the compiler cannot prove threadIdx.x >> 6 wave-uniform: without the readfirstlane everything derived from the wave's
     // number -- spans, positions, the whole visit bookkeeping -- lives in vector registers and every branch on it saves and
     // restores the exec mask)
@@ -861,7 +875,7 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
     const uint32_t lane = lane_id();
     // (the kernel that queues its general-form fields is only launched with the column tables in LDS: zdw_capi.hip)
     const bool cols_in_lds = DEFER ? true : a.use_lds_ranges != 0;
-    const P1Lds L = p1_layout(a.ncols, a.nnum, cols_in_lds, QCAP, wpb);
+    const P1Lds L = p1_layout(a.ncols, a.nnum, cols_in_lds, QCAP * DB, wpb);
     ColTables t;
     t.meta = L.meta; t.mn = L.mn; t.mx = L.mx; t.seen = L.seen; t.cols_in_lds = cols_in_lds;
 
@@ -890,11 +904,11 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
     asm volatile("" : "+s"(rebase_at), "+s"(hot_stride));
     WaveState ws;
     ws.rec_stride = hot_stride;
-    ws.desc = L.desc + wv * QCAP * 4u;
+    ws.desc = L.desc + wv * QCAP * DB;
     ws.bytes = L.bytes + wv * RING_STRIDE + RING_HEAD;
     ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.rel_se1 = 0; ws.first_pending = false; ws.vbase = 0;
     ws.ignoring = false; ws.prev_nl = false; ws.done = false; ws.row_start = 0; ws.last_e = 0;
-    ws.last_ord = 255u; ws.tok_ord = 0; ws.tok_prevb = 0; ws.tok_bs = false; ws.far = false; ws.far_abs = 0;
+    ws.last_ord = 255u; ws.tok_ord = 0; ws.tok_prevb = 0; ws.tok_bs = false; ws.far = false; ws.far_abs = 0; ws.pos_hi = 0;
     ws.ids.cur = ws.ids.end = 0;
     if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
@@ -994,7 +1008,8 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
         ws.tok_prevb = at_row_start ? 1u : 0u;      // the byte before the visit's first row is a line end: tabs right at its start are empty fields
         if (at_row_start) {
             // (every lane stores the same word: a branch on the lane number here would make q_count divergent for the compiler)
-            *reinterpret_cast<uint32_t *>(zdw_lds + ws.desc) = (uint32_t)(ss - 1 - ws.vbase) | (SKIP ? 255u << 24 : 0u);
+            if (SKIP) *reinterpret_cast<uint32_t *>(zdw_lds + ws.desc) = (uint32_t)(ss - 1 - ws.vbase) | (255u << 24);
+            else *reinterpret_cast<uint16_t *>(zdw_lds + ws.desc) = (uint16_t)(ss - 1 - ws.vbase);
             ws.q_count = 1;
         }
 
@@ -1011,14 +1026,18 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
         // this lane's kept boundaries `bits` (bit i = byte pos + i) from ring slot first_slot on; `all`: every boundary of the lane's
         // 16 bytes, ord0: the ordinal of the first of them
         auto emit = [&](uint32_t bits, uint32_t all, uint32_t ord0, uint32_t pos, uint32_t first_slot) {
-            uint32_t qoff = first_slot << 2;
+            uint32_t qoff = first_slot * DB;
             while (bits) {
                 const uint32_t i = (uint32_t)__builtin_ctz(bits);
                 bits &= bits - 1;
                 uint32_t dv = pos + i;
-                if (SKIP) dv |= (ord0 + (uint32_t)__builtin_popcount(all & ((1u << i) - 1u))) << 24;
-                *reinterpret_cast<uint32_t *>(zdw_lds + (ws.desc | (qoff & QM))) = dv;
-                qoff += 4;
+                if (SKIP) {
+                    dv |= (ord0 + (uint32_t)__builtin_popcount(all & ((1u << i) - 1u))) << 24;
+                    *reinterpret_cast<uint32_t *>(zdw_lds + (ws.desc | (qoff & QM))) = dv;
+                } else {
+                    *reinterpret_cast<uint16_t *>(zdw_lds + (ws.desc | (qoff & QM))) = (uint16_t)dv;
+                }
+                qoff += DB;
             }
         };
 
@@ -1040,6 +1059,7 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
         const uint8_t *lane_ptr = v_in + pos0 + 16u * lane;               // this lane's 16 bytes of chunk A of the current round
         uint4 P = load_chunk(lane_ptr);                                   // the one chunk in flight
         uint32_t relb = (uint32_t)(pos0 - ws.vbase);                      // relative position of the current round
+        ws.pos_hi = relb + ROUND;
         uint32_t first_rel = relb;                                        // nothing below it was loaded by this visit
         ws.ring_lo = first_rel;
         // The visit as a small state machine around ONE place that handles descriptors (the field work is most of
@@ -1133,8 +1153,11 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
                 const uint32_t ordA = ord_round + (exb2 & 0xffffu), ordB = ord_round + (totb2 & 0xffffu) + (exb2 >> 16);      // ordinals of this lane's first boundaries
                 ws.tok_ord += (totb2 & 0xffffu) + (totb2 >> 16);
                 near_end = relb + ROUND > ws.rel_se1 || relb + ROUND >= rel_hi;          // the span ends in this round or has ended: find the visit's end promptly
-                if (relb < rebase_at && ws.q_count + nb_total <= QCAP - 1) {
+                // (16-bit descriptors: what is still pending must lie within 64 KiB of this round's end -- it lies behind ws.last_e)
+                const bool in_reach = SKIP || ws.q_count == 0 || relb + ROUND - uniform32(ws.last_e) <= 65000u;      // (last_e lives in a vector register: it feeds a DPP move)
+                if (relb < rebase_at && ws.q_count + nb_total <= QCAP - 1 && in_reach) {
                     // the common round: everything fits
+                    ws.pos_hi = relb + ROUND;
                     const uint32_t tail = ws.q_head + ws.q_count;
                     emit(mA, bA, ordA, lrel, tail + (ex2 & 0xffffu));
                     emit(mB, bB, ordB, lrel + WROUND, tail + totA + (ex2 >> 16));
@@ -1178,6 +1201,7 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
                 const uint32_t piece_end = first_lane == 48u ? tot : lane_value(ex, (int)first_lane + 16);
                 const bool active = (lane >> 4) == (piece & 3u);
                 const uint32_t lrel = relb + 16u * lane;
+                ws.pos_hi = relb + ROUND;
                 emit(active ? (inB ? mB : mA) : 0u, inB ? bB : bA, inB ? ord_round + (totb2 & 0xffffu) + (exb2 >> 16) : ord_round + (exb2 & 0xffffu),
                      inB ? lrel + WROUND : lrel, ws.q_head + ws.q_count + ex - piece_base);
                 ws.q_count += piece_end - piece_base;
@@ -1207,7 +1231,7 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
     }
     retire_ids(ws.ids, COLD(uniq_len), COLD(id_cap));
     if (DEFER) {
-        const uint32_t qs = L.dqs + ws.desc / (QCAP * 4u) * 8u;
+        const uint32_t qs = L.dqs + ws.desc / (QCAP * DB) * 8u;
         uint64_t *dq0 = COLD(dq);
         const uint32_t dqc = COLD(dq_cap);
         for (uint32_t q = lds_u32(qs) + lane; q < lds_u32(qs + 4u); q += 64)
@@ -1311,7 +1335,7 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     // three forms of the kernel: the ordinary one; a descriptor ring of 1024 for inputs with many boundaries per round; and, for
     // tables of mostly empty fields, the one whose tokeniser gives the tabs of empty fields no descriptors (few are left: the small ring)
     const uint32_t mode = a.skip_empty ? 2u : (a.dense_boundaries ? 1u : 0u);
-    const uint32_t qcap = mode == 1u ? QCAP_LARGE : QCAP_SMALL;
+    const uint32_t qcap = (mode == 1u ? QCAP_LARGE : QCAP_SMALL) * desc_bytes(mode == 2u);      // bytes of a wave's descriptor ring
     // Waves walk the spans with a grid stride, so every wave carries the same share of the block: the grid
     // must not exceed what is resident at once, or the surplus waves run alone after the others finish.
     int dev = 0, cus = 256;
@@ -1337,7 +1361,7 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
         if (cache[i].fn == fn && cache[i].ncols == a.ncols && cache[i].nnum == a.nnum && cache[i].lds_tables == a.use_lds_ranges) { wpb = cache[i].wpb; per_cu = cache[i].per_cu; }
     if (!wpb) {
         uint32_t best_waves = 0;
-        for (uint32_t w = 4; w <= P1_WPB_MAX; ++w) {
+        for (uint32_t w = 4; w <= P1_WPB_MAX; w += 4) {          // (whole multiples of the CU's four SIMDs: 7 waves per workgroup, which would fit a 28th wave, ran 8 % slower than 8)
             const size_t l = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, qcap, w).total;
             if (l > 160u * 1024u) break;
             int pc = 0;
