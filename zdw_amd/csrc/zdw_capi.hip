@@ -205,6 +205,7 @@ struct zdw_ctx {
     uint64_t sorted_n = 0, sorted_holes = 0;
     bool uniques_sorted = false, presorted = false;
     // ... and as the owner of one key range of the node-wide dictionary
+    DevBuf own_key;               // ... of the owner's table (optional, like uniq_key)
     DevBuf own_slots, own_upos, own_ulen, own_status, own_extra, own_lens, own_offs, own_ids, own_idoff, own_blob, own_out;
     uint64_t own_count = 0, own_slice = 0, own_nids = 0;
     uint32_t own_max_len = 24;
@@ -993,7 +994,7 @@ std::vector<DevBuf *> all_device_buffers(zdw_ctx *c)
 {
     return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->span_state, &c->nz, &c->d_used_col, &c->scan_tmp, &c->scan_tmp2, &c->rec,
                       &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
-                      &c->own_upos, &c->own_ulen, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
+                      &c->own_upos, &c->own_ulen, &c->own_key, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
                       &c->own_out, &c->own_pos, &c->own_minpos, &c->own_flags, &c->model_len, &c->exp_pos, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
                       &c->uniq_pos, &c->uniq_len, &c->uniq_key, &c->key_a, &c->key_b, &c->val_a, &c->val_b, &c->order, &c->group,
                       &c->active_a, &c->active_b, &c->flags, &c->hist, &c->lenp1, &c->off_excl, &c->slot_off, &c->dict_sec, &c->extra,
@@ -2139,6 +2140,7 @@ int zdw_owner_import(zdw_ctx *c, const void *d_lens, const void *d_bytes, const 
     while (nslots < 2 * count) nslots <<= 1;
     const uint64_t cap = count + 64ull * 16384 + 64;
     HIP_TRY(c, c->own_slots.ensure(nslots * 32)); HIP_TRY(c, c->own_upos.ensure(cap * 8)); HIP_TRY(c, c->own_ulen.ensure(cap * 4));
+    if (c->budget.cap || c->own_key.ensure(cap * 24) != hipSuccess) c->own_key.release();      // (optional: ensure_dict's note on uniq_key)
     HIP_TRY(c, c->own_status.ensure(sizeof(P1Status)));
     HIP_TRY(c, c->own_extra.ensure(nbytes + 16)); HIP_TRY(c, c->own_lens.ensure((count + 1) * 4)); HIP_TRY(c, c->own_offs.ensure((count + 2) * 8));
     HIP_TRY(c, c->own_ids.ensure((count + 1) * 4));
@@ -2163,7 +2165,7 @@ int zdw_owner_import(zdw_ctx *c, const void *d_lens, const void *d_bytes, const 
     launch_import_strings(nullptr, 0, c->own_extra.as<uint8_t>(), c->own_lens.as<uint32_t>(), c->own_offs.as<uint64_t>(), count,
                           c->own_slots.as<uint64_t>(), nslots - 1, (uint32_t)std::min<uint64_t>(nslots - nslots / 8, 0xFFFFFFF0ull),
                           c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), (uint32_t)cap, 0u, 0, c->own_status.as<P1Status>(),
-                          c->own_ids.as<uint32_t>(), s);
+                          c->own_ids.as<uint32_t>(), s, c->own_key.as<uint64_t>());
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->own_status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -2204,7 +2206,8 @@ int zdw_owner_finish(zdw_ctx *c, uint64_t last_pos, uint64_t *slice_bytes)
         if (!c->own_has_pos) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_finish: the strings came without positions");
         launch_owner_filter(c->own_minpos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), (uint32_t)u, last_pos, s);
     }
-    int rc = sort_strings(c, nullptr, 0, c->own_extra.as<uint8_t>(), c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), u, c->own_max_len);
+    int rc = sort_strings(c, nullptr, 0, c->own_extra.as<uint8_t>(), c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(), u, c->own_max_len,
+                          c->own_key.as<uint64_t>());
     if (rc) return rc;
     {
         StageScope ts(c, ZDW_STAGE_DICT_EMIT);
@@ -2218,7 +2221,7 @@ int zdw_owner_finish(zdw_ctx *c, uint64_t last_pos, uint64_t *slice_bytes)
         HIP_TRY(c, c->own_idoff.ensure((u + 1) * 4));
         // blob[0] is the byte before the range (the origin byte when this is the first range); local offsets start at 1
         launch_dict_emit(nullptr, 0, c->own_extra.as<uint8_t>(), c->order.as<uint32_t>(), c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(),
-                         c->off_excl.as<uint64_t>(), u, c->own_blob.as<uint8_t>() + 8, c->own_idoff.as<uint32_t>(), s);
+                         c->off_excl.as<uint64_t>(), u, c->own_blob.as<uint8_t>() + 8, c->own_idoff.as<uint32_t>(), s, c->own_key.as<uint64_t>());
         HIP_TRY(c, hipStreamSynchronize(s));
         c->own_slice = total;
     }
