@@ -389,52 +389,79 @@ class _Laps:
             print("[dist laps, ms] " + " | ".join(self.out), file=sys.stderr)
 
 
+def _local(fn):
+    """Runs a rank-local step; returns (its result or None, 0 or the error's code, the error).  The code travels with the NEXT collective
+    (a rank that failed alone must not leave the others waiting in it): no collective of its own."""
+    from . import capi
+    try:
+        return fn(), 0, None
+    except capi.ZdwError as e:
+        return None, (e.code or 20), e
+
+
+def _raise_together(rcs, mine, err, what):
+    """rcs: every rank's code for the same step (the same list on every rank).  Raises on all of them when one failed."""
+    from . import capi
+    if any(rcs):
+        if err is not None:
+            raise err
+        raise capi.ZdwError(mine or max(rcs), "%s failed on a rank" % what)
+
+
 def partitioned_dictionary(enc, rank, world, device, group=None):
-    """The dictionary steps of one rank with the range-partitioned dictionary (after the range exchange)."""
+    """The dictionary steps of one rank with the range-partitioned dictionary (after the range exchange).  Returns the return code of
+    its last two rank-local steps (0, or the first failure's) and the error: the caller's next collective carries it (exchange_prev_row)."""
     laps = _Laps(rank)
 
     def _sample():
         enc.sort_uniques()
         return enc.sample_keys(SAMPLES_PER_SHARD)
-    mine = _guarded(_sample, device, group, "sampling the dictionary")
-    flat = [_u64_to_i64(w) for k in mine for w in k]
+    mine, rc, err = _local(_sample)
+    flat = [_u64_to_i64(w) for k in (mine or [(0, 0)] * SAMPLES_PER_SHARD) for w in k] + [rc]
     allk = allgather_i64(flat, device, group=group)
-    samples = [(_i64_to_u64(a[2 * i]), _i64_to_u64(a[2 * i + 1])) for a in allk for i in range(len(a) // 2)]
+    _raise_together([a[-1] for a in allk], rc, err, "sampling the dictionary")
+    samples = [(_i64_to_u64(a[2 * i]), _i64_to_u64(a[2 * i + 1])) for a in allk for i in range((len(a) - 1) // 2)]
     splitters = pick_splitters(samples, world)
     laps.mark("sample+splitters")
-    counts, nb, d_lens, d_bytes = _guarded(lambda: enc.partition(splitters), device, group, "partitioning the dictionary")
+    part, rc, err = _local(lambda: enc.partition(splitters))
+    if part is not None:
+        counts, nb, d_lens, d_bytes = part
+        lens = _wrap(d_lens, sum(counts) * 4, "<i4", device).clone()      # torch-owned copies: the collectives work on memory torch allocated
+        byts = _wrap(d_bytes, sum(nb), "|u1", device).clone()
+        _torch_done()
+    else:
+        counts, nb = [0] * world, [0] * world
+        lens, byts = torch.empty(0, dtype=torch.int32, device=device), torch.empty(0, dtype=torch.uint8, device=device)
     laps.mark("partition")
-    lens = _wrap(d_lens, sum(counts) * 4, "<i4", device).clone()      # torch-owned copies: the collectives work on memory torch allocated
-    byts = _wrap(d_bytes, sum(nb), "|u1", device).clone()
-    _torch_done()
-    rcounts, rbytes = exchange_counts(counts, device, group, nb)
+    rcounts, rbytes, rcs = exchange_counts(counts, device, group, nb, [rc] * world)
+    _raise_together(rcs, rc, err, "partitioning the dictionary")
     got_lens = alltoallv(lens, counts, rcounts, group=group)
     got_byts = alltoallv(byts, nb, rbytes, group=group)
     _torch_done()
     laps.mark("strings all-to-all")
     # (an owner whose build fails still reports: the size all-gather carries its code, so nobody waits for it in vain)
-    from . import capi
-    rc_own, slice_bytes = 0, 0
-    try:
-        slice_bytes = enc.owner_build(got_lens.data_ptr() if got_lens.numel() else 0, got_byts.data_ptr() if got_byts.numel() else 0,
-                                      got_lens.numel(), got_byts.numel())
-    except capi.ZdwError as e:
-        rc_own = e.code or 20
-    gathered = allgather_i64([slice_bytes, rc_own], device, group=group)
-    if any(a[1] for a in gathered):
-        raise capi.ZdwError(rc_own or max(a[1] for a in gathered), "building a dictionary range failed on a rank")
+    slice_bytes, rc_own, err = _local(lambda: enc.owner_build(got_lens.data_ptr() if got_lens.numel() else 0, got_byts.data_ptr() if got_byts.numel() else 0,
+                                                              got_lens.numel(), got_byts.numel()))
+    gathered = allgather_i64([slice_bytes or 0, rc_own], device, group=group)
+    _raise_together([a[1] for a in gathered], rc_own, err, "building a dictionary range")
     slices = [a[0] for a in gathered]
     laps.mark("owner build")
     bases, total = range_bases(slices)
-    d_offs = _guarded(lambda: enc.owner_offsets(bases[rank]), device, group, "dictionary offsets")
-    offs = _wrap(d_offs, sum(rcounts) * 4, "<i4", device).clone()
-    _torch_done()
+    # (the last two rank-local steps: their codes go to the caller, whose next collective carries them)
+    d_offs, rc_tail, err_tail = _local(lambda: enc.owner_offsets(bases[rank]))
+    if d_offs is not None:
+        offs = _wrap(d_offs, sum(rcounts) * 4, "<i4", device).clone()
+        _torch_done()
+    else:
+        offs = torch.zeros(int(sum(rcounts)), dtype=torch.int32, device=device)
     back = alltoallv(offs, rcounts, counts, group=group)
     _torch_done()
     laps.mark("offsets back")
-    _guarded(lambda: enc.set_offsets(back.data_ptr() if back.numel() else 0, back.numel(), total, rank == 0), device, group, "dictionary offsets")
+    if rc_tail == 0:
+        _, rc_tail, err_tail = _local(lambda: enc.set_offsets(back.data_ptr() if back.numel() else 0, back.numel(), total, rank == 0))
     laps.mark("set offsets")
     laps.done()
+    return rc_tail, err_tail
 
 
 def allreduce_ranges(mn, mx, seen, device, group=None, status=None):
@@ -505,22 +532,29 @@ def allgather_uniques(lens, byts, rank, world, group=None):
     return concat_uniques(parts, skip=rank)
 
 
-def exchange_prev_row(last_row, nrows, rank, world, device, group=None, line_caps=None, start_cap=FIRST_ROW_CAP, first=0):
+def exchange_prev_row(last_row, nrows, rank, world, device, group=None, line_caps=None, start_cap=FIRST_ROW_CAP, first=0, status=None):
     """Row halo: every rank learns the stored values that precede its first row.  With `line_caps` (this rank's
-    capi.Encoder.line_caps()) the same all-gather carries the tables and the block's m_LongestLine is returned too."""
+    capi.Encoder.line_caps()) the same all-gather carries the tables and the block's m_LongestLine is returned too.
+    status = (code, error) of this rank's steps since the last collective: the all-gather carries the code, and every rank raises
+    when one of them failed."""
     import torch.distributed as dist
     ncols = len(last_row)
     caps = list(line_caps) if line_caps is not None else []
-    mine = torch.empty(ncols + 1 + len(caps), dtype=torch.int64)
+    mine = torch.empty(ncols + 1 + len(caps) + (1 if status is not None else 0), dtype=torch.int64)
     mine[0] = nrows
     if ncols:
         mine[1:ncols + 1] = u64_to_ordered_i64(last_row)
     if caps:
-        mine[ncols + 1:] = torch.tensor(caps, dtype=torch.int64)
+        mine[ncols + 1:ncols + 1 + len(caps)] = torch.tensor(caps, dtype=torch.int64)
+    if status is not None:
+        mine[-1] = int(status[0])
     mine = mine.to(device)
     allr = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine, group=group)
     allr = [t.cpu() for t in allr]
+    if status is not None:
+        _raise_together([int(t[-1].item()) for t in allr], status[0], status[1], "the dictionary")
+        allr = [t[:-1] for t in allr]
     rows = [ordered_i64_to_u64(t[1:ncols + 1]) for t in allr]
     counts = [int(t[0].item()) for t in allr]
     # (`first`: the ranks before it hold none of the block's rows and say nothing about the row before its first one)
@@ -549,16 +583,18 @@ def encode_shard_dist(enc, rank, world, group=None, fetch=False, merge=None):
     if worst:
         raise capi.ZdwError(rc or worst, "pass 1 failed on rank %d" % rank if rc else "pass 1 failed on another rank")
     enc.import_ranges(mn, mx, seen)
+    rc_tail, err_tail = 0, None
     if merge == "partition":
-        partitioned_dictionary(enc, rank, world, device, group=group)
+        rc_tail, err_tail = partitioned_dictionary(enc, rank, world, device, group=group)
     else:
         lens, byts = export_uniques_tensors(enc, device)
         olens, obyts = allgather_uniques(lens, byts, rank, world, group=group)
         _torch_done()
-        _guarded(lambda: enc.import_uniques(olens.data_ptr(), obyts.data_ptr(), olens.numel(), obyts.numel()) if olens.numel() else None,
-                 device, group, "the dictionary import")
-    last, caps = _guarded(lambda: (enc.last_row(), enc.line_caps()), device, group, "the dictionary")
-    prev, longest = exchange_prev_row(last, p1.num_rows, rank, world, device, group=group, line_caps=caps)
+        _, rc_tail, err_tail = _local(lambda: enc.import_uniques(olens.data_ptr(), obyts.data_ptr(), olens.numel(), obyts.numel()) if olens.numel() else None)
+    # (the row halo's all-gather carries the code of everything rank-local since the last collective)
+    halo, rc_h, err_h = _local(lambda: (enc.last_row(), enc.line_caps())) if rc_tail == 0 else (None, rc_tail, err_tail)
+    last, caps = halo if halo is not None else ([0] * ncols, list(IDENTITY_CAPS))
+    prev, longest = exchange_prev_row(last, p1.num_rows, rank, world, device, group=group, line_caps=caps, status=(rc_h, err_h))
     enc.set_prev_row(prev)
     if fetch:
         sec, _ = enc.dict_section()
