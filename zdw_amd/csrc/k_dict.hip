@@ -380,7 +380,8 @@ void launch_dict_emit(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra
 __global__ __launch_bounds__(256) void k_export_strings(const uint8_t *__restrict__ in, const uint8_t *__restrict__ extra,
                                                          const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
                                                          const uint32_t *__restrict__ order, const uint64_t *__restrict__ off_excl, uint32_t n,
-                                                         uint8_t *__restrict__ bytes, uint32_t *__restrict__ lens_out)
+                                                         uint8_t *__restrict__ bytes, uint32_t *__restrict__ lens_out,
+                                                         const uint64_t *__restrict__ uniq_key)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -388,18 +389,30 @@ __global__ __launch_bounds__(256) void k_export_strings(const uint8_t *__restric
     const uint32_t len = uniq_len[u];
     if (lens_out) lens_out[i] = len;
     if (!len) return;                                            // hole: no bytes were reserved for it
-    const uint8_t *p = string_at(in, extra, uniq_pos[u]);
     uint8_t *q = bytes + off_excl[i];
+    if (uniq_key && len <= 24u) {                                // the whole string was kept by id (Pass1Args.uniq_key)
+        const uint64_t *k = uniq_key + 3ull * u;
+        uint64_t w = k[0];
+        uint32_t j = 0;
+        for (; j + 8 <= len; j += 8) {
+            reinterpret_cast<PackedU64 *>(q + j)->v = w;
+            w = j + 8 < len ? k[j / 8 + 1] : 0ull;
+        }
+        for (; j < len; ++j) { q[j] = (uint8_t)w; w >>= 8; }
+        q[len] = 0;
+        return;
+    }
+    const uint8_t *p = string_at(in, extra, uniq_pos[u]);
     for (uint32_t k = 0; k < len; ++k) q[k] = p[k];
     q[len] = 0;
 }
 
 void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, const uint32_t *order,
-                           const uint64_t *off_excl, uint64_t n, uint8_t *bytes, uint32_t *lens_out, hipStream_t s)
+                           const uint64_t *off_excl, uint64_t n, uint8_t *bytes, uint32_t *lens_out, hipStream_t s, const uint64_t *uniq_key)
 {
     if (!n) return;
     hipLaunchKernelGGL(k_export_strings, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, in, extra, uniq_pos, uniq_len, order, off_excl,
-                       (uint32_t)n, bytes, lens_out);
+                       (uint32_t)n, bytes, lens_out, uniq_key);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -440,14 +453,16 @@ __global__ __launch_bounds__(64) void k_key16_sample(const uint8_t *in, uint64_t
 // bucket of every unique id for the range partition: 0 = hole, 1 + (number of splitters <= the string's 16-byte key)
 __global__ __launch_bounds__(256) void k_bucket_of(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *__restrict__ uniq_pos,
                                                     const uint32_t *__restrict__ uniq_len, uint32_t nids, const uint64_t *__restrict__ splitters,
-                                                    uint32_t nsplit, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                                                    uint32_t nsplit, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                    const uint64_t *__restrict__ uniq_key)
 {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nids) return;
     uint32_t b = 0;
     if (uniq_len[id]) {
         uint64_t k0, k1;
-        key16_of(in, in_bytes, extra, uniq_pos, uniq_len, id, k0, k1);
+        if (uniq_key) { k0 = __builtin_bswap64(uniq_key[3ull * id]); k1 = __builtin_bswap64(uniq_key[3ull * id + 1]); }      // (kept by id: a streaming read)
+        else key16_of(in, in_bytes, extra, uniq_pos, uniq_len, id, k0, k1);
         uint32_t lo = 0, hi = nsplit;          // first splitter greater than the key
         while (lo < hi) {
             const uint32_t m = (lo + hi) >> 1;
@@ -521,13 +536,13 @@ void launch_key16_sample(const uint8_t *in, uint64_t in_bytes, const uint8_t *ex
 // (ids ascending inside a group); bounds has nparts + 2 entries (device).  One stable radix pass on the bucket number.
 void launch_bucket_partition(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                              uint32_t nids, const uint64_t *splitters, uint32_t nparts, SortBuffers &b, uint32_t *order_out, uint32_t *bounds,
-                             hipStream_t s)
+                             hipStream_t s, const uint64_t *uniq_key)
 {
     if (!nids) { (void)hipMemsetAsync(bounds, 0, (nparts + 2) * 4, s); return; }
     uint64_t *keys = b.key_a, *keys_alt = b.key_b;
     uint32_t *vals = b.val_a, *vals_alt = b.val_b;
     hipLaunchKernelGGL(k_bucket_of, dim3((nids + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, nids, splitters, nparts - 1,
-                       keys, vals);
+                       keys, vals, uniq_key);
     radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, nids, 0, nparts + 1 <= 256 ? 8 : 16, b.hist, b.scan_tmp, s);
     hipLaunchKernelGGL(k_lower_bounds, dim3((nparts + 2 + 63) / 64), dim3(64), 0, s, (const uint64_t *)keys, nids, nparts + 2, bounds);
     (void)hipMemcpyAsync(order_out, vals, (size_t)nids * 4, hipMemcpyDeviceToDevice, s);

@@ -1888,7 +1888,7 @@ int zdw_shard_export_uniques(zdw_ctx *c, const void **d_lens, const void **d_byt
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, c->exp_bytes.ensure(total + 16));
     launch_export_strings(c->d_in, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), nullptr, c->off_excl.as<uint64_t>(), u,
-                          c->exp_bytes.as<uint8_t>(), nullptr, s);
+                          c->exp_bytes.as<uint8_t>(), nullptr, s, c->uniq_key.as<uint64_t>());
     HIP_TRY(c, hipStreamSynchronize(s));
     if (d_lens) *d_lens = c->uniq_len.p;
     if (d_bytes) *d_bytes = c->exp_bytes.p;
@@ -2085,7 +2085,8 @@ int zdw_shard_partition(zdw_ctx *c, uint32_t nparts, const uint64_t *splitters, 
         HIP_TRY(c, c->part_split.ensure(nparts * 16 + 16)); HIP_TRY(c, c->part_bounds.ensure((nparts + 2) * 4));
         if (nparts > 1) HIP_TRY(c, hipMemcpyAsync(c->part_split.p, splitters, (nparts - 1) * 16, hipMemcpyHostToDevice, s));
         launch_bucket_partition(c->d_in, c->n, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), (uint32_t)c->sorted_n,
-                                c->part_split.as<uint64_t>(), nparts, b, c->my_order.as<uint32_t>(), c->part_bounds.as<uint32_t>(), s);
+                                c->part_split.as<uint64_t>(), nparts, b, c->my_order.as<uint32_t>(), c->part_bounds.as<uint32_t>(), s,
+                                c->uniq_key.as<uint64_t>());
         std::vector<uint32_t> gb(nparts + 2, 0);
         HIP_TRY(c, hipMemcpyAsync(gb.data(), c->part_bounds.p, (nparts + 2) * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
@@ -2116,7 +2117,7 @@ int zdw_shard_partition(zdw_ctx *c, uint32_t nparts, const uint64_t *splitters, 
     offs[nparts] = total;
     HIP_TRY(c, c->exp_bytes.ensure(total + 16));
     launch_export_strings(c->d_in, c->extra.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), c->uniq_len.as<uint32_t>(), order, c->off_excl.as<uint64_t>(),
-                          real, c->exp_bytes.as<uint8_t>(), c->part_lens.as<uint32_t>(), s);
+                          real, c->exp_bytes.as<uint8_t>(), c->part_lens.as<uint32_t>(), s, c->uniq_key.as<uint64_t>());
     HIP_TRY(c, hipStreamSynchronize(s));
     for (uint32_t p = 0; p < nparts; ++p) { counts[p] = bounds[p + 1] - bounds[p]; nbytes[p] = offs[p + 1] - offs[p]; }
     if (d_lens) *d_lens = c->part_lens.p;

@@ -147,7 +147,7 @@ void launch_import_strings(const uint8_t *in, uint64_t n, const uint8_t *extra, 
                            uint64_t *uniq_key = nullptr);
 void launch_export_strings(const uint8_t *in, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                            const uint32_t *order /* optional */, const uint64_t *off_excl, uint64_t n, uint8_t *bytes,
-                           uint32_t *lens_out /* optional */, hipStream_t s);
+                           uint32_t *lens_out /* optional */, hipStream_t s, const uint64_t *uniq_key = nullptr);
 // the reference's --mem-limit as a deterministic model (block ends)
 void launch_model_sort(const uint64_t *uniq_pos, const uint32_t *uniq_len, uint32_t n, SortBuffers &b, uint32_t **vals_out, hipStream_t s);
 void launch_model_trip(const uint64_t *excl, uint32_t nreal, double base_mb, double node_bytes, double limit_mb, uint64_t arena_bytes, uint64_t *out,
@@ -172,7 +172,7 @@ void launch_key16_sample(const uint8_t *in, uint64_t in_bytes, const uint8_t *ex
 struct SortBuffers;
 void launch_bucket_partition(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                              uint32_t nids, const uint64_t *splitters, uint32_t nparts, SortBuffers &b, uint32_t *order_out, uint32_t *bounds,
-                             hipStream_t s);
+                             hipStream_t s, const uint64_t *uniq_key = nullptr);
 void launch_partition_search(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                              const uint32_t *order, uint32_t lo, uint32_t hi, const uint64_t *splitters, uint32_t nsplit, uint32_t *bounds,
                              hipStream_t s);
