@@ -492,7 +492,10 @@ class Encoder:
         n = max(1, self.ncols)
         mn, mx, seen = (C.c_uint64 * n)(), (C.c_uint64 * n)(), (C.c_uint8 * n)()
         self._chk(self.L.zdw_shard_export_ranges(self.h, mn, mx, seen))
-        return list(mn)[:self.ncols], list(mx)[:self.ncols], list(seen)[:self.ncols]
+        import numpy as np
+        k = self.ncols
+        return (np.frombuffer(mn, dtype=np.uint64, count=k).tolist(), np.frombuffer(mx, dtype=np.uint64, count=k).tolist(),
+                np.frombuffer(seen, dtype=np.uint8, count=k).tolist())
 
     def import_ranges(self, mn, mx, seen):
         n = max(1, self.ncols)
@@ -585,7 +588,8 @@ class Encoder:
     def last_row(self):
         out = (C.c_uint64 * max(1, self.ncols))()
         self._chk(self.L.zdw_shard_last_row(self.h, out))
-        return list(out)[:self.ncols]
+        import numpy as np
+        return np.frombuffer(out, dtype=np.uint64, count=self.ncols).tolist()
 
     def line_caps(self):
         """[cap after this shard's rows when the line buffer held 16384 << k before them, k = 0..17]"""

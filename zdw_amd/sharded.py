@@ -40,12 +40,15 @@ def merge_ranges(parts):
 
 def u64_to_ordered_i64(vals):
     """unsigned order -> signed order (x xor 2^63), so that int64 MIN/MAX all-reduces compare as unsigned"""
-    t = torch.tensor([(v ^ U64_SIGN) - (1 << 64) if (v ^ U64_SIGN) >= U64_SIGN else (v ^ U64_SIGN) for v in vals], dtype=torch.int64)
-    return t
+    import numpy as np
+    a = np.asarray(vals, dtype=np.uint64) ^ np.uint64(U64_SIGN)          # (numpy: this runs once per step and column on every rank)
+    return torch.from_numpy(a.view(np.int64).copy())
 
 
 def ordered_i64_to_u64(t):
-    return [((int(x) & ((1 << 64) - 1)) ^ U64_SIGN) for x in t.tolist()]
+    import numpy as np
+    a = t.contiguous().numpy().view(np.uint64) ^ np.uint64(U64_SIGN)
+    return a.tolist()
 
 
 def concat_uniques(parts, skip=None):
