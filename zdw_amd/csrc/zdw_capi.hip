@@ -183,6 +183,8 @@ struct zdw_ctx {
     std::vector<uint64_t> h_min, h_max;
     std::vector<uint8_t> h_seen;
     // dictionary
+    P1Status st_host{};           // the device's status block as the host last read it, behind the last kernel that writes it
+    bool st_known = false;        // ... (pass 1, a block trim, a dictionary import): ensure_dict_size need not read it again
     DevBuf uniq_key;              // the strings' first 24 bytes by id (Pass1Args.uniq_key); left out when memory is short
     DevBuf uniq_pos, uniq_len, key_a, key_b, val_a, val_b, order, group, active_a, active_b, flags, hist, lenp1, off_excl,
         slot_off, dict_sec, extra, extra_lens, extra_offs, exp_bytes;
@@ -292,6 +294,7 @@ void collect_times(zdw_ctx *c)
 
 void reset_block(zdw_ctx *c)
 {
+    c->st_known = false;
     c->p1_done = c->dict_size_done = c->dict_done = c->stats_done = c->p2_size_done = c->p2_done = false;
     c->uniques_sorted = c->own_built = c->own_imported = false;
     c->nrows = 0; c->nuniq = 0; c->nids = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
@@ -611,9 +614,11 @@ int ensure_dict_size(zdw_ctx *c)
     if (!c->p1_done) return fail(c, ZDW_UNKNOWN_ERROR, "zdw_block_pass1 has not run for this block");
     hipStream_t s = c->stream;
     // pass 1 (and the shard import) left the uniques by id: uniq_pos / uniq_len, length 0 = hole
-    P1Status st{};
-    HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    P1Status st = c->st_host;
+    if (!c->st_known) {
+        HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
     const uint32_t count = st.id_next;
     c->dict_max_len = st.max_len > 24 ? st.max_len : 24;
     if (count > c->id_cap) return fail(c, ZDW_UNKNOWN_ERROR, "unique id counter (%u) beyond its table (%u)", count, c->id_cap);
@@ -788,6 +793,7 @@ int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zd
     HIP_TRY(c, hipMemsetAsync(c->col_max.p, 0, c->ncols * 8 + 8, s));
     HIP_TRY(c, hipMemsetAsync(c->col_seen.p, 0, c->ncols + 8, s));
     uint32_t *d_entries = &c->status.as<P1Status>()->entries;
+    c->st_known = false;
     HIP_TRY(c, hipMemsetAsync(d_entries, 0, 4, s));
     {
         StageScope ts(c, ZDW_STAGE_PASS1);
@@ -797,6 +803,7 @@ int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zd
     }
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    c->st_host = st; c->st_known = true;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "block trim launch: %s", hipGetErrorString(le));
     c->nrows = row;
@@ -1684,6 +1691,7 @@ int Pass1Job::results()
         HIP_TRY(c, hipMemcpy(c->h_seen.data(), c->col_seen.p, c->ncols, hipMemcpyDeviceToHost));
     }
     c->p1_done = true;
+    c->st_host = st; c->st_known = true;
     lap.mark("tail");
     lap.done("pass1_impl");
     if (tripped && nrows == 0) return fail(c, ZDW_OUT_OF_MEMORY, "block limit leaves no room for a single row");
@@ -1922,6 +1930,7 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
             return fail(c, ZDW_UNKNOWN_ERROR, "zdw_shard_import_uniques: lengths add up to %llu bytes, %llu were passed",
                         (unsigned long long)total, (unsigned long long)nbytes);
     }
+    c->st_known = false;
     launch_import_strings(c->d_in, c->n, c->extra.as<uint8_t>(), c->extra_lens.as<uint32_t>(), c->extra_offs.as<uint64_t>(), count,
                           c->slots.as<uint64_t>(), c->nslots - 1,
                           (uint32_t)std::min<uint64_t>(c->nslots - c->nslots / 8, 0xFFFFFFF0ull), c->uniq_pos.as<uint64_t>(),
@@ -1929,6 +1938,7 @@ int zdw_shard_import_uniques(zdw_ctx *c, const void *d_lens, const void *d_bytes
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    c->st_host = st; c->st_known = true;
     if (st.overflow)
         return fail(c, ZDW_OUT_OF_MEMORY, "dictionary table (%llu slots) too small for the merged dictionary: raise zdw_opts.dict_slots",
                     (unsigned long long)c->nslots);
