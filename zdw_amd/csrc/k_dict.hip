@@ -25,6 +25,7 @@ namespace zdw {
 // LSD radix sort of (u64 key, u32 value) pairs, 8-bit digits.  One wave per 2048-element chunk.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t SORT_CHUNK = 2048;
+constexpr uint32_t SMALL_RUN = 64;          // tied runs of up to this many strings are finished by one wave each (k_sort_finish_small)
 
 uint32_t sort_blocks(uint64_t n) { return (uint32_t)((n + SORT_CHUNK - 1) / SORT_CHUNK); }
 
@@ -212,9 +213,11 @@ __global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ i
 
 // tmp[j] = the unique that belongs at the j-th tied position after this round
 __global__ __launch_bounds__(256) void k_sort_gather(const uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
-                                                      const uint32_t *__restrict__ vals, uint32_t m, uint32_t *__restrict__ tmp)
+                                                      const uint32_t *__restrict__ vals, uint32_t m, uint32_t *__restrict__ tmp,
+                                                      uint32_t *__restrict__ max_run)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) *max_run = 0;                                  // (k_sort_ties, the next launch, takes the maximum)
     if (j < m) tmp[j] = order ? order[active[vals[j]]] : vals[j];
 }
 
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint32_t *__restrict_
 __global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     const uint32_t *__restrict__ group, const uint32_t *__restrict__ tmp,
                                                     const uint64_t *__restrict__ sorted_keys, uint32_t m,
-                                                    uint32_t *__restrict__ head, uint32_t *__restrict__ still)
+                                                    uint32_t *__restrict__ head, uint32_t *__restrict__ still, uint32_t *__restrict__ max_run)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -239,18 +242,88 @@ __global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order,
     // as the number of still-tied strings needs: count a head only for runs that stay in the working set
     head[j] = (!tie_prev && tie_next) ? 1u : 0u;
     still[j] = (tie_prev || tie_next) ? 1u : 0u;
+    if (!tie_prev && tie_next) {
+        // how long is the run this position starts?  Counted up to SMALL_RUN + 1: the host only asks whether every run is small
+        // enough for k_sort_finish_small to end the sort here
+        uint32_t len = 2;
+        while (len <= SMALL_RUN && j + len < m && group[j + len] == g && sorted_keys[j + len] == k) ++len;
+        if (len > *max_run) atomicMax(max_run, len);             // (an ordinary read first: the value only rises)
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sort_compact(const uint32_t *__restrict__ active, const uint32_t *__restrict__ head,
                                                        const uint32_t *__restrict__ still, const uint32_t *__restrict__ head_scan,
                                                        const uint32_t *__restrict__ still_scan, uint32_t m,
-                                                       uint32_t *__restrict__ active_out, uint32_t *__restrict__ group_out)
+                                                       uint32_t *__restrict__ active_out, uint32_t *__restrict__ group_out,
+                                                       uint32_t *__restrict__ run_start)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m || !still[j]) return;
     const uint32_t k = still_scan[j];
     active_out[k] = active[j];
     group_out[k] = head_scan[j] + head[j];      // run label: grows with position, equal inside a run
+    if (head[j]) run_start[head_scan[j]] = k;   // where run number label - 1 begins in the next round's working set
+}
+
+// The end of the sort when every tied run is small: one wave per run, a lane per string, every string compared with every other of
+// its run (the strings' first 24 bytes from the words kept by id where there are any, what lies behind from the image); the lane's
+// rank is where its string belongs.  The benchmark's table ends its second round with 1.7 M date-times tied in runs of up to 60 (one
+// per minute): this kernel instead of ten more radix passes.
+__global__ __launch_bounds__(256) void k_sort_finish_small(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
+                                                            const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
+                                                            const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ order,
+                                                            const uint32_t *__restrict__ active, const uint32_t *__restrict__ run_start,
+                                                            uint32_t nruns, uint32_t m, uint32_t *__restrict__ tmp, uint32_t *__restrict__ err)
+{
+    __shared__ uint64_t K[4][3][64];
+    __shared__ uint32_t U[4][64];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t r = blockIdx.x * 4u + wv;
+    if (r >= nruns) return;
+    const uint32_t s0 = run_start[r], e0 = r + 1 < nruns ? run_start[r + 1] : m;
+    const uint32_t len = e0 - s0;
+    if (len > 64u || e0 > m) { if (lane == 0) *err = 1; return; }      // (the host checked: cannot happen)
+    auto key_at = [&](uint32_t u, uint32_t ulen, uint32_t depth) -> uint64_t {
+        if (uniq_key && depth < 3) return __builtin_bswap64(uniq_key[3ull * u + depth]);
+        const uint64_t pos = uniq_pos[u];
+        const uint8_t *p = string_at(in, extra, pos);
+        return sort_key8(p, ulen, depth, pos >= EXTRA_BASE ? p + ulen + 16 : in + in_bytes);
+    };
+    uint32_t u = 0, ulen = 0;
+    uint64_t k0 = 0, k1 = 0, k2 = 0;
+    if (lane < len) {
+        u = order[active[s0 + lane]];
+        ulen = uniq_len[u];
+        k0 = key_at(u, ulen, 0); k1 = key_at(u, ulen, 1); k2 = key_at(u, ulen, 2);
+        K[wv][0][lane] = k0; K[wv][1][lane] = k1; K[wv][2][lane] = k2; U[wv][lane] = u;
+    }
+    __builtin_amdgcn_wave_barrier();          // (one wave per run: its LDS operations execute in order)
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < len; ++j) {
+        const uint64_t o0 = K[wv][0][j], o1 = K[wv][1][j], o2 = K[wv][2][j];
+        if (lane >= len || j == lane) continue;
+        bool less;                                                 // the other string sorts before mine
+        if (o0 != k0) less = o0 < k0;
+        else if (o1 != k1) less = o1 < k1;
+        else if (o2 != k2) less = o2 < k2;
+        else {
+            // equal in their first 24 bytes: both are longer; on through the image, 8 bytes at a time (zero padding: the shorter first)
+            const uint32_t ou = U[wv][j], olen = uniq_len[ou];
+            less = false;
+            for (uint32_t d = 3; 8u * d < ulen || 8u * d < olen; ++d) {
+                const uint64_t a = key_at(ou, olen, d), b = key_at(u, ulen, d);
+                if (a != b) { less = a < b; break; }
+            }
+        }
+        rank += less ? 1u : 0u;
+    }
+    if (lane < len) tmp[s0 + rank] = u;
+}
+
+__global__ __launch_bounds__(256) void k_sort_place(uint32_t *__restrict__ order, const uint32_t *__restrict__ active, const uint32_t *__restrict__ tmp, uint32_t m)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) order[active[k]] = tmp[k];
 }
 
 // Sort n unique strings.  Buffers: see SortBuffers.  Returns 0 or a hipError_t.
@@ -273,6 +346,8 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     uint32_t *still_scan = head_scan + n + 1;
     uint32_t *tmp = still_scan + n + 1;
     uint32_t *group_next = tmp + n;
+    uint32_t *d_max_run = b.hist + 2 * ((size_t)256 * sort_blocks(n) + 1);      // two spare words behind the histograms: the round's longest tied run (capped), an error flag
+    HIPCHK(hipMemsetAsync(d_max_run, 0, 8, s));
     for (uint32_t depth = 0; m > 1; ++depth) {
         ++rounds;
         if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] depth %u: m = %u of n = %u\n", depth, m, n);
@@ -289,19 +364,33 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
             while (bits < 32 && (1ull << bits) <= (uint64_t)max_label) ++bits;
             radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
         }
-        hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active, vals, m, tmp);
-        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active, group, tmp, (const uint64_t *)keys, m, head, still);
+        hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active, vals, m, tmp, d_max_run);
+        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active, group, tmp, (const uint64_t *)keys, m, head, still, d_max_run);
         launch_scan_u32_to_u32(head, head_scan, m, b.scan_tmp, nullptr, s);
         launch_scan_u32_to_u32(still, still_scan, m, b.scan_tmp, nullptr, s);
+        uint32_t *run_start = reinterpret_cast<uint32_t *>(keys == b.key_a ? b.key_b : b.key_a);      // (the pairs' other buffer: free behind the radix passes)
         hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active, head, still, head_scan, still_scan, m, active_alt,
-                           group_next);
+                           group_next, run_start);
         uint32_t m_next = 0;
         HIPCHK(hipMemcpyAsync(&m_next, still_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(&max_label, head_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        uint32_t max_run = 0;
+        HIPCHK(hipMemcpyAsync(&max_run, d_max_run, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         uint32_t *t = active; active = active_alt; active_alt = t;
         t = group; group = group_next; group_next = t;
         m = m_next;
+        if (m > 1 && max_run <= SMALL_RUN && max_label > 0 && !test_hook("ZDW_SORT_NO_FINISH")) {
+            // every run that is still tied is small: a wave each instead of further rounds
+            hipLaunchKernelGGL(k_sort_finish_small, dim3((max_label + 3) / 4), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order,
+                               active, run_start, max_label, m, tmp, d_max_run + 1);
+            hipLaunchKernelGGL(k_sort_place, dim3((m + 255) / 256), dim3(256), 0, s, b.order, active, tmp, m);
+            uint32_t bad = 0;
+            HIPCHK(hipMemcpyAsync(&bad, d_max_run + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (bad) return (int)hipErrorUnknown;
+            break;
+        }
         if (depth > max_len / 8 + 2) return (int)hipErrorUnknown;   // cannot happen: two distinct strings differ within max_len bytes
     }
     if (rounds_out) *rounds_out = rounds;
