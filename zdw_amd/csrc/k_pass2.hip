@@ -693,9 +693,11 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
             const void *fn = staged ? (const void *)k_pass2_size_cols<true> : (const void *)k_pass2_size_cols<false>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
             uint32_t per_cu = std::min(6u, (uint32_t)occ);      // six workgroups per CU measured best (8: 1.36x the time)
-            // ... alone on the chip.  Beside the dictionary sort (second stream, ensure_dict) three leave the sort's launch-bound
-            // kernels room: 10 GB, sort + sizes 3.6 + 1.6 ms with six (no better than one after the other), 3.2 + 3.9 with three
-            if (a.background) per_cu = std::min(per_cu, 3u);
+            // ... alone on the chip.  Beside the dictionary sort (second stream, ensure_dict) fewer leave the sort's launch-bound
+            // kernels room: 10 GB, sort / sizes / step 3.5 / 1.6 / 20.0 ms with six (no better than one after the other),
+            // 2.9 / 2.1 / 19.35 with five, 2.7 / 2.5 / 19.08 with four, 2.7 / 3.3 / 19.14 with three, 2.4 / 4.2 / 19.9 with two
+            // (tools/ab_size_wgs.sh; three was best while the sort took 3.1 ms)
+            if (a.background) per_cu = std::min(per_cu, 4u);
             if (const char *e = experiment("ZDW_P2_SIZE_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
             if (staged) hipLaunchKernelGGL(k_pass2_size_cols<true>, dim3(grid), dim3(256), lds, s, a);
