@@ -243,11 +243,10 @@ __global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order,
     head[j] = (!tie_prev && tie_next) ? 1u : 0u;
     still[j] = (tie_prev || tie_next) ? 1u : 0u;
     if (!tie_prev && tie_next) {
-        // how long is the run this position starts?  Counted up to SMALL_RUN + 1: the host only asks whether every run is small
-        // enough for k_sort_finish_small to end the sort here
-        uint32_t len = 2;
-        while (len <= SMALL_RUN && j + len < m && group[j + len] == g && sorted_keys[j + len] == k) ++len;
-        if (len > *max_run) atomicMax(max_run, len);             // (an ordinary read first: the value only rises)
+        // is the run this position starts longer than SMALL_RUN?  The host only asks whether EVERY run is small enough for
+        // k_sort_finish_small to end the sort here: one look at the element SMALL_RUN places on (the run is contiguous), and a plain
+        // store of the same word by whoever finds a long one (no atomic: a few hundred thousand heads would queue on it)
+        if (j + SMALL_RUN < m && group[j + SMALL_RUN] == g && sorted_keys[j + SMALL_RUN] == k) *max_run = SMALL_RUN + 1;
     }
 }
 
