@@ -222,14 +222,14 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint32_t *__restrict_
 }
 
 // writes the round's result back and flags what is still tied:
-//   head[j]   = 1 when position j starts a run of two or more equal (group, key)
-//   still[j]  = 1 when position j is tied with a neighbour (needs another round)
+//   bit 1 of still[j] ("head") = position j starts a run of two or more equal (group, key)
+//   bit 0 of still[j]          = position j is tied with a neighbour (needs another round)
 // The radix sort's key array is aligned with the result (the tie-group passes move the pairs along), so no
 // string is read here.
 __global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     const uint32_t *__restrict__ group, const uint32_t *__restrict__ tmp,
                                                     const uint64_t *__restrict__ sorted_keys, uint32_t m,
-                                                    uint32_t *__restrict__ head, uint32_t *__restrict__ still, uint32_t *__restrict__ max_run)
+                                                    uint32_t *__restrict__ still, uint32_t *__restrict__ max_run)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -240,8 +240,7 @@ __global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order,
     const bool tie_next = j + 1 < m && group[j + 1] == g && sorted_keys[j + 1] == k;
     // run labels must stay dense (1..#runs) because the next round radix-sorts them on as few bits
     // as the number of still-tied strings needs: count a head only for runs that stay in the working set
-    head[j] = (!tie_prev && tie_next) ? 1u : 0u;
-    still[j] = (tie_prev || tie_next) ? 1u : 0u;
+    still[j] = ((tie_prev || tie_next) ? 1u : 0u) | ((!tie_prev && tie_next) ? 2u : 0u);
     if (!tie_prev && tie_next) {
         // is the run this position starts longer than SMALL_RUN?  The host only asks whether EVERY run is small enough for
         // k_sort_finish_small to end the sort here: one look at the element SMALL_RUN places on (the run is contiguous), and a plain
@@ -250,18 +249,20 @@ __global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order,
     }
 }
 
-__global__ __launch_bounds__(256) void k_sort_compact(const uint32_t *__restrict__ active, const uint32_t *__restrict__ head,
+__global__ __launch_bounds__(256) void k_sort_compact(const uint32_t *__restrict__ active,
                                                        const uint32_t *__restrict__ still, const uint32_t *__restrict__ head_scan,
                                                        const uint32_t *__restrict__ still_scan, uint32_t m,
                                                        uint32_t *__restrict__ active_out, uint32_t *__restrict__ group_out,
                                                        uint32_t *__restrict__ run_start)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m || !still[j]) return;
-    const uint32_t k = still_scan[j];
+    if (j >= m) return;
+    const uint32_t f = still[j];
+    if (!(f & 1u)) return;
+    const uint32_t k = still_scan[j], head = (f >> 1) & 1u;
     active_out[k] = active[j];
-    group_out[k] = head_scan[j] + head[j];      // run label: grows with position, equal inside a run
-    if (head[j]) run_start[head_scan[j]] = k;   // where run number label - 1 begins in the next round's working set
+    group_out[k] = head_scan[j] + head;         // run label: grows with position, equal inside a run
+    if (head) run_start[head_scan[j]] = k;      // where run number label - 1 begins in the next round's working set
 }
 
 // The end of the sort when every tied run is small: one wave per run, a lane per string, every string compared with every other of
@@ -364,11 +365,10 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
             radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
         }
         hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active, vals, m, tmp, d_max_run);
-        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active, group, tmp, (const uint64_t *)keys, m, head, still, d_max_run);
-        launch_scan_u32_to_u32(head, head_scan, m, b.scan_tmp, nullptr, s);
-        launch_scan_u32_to_u32(still, still_scan, m, b.scan_tmp, nullptr, s);
+        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active, group, tmp, (const uint64_t *)keys, m, still, d_max_run);
+        launch_scan_two_flags(still, still_scan, head_scan, m, b.scan_tmp, s);
         uint32_t *run_start = reinterpret_cast<uint32_t *>(keys == b.key_a ? b.key_b : b.key_a);      // (the pairs' other buffer: free behind the radix passes)
-        hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active, head, still, head_scan, still_scan, m, active_alt,
+        hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active, still, head_scan, still_scan, m, active_alt,
                            group_next, run_start);
         uint32_t m_next = 0;
         HIPCHK(hipMemcpyAsync(&m_next, still_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

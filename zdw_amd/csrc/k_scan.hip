@@ -113,6 +113,55 @@ static void scan_impl(const uint32_t *in, TOut *out, uint64_t n, void *tmp, uint
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_apply<TOut>), dim3((uint32_t)nchunks), dim3(SCAN_THREADS), 0, s, in, out, n, sums);
 }
 
+// Two exclusive scans in one: in[i] holds two flags (bit 0, bit 1); out0 / out1 (n + 1 elements each) = how many elements before i have
+// bit 0 / bit 1 set.  The two counts travel as the halves of one 64-bit sum (n < 2^32), so the three launches serve both.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan2_chunk_sums(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ sums)
+{
+    __shared__ uint64_t lds[8];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) { const uint32_t x = in[base + i]; v += (uint64_t)(x & 1u) | ((uint64_t)((x >> 1) & 1u) << 32); }
+    uint64_t tot;
+    block_excl_scan(v, &tot, lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan2_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out0, uint32_t *__restrict__ out1,
+                                                              uint64_t n, const uint64_t *__restrict__ sums)
+{
+    __shared__ uint64_t lds[8];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t x[SCAN_ITEMS];
+    uint64_t v = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < SCAN_ITEMS; ++i) {
+        const uint32_t f = base + i < n ? in[base + i] : 0u;
+        x[i] = (uint64_t)(f & 1u) | ((uint64_t)((f >> 1) & 1u) << 32);
+        v += x[i];
+    }
+    uint64_t tot;
+    uint64_t run = block_excl_scan(v, &tot, lds) + sums[blockIdx.x];
+#pragma unroll
+    for (uint32_t i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) { out0[base + i] = (uint32_t)run; out1[base + i] = (uint32_t)(run >> 32); }
+        run += x[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) {
+        const uint64_t all = sums[blockIdx.x] + tot;
+        out0[n] = (uint32_t)all; out1[n] = (uint32_t)(all >> 32);
+    }
+}
+void launch_scan_two_flags(const uint32_t *in, uint32_t *out0, uint32_t *out1, uint64_t n, void *tmp, hipStream_t s)
+{
+    if (n == 0) { (void)hipMemsetAsync(out0, 0, 4, s); (void)hipMemsetAsync(out1, 0, 4, s); return; }
+    const uint64_t nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    uint64_t *sums = static_cast<uint64_t *>(tmp);
+    hipLaunchKernelGGL(k_scan2_chunk_sums, dim3((uint32_t)nchunks), dim3(SCAN_THREADS), 0, s, in, n, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, s, sums, nchunks, (uint64_t *)nullptr);
+    hipLaunchKernelGGL(k_scan2_apply, dim3((uint32_t)nchunks), dim3(SCAN_THREADS), 0, s, in, out0, out1, n, sums);
+}
+
 void launch_scan_u32_to_u32(const uint32_t *in, uint32_t *out, uint64_t n, void *tmp, uint64_t *total, hipStream_t s)
 {
     scan_impl<uint32_t>(in, out, n, tmp, total, s);

@@ -118,6 +118,8 @@ size_t pass1_lds_bytes(uint32_t ncols, uint32_t nnum, bool use_lds);
 // exclusive scans; tmp must hold scan_tmp_bytes(n) bytes; total (optional) receives the sum
 size_t scan_tmp_bytes(uint64_t n);
 void launch_scan_u32_to_u32(const uint32_t *in, uint32_t *out, uint64_t n, void *tmp, uint64_t *total, hipStream_t s);
+// two flags per element (bit 0, bit 1) -> their two exclusive scans (n + 1 elements each) in one go
+void launch_scan_two_flags(const uint32_t *in, uint32_t *out0, uint32_t *out1, uint64_t n, void *tmp, hipStream_t s);
 void launch_scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, uint64_t *total, hipStream_t s);
 
 // dictionary
