@@ -1357,7 +1357,8 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
     static thread_local Choice cache[8];
     static thread_local uint32_t cache_n = 0;
     uint32_t wpb = 0, per_cu = 0;
-    for (uint32_t i = 0; i < cache_n && i < 8; ++i)
+    const char *forced = test_hook("ZDW_P1_WPB");          // tests: every grouping (not remembered)
+    for (uint32_t i = 0; !forced && i < cache_n && i < 8; ++i)
         if (cache[i].fn == fn && cache[i].ncols == a.ncols && cache[i].nnum == a.nnum && cache[i].lds_tables == a.use_lds_ranges) { wpb = cache[i].wpb; per_cu = cache[i].per_cu; }
     if (!wpb) {
         uint32_t best_waves = 0;
@@ -1377,10 +1378,11 @@ void launch_pass1(const Pass1Args &a, hipStream_t s)
             if (waves > best_waves || (waves == best_waves && w == P1_WPB)) { best_waves = waves; wpb = w; per_cu = (uint32_t)pc; }
         }
         if (!wpb) { wpb = P1_WPB; per_cu = 1; }
-        if (const char *e = test_hook("ZDW_P1_WPB")) { wpb = (uint32_t)atoi(e); if (wpb < 1 || wpb > P1_WPB_MAX) wpb = P1_WPB; per_cu = 1; }      // tests: every grouping
-        cache[cache_n++ & 7u] = Choice{fn, a.ncols, a.nnum, a.use_lds_ranges, wpb, per_cu};
+        if (forced) { wpb = (uint32_t)atoi(forced); if (wpb < 1 || wpb > P1_WPB_MAX) wpb = P1_WPB; per_cu = 1; }
+        else cache[cache_n++ & 7u] = Choice{fn, a.ncols, a.nnum, a.use_lds_ranges, wpb, per_cu};
     }
-    const size_t lds = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, qcap, wpb).total;
+    size_t lds = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, qcap, wpb).total;
+    while (lds > 160u * 1024u && wpb > 1) lds = p1_layout(a.ncols, a.nnum, a.use_lds_ranges != 0, qcap, --wpb).total;      // (a forced grouping the schema's tables leave no room for)
     uint32_t max_blocks = (uint32_t)cus * per_cu;
     if (const char *e = experiment("ZDW_P1_WAVES_PER_CU")) max_blocks = (uint32_t)cus * (uint32_t)atoi(e) / wpb;   // tuning experiments
     const uint32_t want_blocks = (a.nspans + wpb - 1) / wpb;
