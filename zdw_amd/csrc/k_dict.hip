@@ -242,10 +242,10 @@ __global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order,
     // as the number of still-tied strings needs: count a head only for runs that stay in the working set
     still[j] = ((tie_prev || tie_next) ? 1u : 0u) | ((!tie_prev && tie_next) ? 2u : 0u);
     if (!tie_prev && tie_next) {
-        // is the run this position starts longer than SMALL_RUN?  The host only asks whether EVERY run is small enough for
-        // k_sort_finish_small to end the sort here: one look at the element SMALL_RUN places on (the run is contiguous), and a plain
-        // store of the same word by whoever finds a long one (no atomic: a few hundred thousand heads would queue on it)
-        if (j + SMALL_RUN < m && group[j + SMALL_RUN] == g && sorted_keys[j + SMALL_RUN] == k) *max_run = SMALL_RUN + 1;
+        // is the run this position starts longer than SMALL_RUN?  One look at the element SMALL_RUN places on (the run is contiguous).
+        // The host asks how many such runs there are: none -- k_sort_finish_small ends the sort here; one -- it finishes all the others
+        // and the next round sorts that one run alone (no tie-group passes)
+        if (j + SMALL_RUN < m && group[j + SMALL_RUN] == g && sorted_keys[j + SMALL_RUN] == k) atomicAdd(max_run, 1u);      // (long runs are few: one count each)
     }
 }
 
@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void k_sort_finish_small(const uint8_t *__rest
     if (r >= nruns) return;
     const uint32_t s0 = run_start[r], e0 = r + 1 < nruns ? run_start[r + 1] : m;
     const uint32_t len = e0 - s0;
-    if (len > 64u || e0 > m) { if (lane == 0) *err = 1; return; }      // (the host checked: cannot happen)
+    if (e0 > m || e0 <= s0) { if (lane == 0) err[0] = 1; return; }      // (cannot happen)
+    if (len > SMALL_RUN) { if (lane == 0) { err[1] = s0; err[2] = e0; } return; }      // the one long run (the host has counted): where it lies, for the next round
     auto key_at = [&](uint32_t u, uint32_t ulen, uint32_t depth) -> uint64_t {
         if (uniq_key && depth < 3) return __builtin_bswap64(uniq_key[3ull * u + depth]);
         const uint64_t pos = uniq_pos[u];
@@ -320,10 +321,66 @@ __global__ __launch_bounds__(256) void k_sort_finish_small(const uint8_t *__rest
     if (lane < len) tmp[s0 + rank] = u;
 }
 
-__global__ __launch_bounds__(256) void k_sort_place(uint32_t *__restrict__ order, const uint32_t *__restrict__ active, const uint32_t *__restrict__ tmp, uint32_t m)
+// The same for runs of two or three strings (hundreds of thousands of them after a first round: a wave each would be a wave of two
+// busy lanes): a THREAD per string, which walks its run and counts the members that sort before it.  Strings of the one long run
+// leave at once.
+__global__ __launch_bounds__(256) void k_sort_finish_tiny(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
+                                                           const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
+                                                           const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ order,
+                                                           const uint32_t *__restrict__ active, const uint32_t *__restrict__ group,
+                                                           const uint32_t *__restrict__ run_start, uint32_t nruns, uint32_t m,
+                                                           uint32_t *__restrict__ tmp, uint32_t *__restrict__ err)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < m) order[active[k]] = tmp[k];
+    if (k >= m) return;
+    const uint32_t r = group[k] - 1u;
+    if (r >= nruns) { err[0] = 1; return; }                             // (cannot happen)
+    const uint32_t s0 = run_start[r], e0 = r + 1 < nruns ? run_start[r + 1] : m;
+    if (e0 > m || e0 <= s0 || k < s0 || k >= e0) { err[0] = 1; return; }      // (cannot happen)
+    if (e0 - s0 > SMALL_RUN) { if (k == s0) { err[1] = s0; err[2] = e0; } return; }
+    auto key_at = [&](uint32_t u, uint32_t ulen, uint32_t depth) -> uint64_t {
+        if (uniq_key && depth < 3) return __builtin_bswap64(uniq_key[3ull * u + depth]);
+        const uint64_t pos = uniq_pos[u];
+        const uint8_t *p = string_at(in, extra, pos);
+        return sort_key8(p, ulen, depth, pos >= EXTRA_BASE ? p + ulen + 16 : in + in_bytes);
+    };
+    const uint32_t u = order[active[k]], ulen = uniq_len[u];
+    const uint64_t k0 = key_at(u, ulen, 0), k1 = key_at(u, ulen, 1), k2 = key_at(u, ulen, 2);
+    uint32_t rank = 0;
+    for (uint32_t i = s0; i < e0; ++i) {
+        if (i == k) continue;
+        const uint32_t ou = order[active[i]], olen = uniq_len[ou];
+        const uint64_t o0 = key_at(ou, olen, 0);
+        bool less;
+        if (o0 != k0) less = o0 < k0;
+        else {
+            const uint64_t o1 = key_at(ou, olen, 1);
+            if (o1 != k1) less = o1 < k1;
+            else {
+                const uint64_t o2 = key_at(ou, olen, 2);
+                if (o2 != k2) less = o2 < k2;
+                else {
+                    less = false;
+                    for (uint32_t d = 3; 8u * d < ulen || 8u * d < olen; ++d) {
+                        const uint64_t a = key_at(ou, olen, d), b = key_at(u, ulen, d);
+                        if (a != b) { less = a < b; break; }
+                    }
+                }
+            }
+        }
+        rank += less ? 1u : 0u;
+    }
+    tmp[s0 + rank] = u;
+}
+
+// (skip: the run k_sort_finish_small left for the next round, [skip[0], skip[1]); nullptr: none)
+__global__ __launch_bounds__(256) void k_sort_place(uint32_t *__restrict__ order, const uint32_t *__restrict__ active, const uint32_t *__restrict__ tmp, uint32_t m,
+                                                    const uint32_t *__restrict__ skip)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    if (skip && k >= skip[0] && k < skip[1]) return;
+    order[active[k]] = tmp[k];
 }
 
 // Sort n unique strings.  Buffers: see SortBuffers.  Returns 0 or a hipError_t.
@@ -346,8 +403,11 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     uint32_t *still_scan = head_scan + n + 1;
     uint32_t *tmp = still_scan + n + 1;
     uint32_t *group_next = tmp + n;
-    uint32_t *d_max_run = b.hist + 2 * ((size_t)256 * sort_blocks(n) + 1);      // two spare words behind the histograms: the round's longest tied run (capped), an error flag
-    HIPCHK(hipMemsetAsync(d_max_run, 0, 8, s));
+    // four spare words behind the histograms: [0] runs longer than SMALL_RUN that stay tied after the round, [1] an error flag,
+    // [2], [3] where the one long run lies in the next working set (k_sort_finish_small)
+    uint32_t *d_big = b.hist + 2 * ((size_t)256 * sort_blocks(n) + 1);
+    HIPCHK(hipMemsetAsync(d_big, 0, 16, s));
+    uint32_t off = 0;                              // the working set is [off, off + m) of the active list (off > 0: one long run alone)
     for (uint32_t depth = 0; m > 1; ++depth) {
         ++rounds;
         if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] depth %u: m = %u of n = %u\n", depth, m, n);
@@ -355,40 +415,50 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
         uint64_t *keys = b.key_a, *keys_alt = b.key_b;
         uint32_t *vals = b.val_a, *vals_alt = b.val_b;
         const uint32_t *order_in = depth ? b.order : nullptr;      // identity in the first round
-        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active, m, depth, keys, vals, uniq_key);
+        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active + off, m, depth, keys, vals, uniq_key);
         radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, 64, b.hist, b.scan_tmp, s);
-        if (depth > 0) {
+        if (depth > 0 && max_label > 1) {
             // stable, more significant key: the tie group of the element's old position (labels are < m + 1)
             // (labels are 1 .. the number of runs that stayed in the working set: read back with the round's count)
             uint32_t bits = 1;
             while (bits < 32 && (1ull << bits) <= (uint64_t)max_label) ++bits;
-            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
+            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group + off, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
         }
-        hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active, vals, m, tmp, d_max_run);
-        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active, group, tmp, (const uint64_t *)keys, m, still, d_max_run);
+        hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active + off, vals, m, tmp, d_big);
+        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active + off, group + off, tmp, (const uint64_t *)keys, m, still, d_big);
         launch_scan_two_flags(still, still_scan, head_scan, m, b.scan_tmp, s);
         uint32_t *run_start = reinterpret_cast<uint32_t *>(keys == b.key_a ? b.key_b : b.key_a);      // (the pairs' other buffer: free behind the radix passes)
-        hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active, still, head_scan, still_scan, m, active_alt,
+        hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active + off, still, head_scan, still_scan, m, active_alt,
                            group_next, run_start);
-        uint32_t m_next = 0;
+        uint32_t m_next = 0, nbig = 0;
         HIPCHK(hipMemcpyAsync(&m_next, still_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(&max_label, head_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        uint32_t max_run = 0;
-        HIPCHK(hipMemcpyAsync(&max_run, d_max_run, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&nbig, d_big, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         uint32_t *t = active; active = active_alt; active_alt = t;
         t = group; group = group_next; group_next = t;
         m = m_next;
-        if (m > 1 && max_run <= SMALL_RUN && max_label > 0 && !test_hook("ZDW_SORT_NO_FINISH")) {
-            // every run that is still tied is small: a wave each instead of further rounds
-            hipLaunchKernelGGL(k_sort_finish_small, dim3((max_label + 3) / 4), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order,
-                               active, run_start, max_label, m, tmp, d_max_run + 1);
-            hipLaunchKernelGGL(k_sort_place, dim3((m + 255) / 256), dim3(256), 0, s, b.order, active, tmp, m);
-            uint32_t bad = 0;
-            HIPCHK(hipMemcpyAsync(&bad, d_max_run + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        off = 0;
+        if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort]   -> %u still tied in %u runs, %u of them longer than %u\n", m, max_label, nbig, SMALL_RUN);
+        if (m > 1 && nbig <= 1 && max_label > nbig && !test_hook("ZDW_SORT_NO_FINISH")) {
+            // Every run that is still tied is small, or all but one are: a wave each finishes the small ones.  What remains is nothing,
+            // or the one long run -- contiguous in the working set, so the next round takes it alone and needs no tie-group passes.
+            // (The benchmark's table after its first round: 1.7 M date-times that all begin "2024-01-" among 0.3 M pairs and triples.)
+            // (runs of a few strings: a thread per string; runs of dozens: a wave per run)
+            if (nbig || m / max_label < 8)
+                hipLaunchKernelGGL(k_sort_finish_tiny, dim3((m + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order,
+                                   active, group, run_start, max_label, m, tmp, d_big + 1);
+            else
+                hipLaunchKernelGGL(k_sort_finish_small, dim3((max_label + 3) / 4), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order,
+                                   active, run_start, max_label, m, tmp, d_big + 1);
+            hipLaunchKernelGGL(k_sort_place, dim3((m + 255) / 256), dim3(256), 0, s, b.order, active, tmp, m, nbig ? d_big + 2 : (const uint32_t *)nullptr);
+            uint32_t res[3] = {0, 0, 0};
+            HIPCHK(hipMemcpyAsync(res, d_big + 1, sizeof res, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (bad) return (int)hipErrorUnknown;
-            break;
+            if (res[0]) return (int)hipErrorUnknown;
+            if (!nbig) break;
+            if (res[2] <= res[1] || res[2] > m) return (int)hipErrorUnknown;
+            off = res[1]; m = res[2] - res[1]; max_label = 1;
         }
         if (depth > max_len / 8 + 2) return (int)hipErrorUnknown;   // cannot happen: two distinct strings differ within max_len bytes
     }
