@@ -476,6 +476,31 @@ __global__ __launch_bounds__(256) void k_dict_lengths(const uint32_t *__restrict
     if (r < n) { const uint32_t len = uniq_len[order ? order[r] : r]; len_plus1[r] = len ? len + 1 : 0u; }    // holes take no room; no order = identity
 }
 
+// Dictionary::getSize() - 1 in one launch: partial[b] = the sum of len + 1 over the strings block b looked at (holes take no room);
+// the caller adds up the (at most DICT_TOTAL_BLOCKS) partial sums it reads back.
+__global__ __launch_bounds__(256) void k_dict_total(const uint32_t *__restrict__ uniq_len, uint32_t n, uint64_t *__restrict__ partial)
+{
+    __shared__ uint64_t wsum[4];
+    uint64_t v = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) { const uint32_t len = uniq_len[i]; v += len ? len + 1u : 0u; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), d, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+uint32_t launch_dict_total(const uint32_t *uniq_len, uint64_t n, uint64_t *partial, hipStream_t s)
+{
+    uint32_t grid = (uint32_t)((n + 4095) / 4096);
+    if (grid < 1) grid = 1;
+    if (grid > DICT_TOTAL_BLOCKS) grid = DICT_TOTAL_BLOCKS;
+    hipLaunchKernelGGL(k_dict_total, dim3(grid), dim3(256), 0, s, uniq_len, (uint32_t)n, partial);
+    return grid;
+}
+
 void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s)
 {
     if (!n) return;

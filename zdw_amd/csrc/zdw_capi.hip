@@ -629,11 +629,18 @@ int ensure_dict_size(zdw_ctx *c)
     HIP_TRY(c, c->off_excl.ensure((u + 2) * 8));
     HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(u + 1)));
     HIP_TRY(c, c->slot_off.ensure((u + 1) * 4));
-    launch_dict_lengths(nullptr, c->uniq_len.as<uint32_t>(), u, c->lenp1.as<uint32_t>(), s);      // by id: the sum does not depend on the order
-    launch_scan_u32_to_u64(c->lenp1.as<uint32_t>(), c->off_excl.as<uint64_t>(), u, c->scan_tmp.p, nullptr, s);
+    // (by id: the sum does not depend on the order.  One launch and the partial sums read back, not lengths + a three-launch scan:
+    // this sits between pass 1 and everything that follows it)
     uint64_t total = 0;
-    HIP_TRY(c, hipMemcpyAsync(&total, c->off_excl.as<uint64_t>() + u, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    {
+        static_assert(DICT_TOTAL_BLOCKS * 8 <= 16384, "the partial sums live at the start of the scan scratch");
+        HIP_TRY(c, c->scan_tmp.ensure(std::max<size_t>(scan_tmp_bytes(u + 1), DICT_TOTAL_BLOCKS * 8)));
+        const uint32_t nb = launch_dict_total(c->uniq_len.as<uint32_t>(), u, static_cast<uint64_t *>(c->scan_tmp.p), s);
+        std::vector<uint64_t> part(nb);
+        HIP_TRY(c, hipMemcpyAsync(part.data(), c->scan_tmp.p, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (uint64_t v : part) total += v;
+    }
     c->dict_size = total + 1;                       // Dictionary::getSize(): origin byte included
     {
         const uint64_t limit = c->max_dict_bytes && c->max_dict_bytes < (1ull << 32) ? c->max_dict_bytes : (1ull << 32) - 1;

@@ -139,6 +139,9 @@ uint32_t sort_blocks(uint64_t n);
 int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n,
               SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len, const uint64_t *uniq_key = nullptr);
 void launch_dict_lengths(const uint32_t *order, const uint32_t *uniq_len, uint64_t n, uint32_t *len_plus1, hipStream_t s);
+constexpr uint32_t DICT_TOTAL_BLOCKS = 1024;
+// the sum of len + 1 over the n ids as up to DICT_TOTAL_BLOCKS partial sums (returns how many): one launch where only the total is wanted
+uint32_t launch_dict_total(const uint32_t *uniq_len, uint64_t n, uint64_t *partial, hipStream_t s);
 void launch_dict_emit(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint32_t *order, const uint64_t *uniq_pos,
                       const uint32_t *uniq_len, const uint64_t *off_excl, uint64_t n,
                       uint8_t *blob /* string area: offset 1 is blob[1] */, uint32_t *id_off, hipStream_t s,
