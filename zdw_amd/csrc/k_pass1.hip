@@ -1268,6 +1268,14 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
 // ranges in global memory (the fast kernel has flushed its own by then).
 __global__ __launch_bounds__(256) void k_pass1_deferred(const Pass1Args a, uint32_t count)
 {
+    if (count == 0xFFFFFFFFu) {
+        // launched right behind the main kernel: how many fields it queued is in the status block -- and nothing is to be done when
+        // the queue or the table overflowed (the host runs the pass again)
+        const P1Status *st = a.st;
+        if (uniform32(st->deferred_lost | st->overflow)) return;
+        count = uniform32(st->deferred);
+        if (count > a.dq_cap) count = a.dq_cap;
+    }
     const uint32_t lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     ColTables t;
@@ -1324,7 +1332,7 @@ void launch_rec_zero_fill(uint8_t *rec, uint32_t rec_stride, uint32_t nrows, uin
 void launch_pass1_deferred(const Pass1Args &a, uint32_t count, hipStream_t s)
 {
     if (!count) return;
-    const uint32_t want = (count + 255) / 256;
+    const uint32_t want = count == 0xFFFFFFFFu ? 2048u : (count + 255) / 256;          // (all ones: the kernel reads the count on the device)
     hipLaunchKernelGGL(k_pass1_deferred, dim3(want < 2048u ? want : 2048u), dim3(256), 0, s, a, count);
 }
 void launch_pass1(const Pass1Args &a, hipStream_t s)

@@ -1525,6 +1525,8 @@ int Pass1Job::parse()
         init.bad_row = 0xFFFFFFFFu; init.split_pos = c->n;
         HIP_TRY(c, hipMemcpyAsync(c->status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
         c->nslots = nslots;
+        bool defer_used = false;
+        uint32_t dq_cap_used = 0;
         if (hi > lo && total_rows) {
             StageScope ts(c, ZDW_STAGE_PASS1);
             Pass1Args a{};
@@ -1591,31 +1593,32 @@ int Pass1Job::parse()
                 const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(std::max<uint64_t>((hi - lo) / dq_div + 65536, by_rate), c->dq_learned), 1ull << 31);
                 HIP_TRY(c, c->deferred_q.ensure(cap * 16));
                 a.dq = c->deferred_q.as<uint64_t>(); a.dq_cap = (uint32_t)cap;
+                defer_used = true; dq_cap_used = (uint32_t)cap;
             }
             launch_pass1(a, s);
             ++c->pass1_launches;
             c->last_span_shift = span_shift; c->last_span0 = span0; c->last_fold = fold;
-            if (defer) {
-                HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
-                HIP_TRY(c, hipStreamSynchronize(s));
-                if (st.deferred_lost) {
-                    if (experiment("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] deferred queue of %u entries lost fields (%u queued): again\n", a.dq_cap, st.deferred);
-                    const uint64_t need = (uint64_t)st.deferred + st.deferred / 8 + 65536;       // (a re-run hands out its chunks differently)
-                    if (!dq_grown && need * 16 <= (hi - lo) + (64ull << 20) && need > a.dq_cap && need < (1ull << 31) && !st.overflow) {
-                        c->dq_learned = need;
-                        dq_grown = true;              // once per block: a second loss goes to the all-in-one kernel
-                    } else {
-                        c->p1_all_in_one = true;      // this block and the context's later ones
-                    }
-                    --attempt;
-                    continue;
-                }
-                if (hi > lo) c->dq_rate = std::max(c->dq_rate, (double)st.deferred / (double)(hi - lo));
-                if (st.deferred && !st.overflow) launch_pass1_deferred(a, st.deferred, s);
-            }
+            // the queued general-form fields: how many there are, and whether the queue or the table overflowed (then the pass is run
+            // again and this launch does nothing), the kernel reads on the device -- no host round trip between the two launches
+            if (defer) launch_pass1_deferred(a, 0xFFFFFFFFu, s);
         }
         HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
+        if (defer_used) {
+            if (st.deferred_lost) {
+                if (experiment("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] deferred queue of %u entries lost fields (%u queued): again\n", dq_cap_used, st.deferred);
+                const uint64_t need = (uint64_t)st.deferred + st.deferred / 8 + 65536;       // (a re-run hands out its chunks differently)
+                if (!dq_grown && need * 16 <= (hi - lo) + (64ull << 20) && need > dq_cap_used && need < (1ull << 31) && !st.overflow) {
+                    c->dq_learned = need;
+                    dq_grown = true;              // once per block: a second loss goes to the all-in-one kernel
+                } else {
+                    c->p1_all_in_one = true;      // this block and the context's later ones
+                }
+                --attempt;
+                continue;
+            }
+            if (hi > lo) c->dq_rate = std::max(c->dq_rate, (double)st.deferred / (double)(hi - lo));
+        }
         lap.mark("pass1_kernels");
         hipError_t le = hipGetLastError();      // (allocation failures handled above have cleared theirs: DevBuf::ensure)
         if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));
