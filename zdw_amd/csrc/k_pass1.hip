@@ -788,7 +788,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 if (lane_in(freem)) {
                     if (nid >= COLD(id_cap)) { COLD(st)->overflow = 1; }
                     else {
-                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start_of(), len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK, COLD(uniq_key));
+                        const uint64_t old = claim_slot<false, true>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start_of(), len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK, COLD(uniq_key));
                         if (old == 0) { won = 1u; t_id = nid + 1; } else won = 2u;
                     }
                 }
@@ -815,6 +815,10 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (SKIP && a.nz && n_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }
+
+    // the strings this batch put into the table: their slots' word 1 now, behind the batch's stores (claim_slot<.., LATE>) -- and
+    // before the general form below, which may wait for exactly such a slot
+    if (newm) publish_slot(a.slots + 4 * slot_i, c0, lane_in(newm));
 
     // ---- everything else: the general form, from global memory ----
     const uint64_t sm = slowm;

@@ -184,7 +184,10 @@ __device__ __forceinline__ void retire_ids(const IdAlloc &al, uint32_t *uniq_len
 // claim an empty slot for unique `id`: the unique's facts (in flight while the CAS travels: their lines
 // are cold), the CAS, the inline copy, then (all of those drained) word 1; returns the previous key word
 // (0 = claimed).  A lost race leaves the id a hole.
-template <bool FACTS_AT_AGENT_SCOPE>
+// LATE: the claimer does not wait for its copy's words 2-3 and publish word 1 here; it calls publish_slot() later (pass 1's register
+// form does, behind the batch's other memory operations: the wait then costs little, and until then the slot reads as "claimed, not
+// complete", which sends anybody else who wants it to the general form).
+template <bool FACTS_AT_AGENT_SCOPE, bool LATE = false>
 __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uint32_t id, uint64_t pos, uint32_t len, uint64_t *uniq_pos,
                                                uint32_t *uniq_len, uint64_t c0, uint64_t c1, uint64_t c2, bool track_first = false,
                                                uint64_t *uniq_key = nullptr)
@@ -208,14 +211,23 @@ __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uin
     if (old == 0) {
         if (c2) __hip_atomic_store(slot + 3, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c1) __hip_atomic_store(slot + 2, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(slot + 1, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!LATE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(slot + 1, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     } else if (FACTS_AT_AGENT_SCOPE) {
         __hip_atomic_store(uniq_len + id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         uniq_len[id] = 0u;
     }
     return old;
+}
+
+// the second half of a LATE claim: every lane of the wave calls it (the wait is the wave's), the claimers with `mine`
+__device__ __forceinline__ void publish_slot(uint64_t *slot, uint64_t c0, bool mine)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // words 2-3 (and everything else the wave has in flight) have landed
+    if (mine) __hip_atomic_store(slot + 1, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Does the stored occurrence at image position `pos` (same first `len` bytes as the candidate) END
