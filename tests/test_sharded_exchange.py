@@ -53,6 +53,17 @@ def _worker(rank, world, port, q):
     except capi.ZdwError as e:
         raised = e.code
     assert raised == 7, raised          # both ranks: the one that failed and the one that did not
+    # ... and without a collective of its own: the code of a rank-local step rides on the next data collective (the halo all-gather)
+    out, code, err = sharded._local(lambda: (_ for _ in ()).throw(capi.ZdwError(9, "rank-local, late")) if rank == 1 else 5)
+    assert (out, code) == ((5, 0) if rank == 0 else (None, 9))
+    try:
+        sharded.exchange_prev_row(last, nrows, rank, world, device="cpu", line_caps=caps, status=(code, err))
+        late = None
+    except capi.ZdwError as e:
+        late = (e.code, "late" in str(e))
+    assert late == ((9, True) if rank == 1 else (9, False)), late          # the failing rank raises its own error, the other the code it was sent
+    prev3, longest3 = sharded.exchange_prev_row(last, nrows, rank, world, device="cpu", line_caps=caps, status=(0, None))
+    assert prev3 == prev and longest3 == 65536
     q.put((rank, r, ol.tolist(), ob.tolist(), prev, recv_counts, got.tolist(), gathered))
     dist.barrier()
     dist.destroy_process_group()
