@@ -50,11 +50,22 @@ def _sequential_splits(rows):
     return out
 
 
-def _worker(rank, world, port, parts, q):
+def _worker(rank, world, port, parts, q, fail=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     from zdw_amd import sharded
     shard = fake_shard.FakeShard(parts[rank], NCOLS, ARENA)
+    if fail and rank == fail[1]:          # a rank-local step of one rank fails (from its `fail[2]`-th call on): every rank must raise
+        from zdw_amd import capi
+        real, calls = getattr(shard, fail[0]), [0]
+
+        def boom(*a, **k):
+            calls[0] += 1
+            if calls[0] >= fail[2]:
+                raise capi.ZdwError(20, "injected failure of " + fail[0])
+            return real(*a, **k)
+        setattr(shard, fail[0], boom)
     try:
         blocks = sharded.encode_blocks_dist(shard, rank, world, len(parts[rank]), LIMIT, device="cpu")
         q.put((rank, blocks))
@@ -64,11 +75,11 @@ def _worker(rank, world, port, parts, q):
     dist.destroy_process_group()
 
 
-def _run(world, parts):
+def _run(world, parts, fail=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 30500 + (os.getpid() * 7 + world) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, parts, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, parts, q, fail)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -122,3 +133,26 @@ def test_a_bad_row_fails_the_block_it_falls_in():
     got = _run(2, _cut(rows, [0.5]))
     for r in range(2):
         assert got[r][0] == "error" and got[r][1] == 15 and got[r][2] == bad - first + 1, got[r]
+
+
+@pytest.mark.parametrize("step,rank,nth", [("rows", 1, 1), ("rows", 0, 1), ("stats", 1, 2), ("dict_piece", 0, 1), ("model_counts", 1, 1),
+                                           ("export_ranges", 0, 2), ("import_ranges", 1, 1), ("set_prev_row", 1, 1), ("next_block", 0, 1),
+                                           ("next_block", 1, 1)])
+def test_a_rank_local_failure_in_a_block_stops_every_rank(step, rank, nth):
+    """Every rank-local step of the block driver runs through _local() and its code rides on the next collective that exists anyway
+    (the next block's first all-gather for pass 2 and what surrounds it): whichever step fails on one rank, in whichever block,
+    no rank is left waiting in a collective (the process group's timeout is 60 s; the workers must be back long before) and every
+    rank that still had a collective in front of it raises.  A failure behind the LAST collective of the last block concerns the
+    failing rank alone."""
+    tsv, rows = _table(7, 700)
+    assert len(_sequential_splits(rows)) >= 3
+    import time
+    t0 = time.time()
+    got = _run(2, _cut(rows, [0.5]), fail=(step, rank, nth))
+    assert time.time() - t0 < 50, "a rank waited in a collective"
+    assert got[rank][0] == "error" and got[rank][1] == 20 and "injected" in got[rank][3], got[rank]
+    other = got[1 - rank]
+    # (the other rank: the same code, unless the failure lay behind the input's last collective)
+    assert (isinstance(other, tuple) and other[0] == "error" and other[1] == 20) or isinstance(other, list), other
+    if rank == 0 and nth == 1:            # rank 0's first call of any step lies in the first of at least three blocks
+        assert isinstance(other, tuple) and other[0] == "error" and other[1] == 20, other

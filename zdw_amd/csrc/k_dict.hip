@@ -695,7 +695,11 @@ __global__ __launch_bounds__(256) void k_owner_offsets(const uint32_t *__restric
                                                         uint32_t n, uint32_t *__restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = ids[i] ? base + id_off[ids[i] - 1] : 0u;
+    // (a string the owner dropped -- a hole of the layout, id_off 0: local offsets start at 1 -- has no offset: 0, never base + garbage)
+    if (i < n) {
+        const uint32_t o = ids[i] ? id_off[ids[i] - 1] : 0u;
+        out[i] = o ? base + o : 0u;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_scatter_offsets(const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets, uint32_t n,

@@ -2239,7 +2239,10 @@ int zdw_owner_finish(zdw_ctx *c, uint64_t last_pos, uint64_t *slice_bytes)
         HIP_TRY(c, hipStreamSynchronize(s));
         if (total >= (1ull << 32)) return fail(c, ZDW_OUT_OF_MEMORY, "dictionary range exceeds 2^32 bytes: split the block");
         HIP_TRY(c, c->own_blob.ensure(16 + total + 16));
-        HIP_TRY(c, c->own_idoff.ensure((u + 1) * 4));
+        HIP_TRY(c, c->own_idoff.ensure((c->own_nids + 1) * 4));
+        // (strings zdw_owner_finish dropped -- first met beyond the block's end -- are holes the layout skips: their entries read 0, not
+        // whatever the buffer held, so zdw_owner_offsets answers "no offset" for them: a deterministic value a test can look for)
+        HIP_TRY(c, hipMemsetAsync(c->own_idoff.p, 0, (c->own_nids + 1) * 4, s));
         // blob[0] is the byte before the range (the origin byte when this is the first range); local offsets start at 1
         launch_dict_emit(nullptr, 0, c->own_extra.as<uint8_t>(), c->order.as<uint32_t>(), c->own_upos.as<uint64_t>(), c->own_ulen.as<uint32_t>(),
                          c->off_excl.as<uint64_t>(), u, c->own_blob.as<uint8_t>() + 8, c->own_idoff.as<uint32_t>(), s, c->own_key.as<uint64_t>());

@@ -70,13 +70,12 @@ struct Pass1Args {
     uint32_t skip_empty;                  // tabs that directly follow a boundary (empty fields) get no descriptor (tables of mostly empty fields)
     uint32_t rebase_at;                   // relative position at which a visit moves its base (2^23: a descriptor holds 24 bits of position; tests lower it)
     uint64_t *dq; uint32_t dq_cap;        // deferred fields (two words each: position | column << 40, length | row << 32); dq == nullptr: none, one kernel does everything
-#ifdef ZDW_EXPERIMENTS
-    uint32_t debug_skip;                  // profiling builds only (ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary, 4 no record stores, 32 the tokeniser alone
-#endif
     uint32_t rec_zeroed;                  // 1: rec was zeroed before the launch: empty fields leave nothing to do
     uint32_t *nz; uint32_t nz_stride;     // not null (with rec_zeroed, instead of a zeroed rec): a bit per field, bit (column & 31) of word nz[row * nz_stride + column / 32], set where a non-zero record was
                                           // written; what rec holds elsewhere means nothing (tables of mostly empty fields: pass 2 goes by this map)
     uint32_t dense_boundaries;            // 1: the input averages more boundaries per round than the small descriptor ring takes (tables of mostly empty fields): large ring
+    uint32_t debug_skip;                  // read by profiling builds only (-DZDW_EXPERIMENTS, ZDW_DEBUG_SKIP): 1 no field work, 2 no dictionary, 4 no record stores, 32 the
+                                          // tokeniser alone.  Always declared, and last: the struct's layout is the same whatever an object file was compiled with
 };
 
 struct Pass2Args {

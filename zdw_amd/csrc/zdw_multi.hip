@@ -85,6 +85,9 @@ struct Shard {
     void *d_recv_lens = nullptr, *d_recv_bytes = nullptr, *d_recv_offs = nullptr, *d_back = nullptr, *d_recv_pos = nullptr;
     size_t cap_recv_lens = 0, cap_recv_bytes = 0, cap_recv_offs = 0, cap_back = 0, cap_recv_pos = 0;
     bool p1_valid = false;                 // pass 1 has run over the rows this shard still holds and nothing has cut them back since
+    bool mc_valid = false;                 // ... and its share of the memory model's upper bound (zdw_shard_model_counts: a scan and two waits) is known
+    uint64_t mc_entries = 0, mc_bytes = 0;
+    uint32_t mc_max_len = 0;
     // partition results
     std::vector<uint64_t> counts, nbytes;  // per destination range
     const void *d_lens = nullptr, *d_bytes = nullptr, *d_pos = nullptr;
@@ -350,11 +353,13 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     for (;; window *= 2) {
     last = std::min(n - 1, first + window - 1);
 
-    // ---- pass 1 on every requester that has none yet for the rows it still holds ----
+    // ---- pass 1 on every shard that still holds rows and has none yet for them: ALL of them at once, not only the window's (the
+    // ---- shards beyond it keep theirs for the block they end up in; one round of parallel launches instead of one per doubling) ----
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
         s.rc = 0;
-        if (i < first || i > last || s.p1_valid) return;
+        if (i < first || s.p1_valid) return;
+        s.mc_valid = false;
         s.rc = zdw_block_pass1(s.ctx, nullptr, &s.p1);
         if (s.rc) s.err = zdw_last_error(s.ctx); else s.p1_valid = true;
     });
@@ -376,11 +381,13 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
         uint64_t entries = 0, bytes = 0;
         uint32_t max_len = 0;
         for (size_t i = first; i <= last; ++i) {
-            uint64_t e = 0, b = 0;
-            uint32_t ml = 0;
-            rc = zdw_shard_model_counts(m->sh[i].ctx, &e, &b, &ml);
-            if (rc) return mfail(m, rc, "%s", zdw_last_error(m->sh[i].ctx));
-            entries += e; bytes += b; max_len = std::max(max_len, ml);
+            Shard &s = m->sh[i];
+            if (!s.mc_valid) {              // (kept while the shard's pass 1 is: every doubling of the window asks again)
+                rc = zdw_shard_model_counts(s.ctx, &s.mc_entries, &s.mc_bytes, &s.mc_max_len);
+                if (rc) return mfail(m, rc, "%s", zdw_last_error(s.ctx));
+                s.mc_valid = true;
+            }
+            entries += s.mc_entries; bytes += s.mc_bytes; max_len = std::max(max_len, s.mc_max_len);
         }
         const double ub = zdw_model_upper_bound_mb(entries, bytes, max_len);
         maybe = ub >= m->mem_limit_mb;

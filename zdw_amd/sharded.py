@@ -661,10 +661,14 @@ class EncoderPort:
 
     def owner_import(self, lens, byts, pos):
         _torch_done()
+        if pos is not None and not pos.numel():
+            # positions are expected and none arrived: the library still wants a pointer it may read -- eight real bytes of device
+            # memory, not a sentinel (a wild address if anything ever looks at it)
+            pos = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._keep = (lens, byts, pos)
         self._received = lens.numel()
         self.enc.owner_import(lens.data_ptr() if lens.numel() else 0, byts.data_ptr() if byts.numel() else 0,
-                              pos.data_ptr() if pos is not None and pos.numel() else (1 if pos is not None else 0), lens.numel(), byts.numel())
+                              pos.data_ptr() if pos is not None else 0, lens.numel(), byts.numel())
 
     def owner_first_flags(self):
         t = _wrap(self.enc.owner_first_flags(), self._received * 4, "<i4", self.device).clone()
@@ -734,18 +738,30 @@ def encode_blocks_dist(port, rank, world, nbytes, mem_limit_mb, group=None, devi
     first, have_p1, longest = 0, False, FIRST_ROW_CAP
     my_rows = my_bad = 0
     out = []
+    # Rank-local steps (anything that can raise on one rank alone: memory in pass 2, a device error) run through _local(); their
+    # code travels with the NEXT collective that exists anyway, so a rank that failed alone never leaves the others waiting in it.
+    # carry: the code (and error) of the steps behind the last collective of the block before -- it rides on this block's first one.
+    carry_rc, carry_err = 0, None
     while True:
         # ---- pass 1 where this rank still holds rows and has none ----
-        rc = 0
-        if rank >= first and not have_p1:
-            rc, my_rows, my_bad, is_last = port.pass1()
-            if rc == 0 and not is_last:
-                rc = capi.OUT_OF_MEMORY                       # the rank's rows do not fit its device as one block
+        rc, err = carry_rc, carry_err
+        if rc == 0 and rank >= first and not have_p1:
+            res, rc, err = _local(port.pass1)
+            if rc == 0:
+                rc, my_rows, my_bad, is_last = res
+                if rc == 0 and not is_last:
+                    rc = capi.OUT_OF_MEMORY                   # the rank's rows do not fit its device as one block
             have_p1 = rc == 0
-        cnts = port.model_counts() if (rank >= first and rc == 0 and mem_limit_mb) else (0, 0, 0)
+        cnts = (0, 0, 0)
+        if rank >= first and rc == 0 and mem_limit_mb:
+            res, rc, err = _local(port.model_counts)
+            if rc == 0:
+                cnts = res
         info = allgather_i64([rc, my_rows if rank >= first else 0, my_bad if rank >= first else 0] + list(cnts), device, group=group)
         if any(a[0] for a in info):
-            raise capi.ZdwError(rc or max(a[0] for a in info), "pass 1 failed on a rank")
+            if err is not None:
+                raise err
+            raise capi.ZdwError(rc or max(a[0] for a in info), "pass 1 (or the rows of the block before) failed on a rank")
         rows_of = [a[1] for a in info]
         bad_rank = next((r for r in range(first, world) if info[r][2]), None)
         # Not every rank that still holds rows has to send its strings: the block ends where the dictionary has grown to the limit, so
@@ -828,19 +844,25 @@ def encode_blocks_dist(port, rank, world, nbytes, mem_limit_mb, group=None, devi
 
         # ---- column ranges of the block's ranks ----
         ncols = port.ncols
-        mine_r = port.export_ranges() if in_block else ([NO_MIN] * ncols, [0] * ncols, [0] * ncols)
-        mn, mx, seen = allreduce_ranges(*mine_r, device=device, group=group)
-        if in_block:
-            port.import_ranges(mn, mx, seen)
+        no_ranges = ([NO_MIN] * ncols, [0] * ncols, [0] * ncols)
+        mine_r, rc_r, err_r = _local(port.export_ranges) if in_block else (no_ranges, 0, None)
+        mn, mx, seen, worst = allreduce_ranges(*(mine_r if rc_r == 0 else no_ranges), device=device, group=group, status=rc_r)
+        if worst:
+            if err_r is not None:
+                raise err_r
+            raise capi.ZdwError(worst, "the column ranges failed on a rank")
 
         # ---- the owners sort and lay out what belongs to the block; every string's offset travels back ----
-        rc_own, slice_bytes = 0, 0
-        try:
-            slice_bytes = port.owner_finish(trip[3] if trip is not None else None)
-        except capi.ZdwError as e:
-            rc_own = e.code or 20
+        # (the gather of the range sizes also carries the code of installing the ranges)
+        _, rc_own, err_own = _local(lambda: port.import_ranges(mn, mx, seen)) if in_block else (None, 0, None)
+        slice_bytes = 0
+        if rc_own == 0:
+            slice_bytes, rc_own, err_own = _local(lambda: port.owner_finish(trip[3] if trip is not None else None))
+            slice_bytes = slice_bytes or 0
         gathered = allgather_i64([slice_bytes, rc_own], device, group=group)
         if any(a[1] for a in gathered):
+            if err_own is not None:
+                raise err_own
             raise capi.ZdwError(rc_own or max(a[1] for a in gathered), "building a dictionary range failed on a rank")
         range_base, total = range_bases([a[0] for a in gathered])
         if total >= 1 << 32:
@@ -853,16 +875,28 @@ def encode_blocks_dist(port, rank, world, nbytes, mem_limit_mb, group=None, devi
         last, caps = _guarded(lambda: (port.last_row(), port.line_caps()) if in_block else ([0] * ncols, IDENTITY_CAPS), device, group, "the row halo")
         prev, longest = exchange_prev_row(last, my_rows if in_block else 0, rank, world, device, group=group, line_caps=caps, start_cap=longest,
                                           first=first)
-        if in_block:
-            port.set_prev_row(prev)
-        piece = port.dict_piece()
-        cs, cb = port.stats() if in_block else (b"", [])
-        rows = port.rows() if in_block else b""
+        # ---- this rank's share of the block: nothing below takes part in a collective, and the next one is the next block's first
+        # ---- (a rank that fails here must reach it and say so: pass 2 is where a device runs out of memory)
+        def finish():
+            if in_block:
+                port.set_prev_row(prev)
+            piece = port.dict_piece()
+            cs, cb = port.stats() if in_block else (b"", [])
+            rows = port.rows() if in_block else b""
+            if trip is not None and rank == end:
+                port.next_block()
+            return piece, cs, cb, rows
+        res, carry_rc, carry_err = _local(finish)
+        if trip is None:
+            if carry_err is not None:
+                raise carry_err                                # the last block: no collective follows, nobody waits for this rank
+            piece, cs, cb, rows = res
+        else:
+            piece, cs, cb, rows = res if carry_rc == 0 else (b"", b"", [], b"")
         out.append(dict(num_rows=block_rows, longest_line=longest, is_last=trip is None, dict_piece=piece, col_size=cs, col_base=cb, rows=rows,
                         my_rows=my_rows if in_block else 0, partial_fields=trip[1] if trip is not None else 0))
         if trip is None:
             return out
         if rank == end:
-            port.next_block()
             have_p1 = False
         first = end
