@@ -199,6 +199,7 @@ struct zdw_ctx {
     uint32_t nrows_written = 0;   // rows of the matrix pass 1 may have written (the block may have been cut back since)
     bool no_fold = false;         // pass 1 counts its own rows unless that went wrong for this input
     DevBuf span_state;
+    DevBuf rowidx, rx_bsmap;               // pass 1 with a lane per row: the row index (start and terminator of every row), backslashes per 16 KiB span
     bool dense_boundaries = false; // ... and whether fields are so short that pass 1 takes its large descriptor ring
     uint32_t nids = 0;            // unique ids handed out in this block (holes included): entries of id_off
     uint32_t id_cap = 0;                   // capacity of uniq_pos / uniq_len (unique ids, holes included)
@@ -1006,7 +1007,7 @@ int run_pass2(zdw_ctx *c)
 
 std::vector<DevBuf *> all_device_buffers(zdw_ctx *c)
 {
-    return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->span_state, &c->nz, &c->d_used_col, &c->scan_tmp, &c->scan_tmp2, &c->rec,
+    return {&c->d_kind, &c->d_recoff, &c->d_numidx, &c->in_owned, &c->span_starts, &c->span_rowbase, &c->span_state, &c->rowidx, &c->rx_bsmap, &c->nz, &c->d_used_col, &c->scan_tmp, &c->scan_tmp2, &c->rec,
                       &c->slots, &c->deferred_q, &c->my_order, &c->part_idx, &c->part_keys, &c->part_bounds, &c->part_split, &c->part_lens, &c->own_slots,
                       &c->own_upos, &c->own_ulen, &c->own_key, &c->own_status, &c->own_extra, &c->own_lens, &c->own_offs, &c->own_ids, &c->own_idoff, &c->own_blob,
                       &c->own_out, &c->own_pos, &c->own_minpos, &c->own_flags, &c->model_len, &c->exp_pos, &c->col_min, &c->col_max, &c->col_seen, &c->status, &c->long_rows, &c->d_scalar,
@@ -1595,9 +1596,37 @@ int Pass1Job::parse()
                 a.dq = c->deferred_q.as<uint64_t>(); a.dq_cap = (uint32_t)cap;
                 defer_used = true; dq_cap_used = (uint32_t)cap;
             }
-            launch_pass1(a, s);
+            // Two forms of the kernel (the same records, ranges, table and status): lanes take consecutive FIELDS (k_pass1.hip) or a lane
+            // walks its own ROWS (k_rows.hip: a streaming row index first, then wave-uniform columns).  The second wants the
+            // general-form queue, rows that are long against its start-up costs, and none of the other forms' special cases.
+            const bool rows_can = defer && !a.trim && !a.skip_empty && !a.dense_boundaries && pass1_rows_lds_bytes(c->ncols, c->nnum, 1) <= 160u * 1024u;
+            bool rows_form = false;
+            // (tests: 0 never, 1 where it is expected to pay, 2 wherever it can run)
+            if (const char *e = test_hook("ZDW_P1_ROWS")) rows_form = rows_can && (atoi(e) >= 2 || (atoi(e) == 1 && c->ncols >= 16 && c->avg_row >= 256));
+            if (rows_form) {
+                const uint64_t rx0 = lo >> 16, rxn = ((hi + 65535) >> 16) - rx0;              // the row index's spans: 64 KiB
+                const uint64_t rows_cap = fold ? fold_rows_cap : total_rows;
+                HIP_TRY(c, c->span_state.ensure(rxn * 8 + 64));
+                HIP_TRY(c, c->rx_bsmap.ensure(rxn * 4 + 64));                                 // (a byte per 16 KiB)
+                HIP_TRY(c, c->rowidx.ensure((rows_cap + 4) * 16));
+                HIP_TRY(c, hipMemsetAsync(c->span_state.p, 0, rxn * 8, s));
+                RowIndexArgs ri{};
+                ri.in = c->d_in; ri.n = c->n; ri.lo = lo; ri.hi = hi; ri.span0 = rx0; ri.nspans = (uint32_t)rxn;
+                ri.span_state = c->span_state.as<uint64_t>(); ri.rowidx = c->rowidx.as<uint64_t>(); ri.rows_cap = rows_cap;
+                ri.bsmap = c->rx_bsmap.as<uint8_t>(); ri.st = a.st;
+                launch_row_index(ri, s);
+                RowsArgs ra{};
+                ra.rowidx = c->rowidx.as<uint64_t>(); ra.bsmap = c->rx_bsmap.as<uint8_t>(); ra.bs_span0 = rx0 * 4;
+                ra.rows_per_lane = 4;
+                if (const char *e = test_hook("ZDW_P1_ROWS_PER_LANE")) ra.rows_per_lane = std::max(1, atoi(e));
+                a.span_state = nullptr;
+                launch_pass1_rows(a, ra, s);
+                c->last_span_shift = 16; c->last_span0 = rx0; c->last_fold = true;      // (the row index leaves the look-back's words: locate_occurrence)
+            } else {
+                launch_pass1(a, s);
+                c->last_span_shift = span_shift; c->last_span0 = span0; c->last_fold = fold;
+            }
             ++c->pass1_launches;
-            c->last_span_shift = span_shift; c->last_span0 = span0; c->last_fold = fold;
             // the queued general-form fields: how many there are, and whether the queue or the table overflowed (then the pass is run
             // again and this launch does nothing), the kernel reads on the device -- no host round trip between the two launches
             if (defer) launch_pass1_deferred(a, 0xFFFFFFFFu, s);

@@ -35,6 +35,8 @@ struct P1Status {
     uint32_t fold_abort;    // ... a wave gave up waiting for the spans before its own (cannot happen; never hang on it)
     uint64_t rows_total;    // ... rows that start in the block, + 1 (0 = the last span was not reached)
     uint8_t gap4[256 - 16];
+    uint32_t next_group;    // pass 1 with a lane per row (k_rows.hip): the next group of rows to hand out
+    uint8_t gap5[256 - 4];
 };
 
 struct LongRow { uint64_t start; uint64_t len; };   // len includes the terminating newline
@@ -103,7 +105,28 @@ struct Pass2Args {
     uint32_t nz_cols;              // ... columns of the schema; col_meta[nz_cols + column] = the column's base value
 };
 
+// pass 1 with a lane per row (k_rows.hip): the row index, then the walk
+struct RowIndexArgs {
+    const uint8_t *in; uint64_t n;        // TSV image and its allocation size
+    uint64_t lo, hi;                      // block start; effective end (last row terminator + 1)
+    uint64_t span0; uint32_t nspans;      // 16 KiB spans [span0, span0 + nspans) cover [lo, hi)
+    uint64_t *span_state;                 // a word per span, zeroed (the look-back of the row count)
+    uint64_t *rowidx;                     // out: [2 i] start of row i, [2 i + 1] position of its terminator; [2 rows] = hi
+    uint64_t rows_cap;                    // rows the index has room for (rows_cap + 2 pairs allocated)
+    uint8_t *bsmap;                       // out, per span: it holds a backslash
+    P1Status *st;                         // next_span (zeroed), rows_total, nul_seen, fold_abort
+};
+struct RowsArgs {
+    const uint64_t *rowidx;
+    const uint8_t *bsmap; uint64_t bs_span0;      // bsmap[(position >> 14) - bs_span0]
+    uint32_t rows_per_lane;                        // consecutive rows a lane walks before the wave takes the next group
+};
+constexpr uint32_t RW_WPB_MAX = 6;                 // waves per workgroup (24 KiB of LDS each)
+
 // ---- launchers (all asynchronous on `s`) ----
+void launch_row_index(const RowIndexArgs &a, hipStream_t s);
+void launch_pass1_rows(const Pass1Args &a, const RowsArgs &ra, hipStream_t s);
+size_t pass1_rows_lds_bytes(uint32_t ncols, uint32_t nnum, uint32_t wpb);
 void launch_find_effective_end(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t *d_out, hipStream_t s);
 void launch_count_row_starts(const uint8_t *in, uint64_t n, uint64_t lo, uint64_t hi, uint64_t span0, uint32_t nspans, uint32_t span_shift,
                              uint32_t *span_starts, P1Status *st, hipStream_t s);
