@@ -12,6 +12,6 @@ import csv, glob, collections
 for f in sorted(glob.glob('gpurun_out/pmc_ic/*/**/*counter_collection.csv', recursive=True)):
     agg=collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
-        if 'k_pass1<' in r['Kernel_Name']: agg[r['Counter_Name']]+=float(r['Counter_Value'])
+        if ('k_pass1<' in r['Kernel_Name'] or 'k_pass1_rows' in r['Kernel_Name']): agg[r['Counter_Name']]+=float(r['Counter_Value'])
     print({k:'%.4g'%v for k,v in agg.items()})
 PY

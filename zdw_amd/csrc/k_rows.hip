@@ -31,6 +31,7 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include <type_traits>
 
 namespace zdw {
 
@@ -263,7 +264,8 @@ void launch_row_index(const RowIndexArgs &a, hipStream_t s)
 //            consecutive dwords are read from any start without wrapping (ds_read2st64_b32: two rows per instruction)
 //   bitmap   4 x 64 u64: bit i of word u = byte i of the ring's u-th 64 bytes is a tab or a newline.  The bytes are classified ONCE,
 //            when they arrive (aligned dwords straight from the load's registers, no alignment shuffle), not once per field
-//   stage_n / stage_t   records of the row being walked, numeric / text region: 32 bytes each per lane (48 with padding)
+//   stage_n / stage_t   records of the row being walked: 32 bytes of numeric ones per lane; text ones in a ring of three 16-byte pieces --
+//            a piece is written out once the slots of all its fields have been looked at, RW_DEPTH steps behind the walk
 constexpr uint32_t RW_RING_ROWS = 64;                 // dwords of a lane's ring (256 bytes of its row)
 constexpr uint32_t RW_MIRROR = 8;
 constexpr uint32_t RW_RING_BYTES = (RW_RING_ROWS + RW_MIRROR) * 256u;
@@ -275,9 +277,9 @@ constexpr int32_t RW_NEED = 40;                       // bytes a step may look a
 constexpr int32_t RW_LAND = 68;                       // a lane with fewer bytes ahead needs the refill that is in flight NOW (a step takes at most 25 + 1 on the fast path)
 constexpr int32_t RW_ISSUE = 128;                     // a lane with no more bytes ahead than this starts a refill round ...
 constexpr int32_t RW_ROOM = (int32_t)(RW_RING_ROWS * 4u - RW_UNIT - RW_BEHIND);      // ... which every lane with at most this many ahead joins
-constexpr uint32_t RW_STAGE = 48;                     // staged record bytes per lane and region: 32 + 16 of padding (16-byte reads)
-constexpr uint32_t RW_STAGE_DATA = 32;
-constexpr uint32_t RW_WAVE_LDS = RW_RING_BYTES + RW_BITMAP_BYTES + 2u * 64u * RW_STAGE;
+constexpr uint32_t RW_STAGE_N = 40;                             // staged numeric records per lane: 32 bytes (+ 8: lanes on different banks)
+constexpr uint32_t RW_STAGE_T = 56;                             // staged text records per lane: a ring of three 16-byte pieces (+ 8)
+constexpr uint32_t RW_WAVE_LDS = RW_RING_BYTES + RW_BITMAP_BYTES + 64u * (RW_STAGE_N + RW_STAGE_T);
 constexpr uint32_t RW_LUT_ROWS = 25;
 constexpr uint32_t RW_DQ_CHUNK = 256;
 
@@ -336,7 +338,79 @@ __device__ __forceinline__ T rw_kernarg_at(uint32_t off)
 }
 #define RW_COLD(field) rw_kernarg_at<decltype(Pass1Args::field)>((uint32_t)offsetof(Pass1Args, field))
 
-template <bool TRACK>
+// ---- loads in flight across steps -------------------------------------------------------------------------------------------
+// A text field's table slot is requested in one step and looked at RW_DEPTH steps later; a lane's next 64 bytes are requested when it
+// has 128 left and stored into its ring when it has 68.  Between request and use such data must not be a C++ value: the compiler,
+// which places its own s_waitcnt in front of the first use of a load's result, would wait at once wherever it copies the value (the
+// loop over the columns is unrolled RW_DEPTH times: copies at every join), and with the load hidden in an asm statement it copies
+// registers whose data has not arrived (both seen: the first versions of this kernel).  So the loads go into ACCUMULATION registers
+// named in the asm text (a[0:47]; the register allocator never touches them -- the kernel has no MFMA and does not spill), and
+// a second asm statement waits and moves them into ordinary registers (v_accvgpr_read).  Loads return in the order they were issued,
+// so "the loads I want are done" is s_waitcnt vmcnt(number of loads issued behind them), counted in a wave-uniform sequence number
+// (stores and the rare other loads in between only make the wait stricter).
+__device__ __forceinline__ void rw_wait_loads(uint32_t behind)
+{
+#define RW_W(n) asm volatile("s_waitcnt vmcnt(" #n ")" : : : "memory")
+    switch (behind >> 1) {
+    case 0: RW_W(0); break; case 1: RW_W(2); break; case 2: RW_W(4); break; case 3: RW_W(6); break;
+    case 4: RW_W(8); break; case 5: RW_W(10); break; case 6: RW_W(12); break; case 7: RW_W(14); break;
+    case 8: RW_W(16); break; case 9: RW_W(18); break;
+    default: RW_W(20); break;
+    }
+#undef RW_W
+}
+template <int J> __device__ __forceinline__ void rw_slot_request(const uint64_t *sp);
+template <int J> __device__ __forceinline__ void rw_slot_take(rw_u32x4 &lo, rw_u32x4 &hi);
+#define RW_SLOT_FNS(J, A0, A1, A2, A3, A4, A5, A6, A7) \
+    template <> __device__ __forceinline__ void rw_slot_request<J>(const uint64_t *sp) \
+    { \
+        asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off\n\tglobal_load_dwordx4 a[" #A4 ":" #A7 "], %0, off offset:16" \
+                     : : "v"(sp) : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3, "a" #A4, "a" #A5, "a" #A6, "a" #A7); \
+    } \
+    template <> __device__ __forceinline__ void rw_slot_take<J>(rw_u32x4 &lo, rw_u32x4 &hi) \
+    { \
+        asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3 "\n\t" \
+                     "v_accvgpr_read_b32 %4, a" #A4 "\n\tv_accvgpr_read_b32 %5, a" #A5 "\n\tv_accvgpr_read_b32 %6, a" #A6 "\n\tv_accvgpr_read_b32 %7, a" #A7 \
+                     : "=v"(lo.x), "=v"(lo.y), "=v"(lo.z), "=v"(lo.w), "=v"(hi.x), "=v"(hi.y), "=v"(hi.z), "=v"(hi.w) : : "memory"); \
+    }
+RW_SLOT_FNS(0, 0, 1, 2, 3, 4, 5, 6, 7)
+RW_SLOT_FNS(1, 8, 9, 10, 11, 12, 13, 14, 15)
+RW_SLOT_FNS(2, 16, 17, 18, 19, 20, 21, 22, 23)
+RW_SLOT_FNS(3, 24, 25, 26, 27, 28, 29, 30, 31)
+#undef RW_SLOT_FNS
+// a lane's next 64 bytes: a[32:47]
+__device__ __forceinline__ void rw_unit_request(uint32_t off, const uint8_t *base)
+{
+    asm volatile("global_load_dwordx4 a[32:35], %0, %1\n\t"
+                 "global_load_dwordx4 a[36:39], %0, %1 offset:16\n\t"
+                 "global_load_dwordx4 a[40:43], %0, %1 offset:32\n\t"
+                 "global_load_dwordx4 a[44:47], %0, %1 offset:48"
+                 : : "v"(off), "s"(base) : "memory", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
+}
+__device__ __forceinline__ void rw_unit_take(rw_u32x4 (&v)[4])
+{
+    asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\t"
+                 "v_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39"
+                 : "=v"(v[0].x), "=v"(v[0].y), "=v"(v[0].z), "=v"(v[0].w), "=v"(v[1].x), "=v"(v[1].y), "=v"(v[1].z), "=v"(v[1].w) : : "memory");
+    asm volatile("v_accvgpr_read_b32 %0, a40\n\tv_accvgpr_read_b32 %1, a41\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a43\n\t"
+                 "v_accvgpr_read_b32 %4, a44\n\tv_accvgpr_read_b32 %5, a45\n\tv_accvgpr_read_b32 %6, a46\n\tv_accvgpr_read_b32 %7, a47"
+                 : "=v"(v[2].x), "=v"(v[2].y), "=v"(v[2].z), "=v"(v[2].w), "=v"(v[3].x), "=v"(v[3].y), "=v"(v[3].z), "=v"(v[3].w) : : "memory");
+}
+
+#ifdef ZDW_EXPERIMENTS
+#define RW_TICK(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = (unsigned long long)__builtin_readcyclecounter(); \
+        asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); dbg_t##i += now_ - dbg_last; dbg_last = now_; } while (0)
+#else
+#define RW_TICK(i) do { } while (0)
+#endif
+constexpr uint32_t RW_DEPTH = 4;                      // steps between a slot's request and the look at it
+struct RwProbe {                                      // per lane (the slot's 32 bytes travel in a[8 J : 8 J + 7])
+    uint64_t c0, c1, c2, slot;                        // the string's first 24 bytes (masked), the slot's index
+    uint32_t len, tag, fs;                            // its length, hash tag, start (relative to the group's base)
+};
+struct RwProbeU { uint64_t wantm; uint32_t col, stage, mark; };      // wave-uniform: lanes with a request, its column, where its record is staged, sequence number
+
+template <bool TRACK, bool FIND>
 __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Args a, const RowsArgs ra)
 {
     const uint32_t wv = uniform32(threadIdx.x >> 6);
@@ -362,7 +436,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
     __syncthreads();
 
     const uint32_t ring = L.waves + wv * RW_WAVE_LDS;                 // this wave's ring
-    const uint32_t bitmap = ring + RW_RING_BYTES, stage_n = bitmap + RW_BITMAP_BYTES, stage_t = stage_n + 64u * RW_STAGE;
+    const uint32_t bitmap = ring + RW_RING_BYTES, stage_n = bitmap + RW_BITMAP_BYTES, stage_t = stage_n + 64u * RW_STAGE_N;
     const uint32_t ring_l = ring + 4u * lane, bitmap_l = bitmap + 8u * lane;
     uint64_t nstore, nwalk;
     {
@@ -378,6 +452,18 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
     ids.cur = ids.end = 0;
     uint32_t dq_cur = 0, dq_end = 0;                                  // this wave's chunk of deferred-queue entries
     uint32_t new_entries = 0;
+    uint32_t vm_seq = 0;                                              // loads of the kind above issued so far
+#ifdef ZDW_EXPERIMENTS
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_t4 = 0, dbg_t5 = 0, dbg_t6 = 0, dbg_t7 = 0, dbg_t8 = 0, dbg_t9 = 0, dbg_t10 = 0, dbg_t11 = 0,
+                       dbg_last = (unsigned long long)__builtin_readcyclecounter();
+#endif
+    RwProbe pq[RW_DEPTH];
+    RwProbeU pu[RW_DEPTH];
+#pragma unroll
+    for (uint32_t j = 0; j < RW_DEPTH; ++j) {
+        pq[j].c0 = pq[j].c1 = pq[j].c2 = pq[j].slot = 0; pq[j].len = pq[j].tag = pq[j].fs = 0;
+        pu[j].wantm = 0; pu[j].col = pu[j].stage = pu[j].mark = 0;
+    }
 
     for (;;) {
         {
@@ -399,14 +485,17 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
         // positions are kept relative to the group's base (a multiple of 64 below its first row): 32-bit offsets from one scalar pointer
         const uint64_t gbase = uniform64(ra.rowidx[2 * g0]) & ~63ull;
         const uint8_t *const imgb = RW_COLD(in) + gbase;
-        const uint64_t n_img = RW_COLD(n);
         // (a piece past the end of the image: its last piece again -- bytes nobody looks at)
-        const uint32_t last16 = (uint32_t)(((n_img - 1) & ~15ull) - gbase < 0xfffffff0ull ? ((n_img - 1) & ~15ull) - gbase : 0xfffffff0ull);
+        uint32_t last16;
+        {
+            const uint64_t l = ((RW_COLD(n) - 1) & ~15ull) - gbase;
+            last16 = l < 0xfffffff0ull ? (uint32_t)l : 0xfffffff0u;
+        }
         uint32_t cursor = 0, fill = 0;                                // relative positions: next byte to look at; end of what the ring holds
         int32_t avail = 0;                                            // fill - cursor
         uint64_t okm = 0;                                             // lanes whose ring holds what their cursor needs
-        rw_u32x4 pend[4];                                             // a refill in flight: the unit at `fill` of the lanes in pendm
         uint64_t pendm = 0;
+        uint32_t pend_mark = 0;
 
         // a unit of 64 bytes (four 16-byte pieces in v) into the ring rows of relative position f (a multiple of 64), and its boundaries
         auto store_unit = [&](uint32_t f, const rw_u32x4 (&v)[4]) {
@@ -424,6 +513,8 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
             uint32_t *bm = reinterpret_cast<uint32_t *>(zdw_lds + bitmap_l + ((f >> 6) & (RW_UNITS - 1u)) * 512u);
             bm[0] = b16[0] | (b16[1] << 16); bm[1] = b16[2] | (b16[3] << 16);
         };
+        // ... loaded the ordinary way (the compiler waits where it is used): what starts a group, follows a field of the general form, or
+        // reaches the image's end
         auto load_unit = [&](uint32_t f, rw_u32x4 (&v)[4]) {
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
@@ -431,16 +522,17 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                 v[k] = *reinterpret_cast<const rw_u32x4 *>(imgb + (o <= last16 ? o : last16));
             }
         };
-        // the refill in flight lands in the ring.  (Its loads, like the slot requests below, are ordinary C++ loads: the compiler knows
-        // what is in flight and places the s_waitcnt -- with the count that leaves younger loads travelling -- in front of the first
-        // use, and in front of any copy it makes of the registers, e.g. at a loop's back edge.  An asm load would hide that from it.)
-        auto land = [&]() {
+        // the refill in flight lands in the ring
+        auto land = [&](bool arrived) __attribute__((always_inline)) {
+            if (!arrived) rw_wait_loads(vm_seq - pend_mark);
+            rw_u32x4 pend[4];
+            rw_unit_take(pend);
             if (lane_in(pendm)) { store_unit(fill, pend); fill += RW_UNIT; avail += (int32_t)RW_UNIT; }
             pendm = 0;
         };
         // lanes (mask m) whose ring does not hold what their cursor needs: three units from 16 bytes behind the cursor on, waited for
-        auto resync = [&](uint64_t m) {
-            if (pendm) land();
+        auto resync = [&](uint64_t m) __attribute__((always_inline)) {
+            if (pendm) land(false);
             if (lane_in(m)) {
                 const uint32_t f0 = cursor >= RW_BEHIND ? (cursor - RW_BEHIND) & ~63u : 0u;       // (bytes before the group's base are never looked at)
 #pragma unroll
@@ -480,37 +572,55 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                 const uint64_t needm = actm & ~carefulm & (~okm | BAL(avail < RW_NEED) | BAL(avail > (int32_t)(RW_RING_ROWS * 4u - RW_BEHIND)));
                 if (needm) resync(needm);
             }
-            uint32_t off_n = 0, off_t = 0, nb_n = 0, nb_t = 0;         // staged regions of the row: first record offset, bytes staged (wave-uniform)
+            // staged records of the row: the region's first record offset and the bytes staged (wave-uniform).  Both regions of a row's
+            // records are laid out in column order (zdw_capi.hip: numeric columns, then text columns), so what is staged is contiguous.
+            uint32_t off_n = 0, nb_n = 0;
+            uint32_t t_base = 0, t_cnt = 0, t_flushed = 0, t_cnt_prev = 0;      // text records: offset of the row's first; staged so far; written out; staged when the group before began
 
             // records staged for the 64 rows of this step go out as whole pieces, neighbouring lanes on neighbouring pieces of a row
-            auto flush = [&](uint32_t stage, uint32_t off, uint32_t nb) {
+            // rows of the group at this row iteration that leave records: row (g0 + r K + ri) for r < rmax
+            uint32_t rmax;
+            {
+                const uint64_t first = g0 + ri;
+                rmax = first >= nstore ? 0u : (uint32_t)((nstore - first + K - 1) / K < 64u ? (nstore - first + K - 1) / K : 64u);
+            }
+            uint8_t *const rec_ri = a.rec + (g0 + ri) * a.rec_stride;          // record row of lane 0's row; lane r's: + r K stride
+            const uint32_t kstride = K * a.rec_stride;
+            // nb staged bytes (a multiple of 4) at byte `src` of every lane's staging row (stride `stride`) go to byte `off` of the rows'
+            // records: 16-byte pieces first, neighbouring lanes on neighbouring pieces of a row, then single dwords
+            auto flush = [&](uint32_t stage, uint32_t stride, uint32_t src, uint32_t off, uint32_t nb) __attribute__((always_inline)) {
                 if (!nb) return;
                 __builtin_amdgcn_wave_barrier();
-                uint8_t *const rec = a.rec;
-                const uint32_t stride = a.rec_stride;
                 const uint32_t n16 = nb >> 4, rem = (nb & 15u) >> 2;
                 for (uint32_t e0 = 0; e0 < 64u * n16; e0 += 64u) {
                     const uint32_t e = e0 + lane;
-                    const uint32_t r = n16 == 1 ? e : e >> 1, k = e - r * n16;          // (at most two whole pieces: RW_STAGE_DATA)
-                    const uint64_t rr = g0 + (uint64_t)r * K + ri;
-                    const rw_u32x4 v = *reinterpret_cast<const rw_u32x4 *>(zdw_lds + stage + r * RW_STAGE + 16u * k);
-                    if (rr < nstore) {
+                    const uint32_t r = n16 == 1 ? e : e >> 1, k = e - r * n16;          // (at most two whole pieces at a time)
+                    const uint64_t *q = reinterpret_cast<const uint64_t *>(zdw_lds + stage + r * stride + src + 16u * k);
+                    const uint64_t v0 = q[0], v1 = q[1];
+                    if (r < rmax) {
                         // (record offsets are multiples of 4 only; a global store takes any alignment)
                         typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
-                        *reinterpret_cast<u32x4a4 *>(rec + rr * stride + off + 16u * k) = v;
+                        u32x4a4 x; x.x = (uint32_t)v0; x.y = (uint32_t)(v0 >> 32); x.z = (uint32_t)v1; x.w = (uint32_t)(v1 >> 32);
+                        *reinterpret_cast<u32x4a4 *>(rec_ri + (__umul24(r, kstride) + off + 16u * k)) = x;
                     }
                 }
                 for (uint32_t e0 = 0; e0 < 64u * rem; e0 += 64u) {
                     const uint32_t e = e0 + lane;
                     const uint32_t r = rem == 1 ? e : (rem == 2 ? e >> 1 : e / 3u), k = e - r * rem;
-                    const uint64_t rr = g0 + (uint64_t)r * K + ri;
-                    const uint32_t v = *reinterpret_cast<const uint32_t *>(zdw_lds + stage + r * RW_STAGE + 16u * n16 + 4u * k);
-                    if (rr < nstore) *reinterpret_cast<uint32_t *>(rec + rr * stride + off + 16u * n16 + 4u * k) = v;
+                    const uint32_t v = *reinterpret_cast<const uint32_t *>(zdw_lds + stage + r * stride + src + 16u * n16 + 4u * k);
+                    if (r < rmax) *reinterpret_cast<uint32_t *>(rec_ri + (__umul24(r, kstride) + off + 16u * n16 + 4u * k)) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
             };
+            // whole pieces of text records whose fields have all found their slots (those staged before the group before began)
+            auto flush_text = [&](uint32_t resolved) __attribute__((always_inline)) {
+                while (t_flushed + 4u <= resolved) {
+                    flush(stage_t, RW_STAGE_T, 16u * ((t_flushed >> 2) % 3u), t_base + 4u * t_flushed, 16u);
+                    t_flushed += 4u;
+                }
+            };
             // fields for the general form: queued for k_pass1_deferred (position | column << 40, length | row << 32)
-            auto defer = [&](uint64_t sm, uint64_t abs_start, uint32_t raw_len, uint32_t col) {
+            auto defer = [&](uint64_t sm, uint64_t abs_start, uint32_t raw_len, uint32_t col) __attribute__((always_inline)) {
                 if (!sm) return;
                 P1Status *const stp = RW_COLD(st);
                 uint64_t *const dq = RW_COLD(dq);
@@ -535,39 +645,40 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                     }
                 }
             };
-
-            // ---- the text field of the step before: its slot was requested there and is looked at here, behind this step's search for
-            // ---- its own field's end (the probe's latency under the next field's first instructions) ----
-            uint64_t p_c0 = 0, p_c1 = 0, p_c2 = 0, p_slot = 0;
-            uint32_t p_len = 0, p_tag = 0, p_fs = 0;
-            rw_u32x4 p_lo, p_hi;                                        // the slot's 32 bytes, in flight from the request to the next step
-            uint64_t p_wantm = 0;                                       // lanes with a request in flight (0: none)
-            uint32_t p_col = 0, p_stage = 0;                            // its column; where its record goes in the text staging
-            bool p_refill_behind = false;                               // four refill loads were issued behind the request: the wait leaves them in flight
-            auto resolve = [&]() {
-                if (!p_wantm) return;
+            // ---- a text field whose slot was requested RW_DEPTH steps ago: the slot decides ----
+            auto resolve = [&](auto jc) __attribute__((always_inline)) {
+                constexpr int J = decltype(jc)::value;
+                RwProbe &P = pq[J];
+                RwProbeU &U = pu[J];
+                if (!U.wantm) return;
+                rw_wait_loads(vm_seq - U.mark);
+                rw_u32x4 s_lo, s_hi;
+                rw_slot_take<J>(s_lo, s_hi);
+                // (a refill requested before this slot has arrived with it -- loads return in order: it costs no wait of its own)
+                if (pendm && (int32_t)(U.mark - pend_mark) > 0) land(true);
                 SlotWords sw;
-                sw.key = ((uint64_t)p_lo.y << 32) | p_lo.x; sw.s0 = ((uint64_t)p_lo.w << 32) | p_lo.z;
-                sw.s1 = ((uint64_t)p_hi.y << 32) | p_hi.x; sw.s2 = ((uint64_t)p_hi.w << 32) | p_hi.z;
-                // (a refill that was in flight before the request has arrived with it -- loads return in order: it costs no wait of its own)
-                if (!p_refill_behind && pendm) land();
-                uint64_t pm = p_wantm, slowm = 0, newm = 0;
+                sw.key = ((uint64_t)s_lo.y << 32) | s_lo.x; sw.s0 = ((uint64_t)s_lo.w << 32) | s_lo.z;
+                sw.s1 = ((uint64_t)s_hi.y << 32) | s_hi.x; sw.s2 = ((uint64_t)s_hi.w << 32) | s_hi.z;
+                uint64_t pm = U.wantm, slowm = 0, newm = 0;
                 uint32_t t_id = 0;
                 uint64_t *const slots = a.slots;
-                for (uint32_t probe = 0; probe < 4; ++probe) {
+                for (uint32_t probe = 0; probe < (FIND ? 1u : 4u); ++probe) {
                     if (!pm) break;
-                    uint64_t *slot = slots + 4 * p_slot;
-                    if (probe == 0) {
-                        // that was an ordinary load, possibly from this CU's L1: only a complete slot can be taken at its word (request_slot)
+                    uint64_t *slot = slots + 4 * P.slot;
+                    if (FIND) {
+                        // (nobody inserts while this kernel runs: what the ordinary load showed is what the table holds)
+                    } else if (probe == 0) {
+                        // that was an ordinary load, possibly from this CU's L1: only a complete slot can be taken at its word (zdw_dict_dev.h, request_slot)
                         const uint64_t againm = pm & (BAL(sw.key == 0) | BAL(sw.s0 == 0));
                         if (againm) { if (lane_in(againm)) sw = load_slot(slot); }
                     } else if (lane_in(pm)) sw = load_slot(slot);
-                    const uint64_t samem = pm & BAL(sw.s0 == p_c0) & BAL(sw.s1 == p_c1) & BAL(sw.s2 == p_c2) & BAL((((uint32_t)(sw.key >> KEY_LEN_SHIFT)) & 0xffu) == p_len);
+                    const uint64_t samem = pm & BAL(sw.s0 == P.c0) & BAL(sw.s1 == P.c1) & BAL(sw.s2 == P.c2) & BAL((((uint32_t)(sw.key >> KEY_LEN_SHIFT)) & 0xffu) == P.len);
                     if (lane_in(samem)) {
                         t_id = (uint32_t)sw.key;
-                        if (TRACK) note_occurrence(RW_COLD(uniq_pos), t_id - 1u, gbase + p_fs);
+                        if (TRACK) note_occurrence(RW_COLD(uniq_pos), t_id - 1u, gbase + P.fs);
                     }
                     pm &= ~samem;
+                    if (FIND) break;                                    // everything else: the general form, behind this kernel
                     const uint64_t freem = pm & BAL(sw.key == 0);       // an empty slot: the string is new
                     if (freem) {
                         P1Status *const stp = RW_COLD(st);
@@ -576,7 +687,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                         if (lane_in(freem)) {
                             if (nid >= RW_COLD(id_cap)) { stp->overflow = 1; }
                             else {
-                                const uint64_t old = claim_slot<false, false>(slot, make_slot_key(p_tag, p_len, nid), nid, gbase + p_fs, p_len, RW_COLD(uniq_pos), RW_COLD(uniq_len), p_c0, p_c1, p_c2, TRACK, RW_COLD(uniq_key));
+                                const uint64_t old = claim_slot<false, false>(slot, make_slot_key(P.tag, P.len, nid), nid, gbase + P.fs, P.len, RW_COLD(uniq_pos), RW_COLD(uniq_len), P.c0, P.c1, P.c2, TRACK, RW_COLD(uniq_key));
                                 if (old == 0) { won = 1u; t_id = nid + 1; } else won = 2u;
                             }
                         }
@@ -586,165 +697,204 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                     }
                     const uint64_t halfm = pm & BAL(sw.s0 == 0);         // claimed, inline copy not complete yet: general form
                     slowm |= halfm; pm &= ~halfm;
-                    if (lane_in(pm)) p_slot = (p_slot + 1) & a.slot_mask;
+                    if (lane_in(pm)) P.slot = (P.slot + 1) & a.slot_mask;
                 }
                 slowm |= pm;
-                if (lane_in(p_wantm & ~slowm)) *reinterpret_cast<uint32_t *>(zdw_lds + stage_t + lane * RW_STAGE + p_stage) = t_id;
+                if (lane_in(U.wantm & ~slowm)) *reinterpret_cast<uint32_t *>(zdw_lds + stage_t + lane * RW_STAGE_T + U.stage) = t_id;
                 new_entries += popc64(newm);
-                defer(slowm, gbase + p_fs, p_len, p_col);
-                p_wantm = 0;
+                defer(slowm, gbase + P.fs, P.len, U.col);
+                U.wantm = 0;
+            };
+            auto drain = [&]() __attribute__((always_inline)) {
+                resolve(std::integral_constant<int, 0>{}); resolve(std::integral_constant<int, 1>{});
+                resolve(std::integral_constant<int, 2>{}); resolve(std::integral_constant<int, 3>{});
             };
 
-            for (uint32_t col = 0; col < ncols; ++col) {
-                const uint32_t meta = uniform32(*reinterpret_cast<const uint32_t *>(zdw_lds + t.meta + 4u * col));
-                const uint32_t kind = meta & 3u, recoff = meta >> 16;
-                const uint64_t livem = ~deadm & (fullm | BAL(col < my_cols));
-                const uint64_t fastm = livem & ~carefulm;
-                // ---- where my field ends: the first boundary at or behind the cursor, from the bitmap (32 bits of it) ----
-                const uint32_t fs = cursor;
-                uint32_t len;
-                {
-                    const uint32_t u = (fs >> 6) & (RW_UNITS - 1u), o = fs & 63u;
-                    const uint32_t *b0 = reinterpret_cast<const uint32_t *>(zdw_lds + bitmap_l + u * 512u);
-                    const uint32_t *b1 = reinterpret_cast<const uint32_t *>(zdw_lds + bitmap_l + ((u + 1u) & (RW_UNITS - 1u)) * 512u);
-                    const uint32_t w0 = b0[0], w1 = b0[1], w2 = b1[0];
-                    const bool upper = o >= 32u;
-                    const uint32_t lo = upper ? w1 : w0, hi = upper ? w2 : w1;
-                    const uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, o);      // (the shift is o mod 32)
-                    len = bits ? (uint32_t)__builtin_ctz(bits) : 32u;
-                }
-                const uint32_t limit = kind == K_TEXT ? 24u : 16u;
-                uint64_t slowm = (livem & carefulm) | (fastm & BAL(len > limit));
-                // ---- fields the fast path does not take: their end from the image, byte by byte; the general form takes them ----
-                if (slowm) {
-                    if (lane_in(slowm)) {
-                        const uint64_t p0 = gbase + fs, hi = RW_COLD(hi);
-                        const uint64_t e = careful ? rw_scan_careful(RW_COLD(in), p0, hi) : rw_scan_plain(RW_COLD(in), p0, hi);
-                        uint32_t kill = e >= hi ? 1u : 0u;                  // the row runs into the block's end: not a row of ncols fields
-                        const uint64_t l64 = e - p0;
-                        if (l64 >= (1ull << 30)) { RW_COLD(st)->nul_seen = 2; kill = 1u; }
-                        len = (uint32_t)l64;
-                        if (kill) len = 0x40000000u;                        // (marks the lane dead below)
+            for (uint32_t col0 = 0; col0 < ncols; col0 += RW_DEPTH) {
+                // ---- staged records: written out when the next RW_DEPTH columns' records may not fit behind what a region holds
+                // ---- (text: every field that has a record there has found its slot by then) ----
+                if (nb_n) { flush(stage_n, RW_STAGE_N, 0u, off_n, nb_n); nb_n = 0; }
+                flush_text(t_cnt_prev);
+                t_cnt_prev = t_cnt;
+                auto step = [&](auto jc, const uint32_t col) __attribute__((always_inline)) {
+                    constexpr int J = decltype(jc)::value;
+                    RwProbe &P = pq[J];
+                    RwProbeU &U = pu[J];
+                    const uint32_t meta = uniform32(*reinterpret_cast<const uint32_t *>(zdw_lds + t.meta + 4u * col));
+                    const uint32_t kind = meta & 3u, recoff = meta >> 16;
+                    const uint64_t livem = ~deadm & (fullm | BAL(col < my_cols));
+                    const uint64_t fastm = livem & ~carefulm;
+                    // ---- where my field ends: the first boundary at or behind the cursor, from the bitmap (32 bits of it) ----
+                    const uint32_t fs = cursor;
+                    uint32_t len;
+                    {
+                        const uint32_t u = (fs >> 6) & (RW_UNITS - 1u), o = fs & 63u;
+                        const uint32_t *b0 = reinterpret_cast<const uint32_t *>(zdw_lds + bitmap_l + u * 512u);
+                        const uint32_t *b1 = reinterpret_cast<const uint32_t *>(zdw_lds + bitmap_l + ((u + 1u) & (RW_UNITS - 1u)) * 512u);
+                        const uint32_t w0 = b0[0], w1 = b0[1], w2 = b1[0];
+                        const bool upper = o >= 32u;
+                        const uint32_t lo = upper ? w1 : w0, hi = upper ? w2 : w1;
+                        const uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, o);      // (the shift is o mod 32)
+                        len = bits ? (uint32_t)__builtin_ctz(bits) : 32u;
                     }
-                    deadm |= slowm & BAL(len == 0x40000000u);
-                    okm &= ~slowm;                                          // (the cursor may have left what the ring holds)
-                }
-                cursor = fs + len + 1u;
-                avail -= (int32_t)(len + 1u);
-                // ---- the step before's text field ----
-                resolve();
-                // ---- a refill that is needed now: wait for it ----
-                if (pendm) {
-                    if (fastm & okm & BAL(avail < RW_LAND)) land();
-                }
-                // ---- staged records: a region is written out before a record that does not fit behind what it holds ----
-                if (kind == K_TEXT) {
-                    if (nb_t && (recoff != off_t + nb_t || nb_t + 4u > RW_STAGE_DATA)) { flush(stage_t, off_t, nb_t); nb_t = 0; }
-                    if (!nb_t) off_t = recoff;
-                } else {
-                    if (nb_n && (recoff != off_n + nb_n || nb_n + 8u > RW_STAGE_DATA)) { flush(stage_n, off_n, nb_n); nb_n = 0; }
-                    if (!nb_n) off_n = recoff;
-                }
-                bool requested = false;
-                if (kind == K_TEXT) {
-                    // ---- text-like column, <= 24 bytes: one table slot decides; requested here, looked at in the next step ----
-                    const uint64_t wantm = fastm & ~slowm & BAL(len != 0u);
-                    // the record until then (and for good where the field is empty or goes to the general form): 0
-                    *reinterpret_cast<uint32_t *>(zdw_lds + stage_t + lane * RW_STAGE + nb_t) = 0u;
-                    if (wantm) {
-                        if (lane == 0) zdw_lds[t.seen + col] = 1;
-                        if (lane_in(wantm)) {
-                            const uint32_t wrow = (fs >> 2) & (RW_RING_ROWS - 1u), sh = fs & 3u;
-                            const uint32_t *wq = reinterpret_cast<const uint32_t *>(zdw_lds + ring_l + wrow * 256u);
-                            uint32_t d[7], w[6];
-#pragma unroll
-                            for (uint32_t k = 0; k < 7; ++k) d[k] = wq[64 * k];
-#pragma unroll
-                            for (uint32_t k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
-                            const uint32_t lo = L.lut + 32u * len;
-                            p_c0 = rw_u64(w[0], w[1]) & rw_lds_u64(lo); p_c1 = rw_u64(w[2], w[3]) & rw_lds_u64(lo + 8); p_c2 = rw_u64(w[4], w[5]) & rw_lds_u64(lo + 16);
-                            const uint64_t acc = nh24(p_c0, p_c1, p_c2);
-                            p_tag = hash_tag(acc);
-                            p_slot = hash_place(acc) & a.slot_mask;
-                            p_len = len; p_fs = fs;
-                            // an ORDINARY load (zdw_dict_dev.h, request_slot: a slot that reads complete is right however stale; anything
-                            // else is read again at agent scope)
-                            const rw_u32x4 *sp = reinterpret_cast<const rw_u32x4 *>(a.slots + 4 * p_slot);
-                            p_lo = sp[0]; p_hi = sp[1];
+                    RW_TICK(0);          // 0: loop overhead, column facts, the field's end from the bitmap
+                    const uint32_t limit = kind == K_TEXT ? 24u : 16u;
+                    // fields the fast path does not take (the general form takes them): longer than it reads in one piece -- and, where the
+                    // bitmap's 32 bits show no boundary or the row holds a backslash, their end from the image, byte by byte
+                    const uint64_t scanm = (livem & carefulm) | (fastm & BAL(len >= 32u));
+                    uint64_t slowm = scanm | (fastm & BAL(len > limit));
+                    if (scanm) {
+                        if (lane_in(scanm)) {
+                            const uint64_t p0 = gbase + fs, hi = RW_COLD(hi);
+                            const uint64_t e = careful ? rw_scan_careful(RW_COLD(in), p0, hi) : rw_scan_plain(RW_COLD(in), p0, hi);
+                            uint32_t kill = e >= hi ? 1u : 0u;              // the row runs into the block's end: not a row of ncols fields
+                            const uint64_t l64 = e - p0;
+                            if (l64 >= (1ull << 30)) { RW_COLD(st)->nul_seen = 2; kill = 1u; }
+                            len = (uint32_t)l64;
+                            if (kill) len = 0x40000000u;                    // (marks the lane dead below)
                         }
-                        p_wantm = wantm; p_col = col; p_stage = nb_t; p_refill_behind = false;
-                        requested = true;
+                        deadm |= scanm & BAL(len == 0x40000000u);
                     }
-                    nb_t += 4u;
-                } else {
-                    const uint64_t wantm = fastm & ~slowm & BAL(len != 0u);
-                    uint64_t n_rec = 0;
-                    if (wantm) {
-                        uint32_t junk = 0;
-                        if (lane_in(wantm)) {
-                            uint64_t v_rec = 0, v_range = 0;
-                            if (kind == K_INT) {
-                                // the field's last 16 characters, read back from its end (what precedes the field is masked)
-                                const uint32_t k = len > 8u ? len - 8u : 0u;
-                                const uint64_t m2 = rw_lds_u64(L.lut + 32u * (8u + k - len)), m1 = rw_lds_u64(L.lut + 32u * (8u - k));
-                                const uint64_t Z = 0x3030303030303030ull;
-                                const uint32_t bp = fs + len - 16u;
-                                const uint32_t brow = (bp >> 2) & (RW_RING_ROWS - 1u), bsh = bp & 3u;
-                                const uint32_t *bq = reinterpret_cast<const uint32_t *>(zdw_lds + ring_l + brow * 256u);
-                                uint32_t bd[5], nw[4];
-#pragma unroll
-                                for (uint32_t k2 = 0; k2 < 5; ++k2) bd[k2] = bq[64 * k2];
-#pragma unroll
-                                for (uint32_t k2 = 0; k2 < 4; ++k2) nw[k2] = __builtin_amdgcn_alignbyte(bd[k2 + 1], bd[k2], bsh);
-                                const uint64_t w2 = (rw_u64(nw[2], nw[3]) & ~m2) | (Z & m2);
-                                const uint64_t w1 = (rw_u64(nw[0], nw[1]) & ~m1) | (Z & m1);
-                                const uint32_t r0 = (uint32_t)w1, r1 = (uint32_t)(w1 >> 32), r2 = (uint32_t)w2, r3 = (uint32_t)(w2 >> 32);
-                                const uint32_t t0 = r0 - 0x30303030u, t1 = r1 - 0x30303030u, t2 = r2 - 0x30303030u, t3 = r3 - 0x30303030u;
-                                junk = nondigit_bits(r0, t0) | nondigit_bits(r1, t1) | nondigit_bits(r2, t2) | nondigit_bits(r3, t3);
-                                const uint32_t lo8 = __umul24(four_digits(t2), 10000u) + four_digits(t3);
-                                const uint32_t hi8 = __umul24(four_digits(t0), 10000u) + four_digits(t1);
-                                v_rec = v_range = (uint64_t)hi8 * 100000000ull + lo8;
-                            } else {   // char(1): pass 1 adds byte 1 only after a backslash (:358-361), pass 2 always (:543-547)
+                    cursor = fs + len + 1u;
+                    avail -= (int32_t)(len + 1u);
+                    if (scanm) okm &= ~(scanm & BAL(avail < RW_NEED));       // (the cursor may have left what the ring holds)
+                    RW_TICK(1);          // 1: general-form fields of this step
+                    // ---- the text field of RW_DEPTH steps ago ----
+                    resolve(jc);
+                    RW_TICK(2);          // 2: the look at the slot of RW_DEPTH steps ago
+                    // ---- a refill that is needed now: wait for it ----
+                    if (pendm) {
+                        if (fastm & okm & BAL(avail < RW_LAND)) land(false);
+                    }
+                    RW_TICK(3);          // 3: a refill that had to land now
+                    if (kind == K_TEXT) {
+                        // ---- text-like column, <= 24 bytes: one table slot decides; requested here, looked at RW_DEPTH steps on ----
+                        const uint64_t wantm = fastm & ~slowm & BAL(len != 0u);
+                        if (!t_cnt) t_base = recoff;
+                        const uint32_t so = 4u * (t_cnt % 12u);             // (text records of a row lie in column order: record t_cnt is at t_base + 4 t_cnt)
+                        // the record until then (and for good where the field is empty or goes to the general form): 0
+                        *reinterpret_cast<uint32_t *>(zdw_lds + stage_t + lane * RW_STAGE_T + so) = 0u;
+                        ++t_cnt;
+                        if (wantm) {
+                            if (lane == 0) zdw_lds[t.seen + col] = 1;
+                            if (lane_in(wantm)) {
                                 const uint32_t wrow = (fs >> 2) & (RW_RING_ROWS - 1u), sh = fs & 3u;
                                 const uint32_t *wq = reinterpret_cast<const uint32_t *>(zdw_lds + ring_l + wrow * 256u);
-                                const uint32_t x = __builtin_amdgcn_alignbyte(wq[64], wq[0], sh);
-                                const uint32_t b0 = x & 0xffu, b1 = len >= 2u ? ((x >> 8) & 0xffu) : 0u;
-                                const int64_t c0 = (int8_t)b0;
-                                const int64_t hi8 = (int64_t)((int)(int8_t)b1 * 256);
-                                v_range = (uint64_t)(b0 == '\\' ? c0 + hi8 : c0);
-                                v_rec = (uint64_t)(c0 + hi8);
+                                uint32_t d[7], w[6];
+#pragma unroll
+                                for (uint32_t k = 0; k < 7; ++k) d[k] = wq[64 * k];
+#pragma unroll
+                                for (uint32_t k = 0; k < 6; ++k) w[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+                                const uint32_t lo = L.lut + 32u * len;
+                                P.c0 = rw_u64(w[0], w[1]) & rw_lds_u64(lo); P.c1 = rw_u64(w[2], w[3]) & rw_lds_u64(lo + 8); P.c2 = rw_u64(w[4], w[5]) & rw_lds_u64(lo + 16);
+                                const uint64_t acc = nh24(P.c0, P.c1, P.c2);
+                                P.tag = hash_tag(acc);
+                                P.slot = hash_place(acc) & a.slot_mask;
+                                P.len = len; P.fs = fs;
+                                // an ORDINARY load (zdw_dict_dev.h, request_slot: a slot that reads complete is right however stale; anything
+                                // else is read again at agent scope)
+                                rw_slot_request<J>(a.slots + 4 * P.slot);
                             }
-                            if ((junk == 0u) & (v_range > 0)) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
-                            n_rec = v_rec;
+                            vm_seq += 2u;
+                            U.wantm = wantm; U.col = col; U.stage = so; U.mark = vm_seq;
                         }
-                        slowm |= BAL(junk != 0u);                           // signs, blanks, letters: the general form
+                    } else {
+                        const uint64_t wantm = fastm & ~slowm & BAL(len != 0u);
+                        uint64_t n_rec = 0;
+                        if (wantm) {
+                            uint32_t junk = 0;
+                            if (lane_in(wantm)) {
+                                uint64_t v_rec = 0, v_range = 0;
+                                if (kind == K_INT) {
+                                    // the field's last 16 characters, read back from its end (what precedes the field is masked)
+                                    const uint32_t k = len > 8u ? len - 8u : 0u;
+                                    const uint64_t m2 = rw_lds_u64(L.lut + 32u * (8u + k - len)), m1 = rw_lds_u64(L.lut + 32u * (8u - k));
+                                    const uint64_t Z = 0x3030303030303030ull;
+                                    const uint32_t bp = fs + len - 16u;
+                                    const uint32_t brow = (bp >> 2) & (RW_RING_ROWS - 1u), bsh = bp & 3u;
+                                    const uint32_t *bq = reinterpret_cast<const uint32_t *>(zdw_lds + ring_l + brow * 256u);
+                                    uint32_t bd[5], nw[4];
+#pragma unroll
+                                    for (uint32_t k2 = 0; k2 < 5; ++k2) bd[k2] = bq[64 * k2];
+#pragma unroll
+                                    for (uint32_t k2 = 0; k2 < 4; ++k2) nw[k2] = __builtin_amdgcn_alignbyte(bd[k2 + 1], bd[k2], bsh);
+                                    const uint64_t w2 = (rw_u64(nw[2], nw[3]) & ~m2) | (Z & m2);
+                                    const uint64_t w1 = (rw_u64(nw[0], nw[1]) & ~m1) | (Z & m1);
+                                    const uint32_t r0 = (uint32_t)w1, r1 = (uint32_t)(w1 >> 32), r2 = (uint32_t)w2, r3 = (uint32_t)(w2 >> 32);
+                                    const uint32_t t0 = r0 - 0x30303030u, t1 = r1 - 0x30303030u, t2 = r2 - 0x30303030u, t3 = r3 - 0x30303030u;
+                                    junk = nondigit_bits(r0, t0) | nondigit_bits(r1, t1) | nondigit_bits(r2, t2) | nondigit_bits(r3, t3);
+                                    const uint32_t lo8 = __umul24(four_digits(t2), 10000u) + four_digits(t3);
+                                    const uint32_t hi8 = __umul24(four_digits(t0), 10000u) + four_digits(t1);
+                                    v_rec = v_range = (uint64_t)hi8 * 100000000ull + lo8;
+                                } else {   // char(1): pass 1 adds byte 1 only after a backslash (:358-361), pass 2 always (:543-547)
+                                    const uint32_t wrow = (fs >> 2) & (RW_RING_ROWS - 1u), sh = fs & 3u;
+                                    const uint32_t *wq = reinterpret_cast<const uint32_t *>(zdw_lds + ring_l + wrow * 256u);
+                                    const uint32_t x = __builtin_amdgcn_alignbyte(wq[64], wq[0], sh);
+                                    const uint32_t b0 = x & 0xffu, b1 = len >= 2u ? ((x >> 8) & 0xffu) : 0u;
+                                    const int64_t c0 = (int8_t)b0;
+                                    const int64_t hi8 = (int64_t)((int)(int8_t)b1 * 256);
+                                    v_range = (uint64_t)(b0 == '\\' ? c0 + hi8 : c0);
+                                    v_rec = (uint64_t)(c0 + hi8);
+                                }
+                                if ((junk == 0u) & (v_range > 0)) range_update(a, t, col, (meta >> 2) & 0x3fffu, v_range);
+                                n_rec = v_rec;
+                            }
+                            slowm |= BAL(junk != 0u);                       // signs, blanks, letters: the general form
+                        }
+                        if (!nb_n) off_n = recoff;
+                        const uint32_t so = recoff - off_n;
+                        const uint64_t rv = lane_in(slowm) ? 0ull : n_rec;
+                        uint32_t *sp = reinterpret_cast<uint32_t *>(zdw_lds + stage_n + lane * RW_STAGE_N + so);
+                        sp[0] = (uint32_t)rv; sp[1] = (uint32_t)(rv >> 32);
+                        nb_n = so + 8u;
                     }
-                    const uint64_t rv = lane_in(slowm) ? 0ull : n_rec;
-                    uint32_t *sp = reinterpret_cast<uint32_t *>(zdw_lds + stage_n + lane * RW_STAGE + nb_n);
-                    sp[0] = (uint32_t)rv; sp[1] = (uint32_t)(rv >> 32);
-                    nb_n += 8u;
-                }
-                defer(slowm, gbase + fs, len, col);
-                // a lane whose cursor left its ring: the bytes it needs now (waiting for them)
-                {
-                    const uint64_t rsm = actm & ~deadm & ~carefulm & ~okm;
-                    if (rsm) { resolve(); requested = false; resync(rsm); }
-                }
-                // ---- the next refill: a lane that runs short starts a round, every lane with room joins; behind the slot request, so
-                // ---- that the wait for the slot leaves these loads in flight ----
-                if (!pendm) {
-                    const uint64_t fm = ~deadm & ~carefulm & okm & actm;
-                    if (fm & BAL(avail < RW_ISSUE)) {
-                        pendm = fm & BAL(avail <= RW_ROOM);
-                        if (lane_in(pendm)) load_unit(fill, pend);
-                        if (requested) p_refill_behind = true;
+                    RW_TICK(4);          // 4: the field's own work
+                    defer(slowm, gbase + fs, len, col);
+                    // a lane whose cursor left its ring: the bytes it needs now (waiting for them)
+                    {
+                        const uint64_t rsm = actm & ~deadm & ~carefulm & ~okm;
+                        if (rsm) resync(rsm);
+                    }
+                    RW_TICK(6);          // 6: queueing for the general form, rings refilled at once
+                    // ---- the next refill: a lane that runs short starts a round, every lane with room joins ----
+                    if (!pendm) {
+                        const uint64_t fm = ~deadm & ~carefulm & okm & actm;
+                        if (fm & BAL(avail < RW_ISSUE)) {
+                            pendm = fm & BAL(avail <= RW_ROOM);
+                            if (pendm & BAL(fill + 48u > last16)) {
+                                // (the image ends inside the unit: its last pieces clamped, the ordinary way)
+                                if (lane_in(pendm)) {
+                                    rw_u32x4 v[4];
+                                    load_unit(fill, v);
+                                    store_unit(fill, v);
+                                    fill += RW_UNIT; avail += (int32_t)RW_UNIT;
+                                }
+                                pendm = 0;
+                            } else {
+                                if (lane_in(pendm)) rw_unit_request(fill, imgb);
+                                vm_seq += 4u;
+                                pend_mark = vm_seq;
+                            }
+                        }
+                    }
+                    RW_TICK(7);          // 7: the next refill requested
+                };
+                RW_TICK(8);              // 8: staged records written out
+                step(std::integral_constant<int, 0>{}, col0);
+                if (col0 + 1 < ncols) {
+                    step(std::integral_constant<int, 1>{}, col0 + 1);
+                    if (col0 + 2 < ncols) {
+                        step(std::integral_constant<int, 2>{}, col0 + 2);
+                        if (col0 + 3 < ncols) step(std::integral_constant<int, 3>{}, col0 + 3);
                     }
                 }
             }
+            RW_TICK(9);
             // ---- the row's end ----
-            resolve();
-            flush(stage_n, off_n, nb_n);
-            flush(stage_t, off_t, nb_t);
+            drain();
+            flush(stage_n, RW_STAGE_N, 0u, off_n, nb_n);
+            flush_text(t_cnt);
+            flush(stage_t, RW_STAGE_T, 16u * ((t_flushed >> 2) % 3u), t_base + 4u * t_flushed, 4u * (t_cnt - t_flushed));
             if (act) {
                 P1Status *const stp = RW_COLD(st);
                 if (row < nstore) {
@@ -760,8 +910,16 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                 }
             }
         }
-        pendm = 0;          // (a refill still in flight belongs to rows this wave is done with)
+        if (pendm) { rw_wait_loads(0u); pendm = 0; }      // (a refill still in flight belongs to rows this wave is done with: let it land in its registers)
     }
+    RW_TICK(10);                 // 10: rows' ends, groups' starts
+#ifdef ZDW_EXPERIMENTS
+    if (lane == 0) {
+        unsigned long long *d = RW_COLD(st)->dbg;
+        atomicAdd(d + 0, dbg_t0); atomicAdd(d + 1, dbg_t1); atomicAdd(d + 2, dbg_t2); atomicAdd(d + 3, dbg_t3); atomicAdd(d + 4, dbg_t4); atomicAdd(d + 5, dbg_t5);
+        atomicAdd(d + 6, dbg_t6); atomicAdd(d + 7, dbg_t7); atomicAdd(d + 8, dbg_t8); atomicAdd(d + 9, dbg_t9); atomicAdd(d + 10, dbg_t10); atomicAdd(d + 11, dbg_t11);
+    }
+#endif
     retire_ids(ids, RW_COLD(uniq_len), RW_COLD(id_cap));
     {
         uint64_t *const dq = RW_COLD(dq);
@@ -804,7 +962,8 @@ void launch_pass1_rows(const Pass1Args &a, const RowsArgs &ra, hipStream_t s)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     typedef void (*Fn)(const Pass1Args, const RowsArgs);
-    const Fn kfn = a.track_first ? k_pass1_rows<true> : k_pass1_rows<false>;
+    const Fn kfn = ra.find_only ? (a.track_first ? k_pass1_rows<true, true> : k_pass1_rows<false, true>)
+                                : (a.track_first ? k_pass1_rows<true, false> : k_pass1_rows<false, false>);
     uint32_t wpb = RW_WPB_MAX;
     if (const char *e = test_hook("ZDW_P1_ROWS_WPB")) wpb = (uint32_t)atoi(e);
     if (wpb < 1) wpb = 1;

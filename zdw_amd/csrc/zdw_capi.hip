@@ -1619,6 +1619,10 @@ int Pass1Job::parse()
                 ra.rowidx = c->rowidx.as<uint64_t>(); ra.bsmap = c->rx_bsmap.as<uint8_t>(); ra.bs_span0 = rx0 * 4;
                 ra.rows_per_lane = 4;
                 if (const char *e = test_hook("ZDW_P1_ROWS_PER_LANE")) ra.rows_per_lane = std::max(1, atoi(e));
+                if (const char *e = experiment("ZDW_P1_ROWS_FIND")) {
+                    // measurement only: the field form fills the table first, then the row form runs over the same input looking up only
+                    if (atoi(e)) { Pass1Args b = a; launch_pass1(b, s); ra.find_only = 1; }
+                }
                 a.span_state = nullptr;
                 launch_pass1_rows(a, ra, s);
                 c->last_span_shift = 16; c->last_span0 = rx0; c->last_fold = true;      // (the row index leaves the look-back's words: locate_occurrence)
@@ -1648,6 +1652,9 @@ int Pass1Job::parse()
             }
             if (hi > lo) c->dq_rate = std::max(c->dq_rate, (double)st.deferred / (double)(hi - lo));
         }
+#ifdef ZDW_EXPERIMENTS
+        if (experiment("ZDW_P1_ROWS_DBG")) { fprintf(stderr, "[rows dbg cycles]"); for (int i = 0; i < 12; ++i) fprintf(stderr, " %llu", st.dbg[i]); fprintf(stderr, "\n"); }
+#endif
         lap.mark("pass1_kernels");
         hipError_t le = hipGetLastError();      // (allocation failures handled above have cleared theirs: DevBuf::ensure)
         if (le != hipSuccess) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1 launch: %s", hipGetErrorString(le));

@@ -37,6 +37,8 @@ struct P1Status {
     uint8_t gap4[256 - 16];
     uint32_t next_group;    // pass 1 with a lane per row (k_rows.hip): the next group of rows to hand out
     uint8_t gap5[256 - 4];
+    unsigned long long dbg[16];     // profiling builds only (-DZDW_EXPERIMENTS): cycles per part of a kernel, summed over its waves
+    uint8_t gap6[256 - 128];
 };
 
 struct LongRow { uint64_t start; uint64_t len; };   // len includes the terminating newline
@@ -120,6 +122,7 @@ struct RowsArgs {
     const uint64_t *rowidx;
     const uint8_t *bsmap; uint64_t bs_span0;      // bsmap[(position >> 14) - bs_span0]
     uint32_t rows_per_lane;                        // consecutive rows a lane walks before the wave takes the next group
+    uint32_t find_only;                            // 1: the kernel looks strings up and inserts none (what it does not find at the first slot goes to the general form)
 };
 constexpr uint32_t RW_WPB_MAX = 6;                 // waves per workgroup (24 KiB of LDS each)
 
