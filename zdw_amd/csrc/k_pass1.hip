@@ -380,11 +380,17 @@ __device__ __forceinline__ void lds_bytes(uint32_t off, uint32_t (&w)[NW])
 }
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// bits 7, 15, 23, 31 -> bits 0..3 (one 24-bit multiply)
-__device__ __forceinline__ uint32_t pack4(uint32_t m7) { return ((__umul24((m7 & 0x00808080u) >> 7, 0x4081u) >> 14) & 7u) | ((m7 >> 28) & 8u); }      // (the mask lets the compiler prove 24 bits: v_mul_u32_u24, not the quarter-rate 32-bit multiply)
+// Flags in bit 7 of the bytes of four dwords (0x80 or 0) -> 16 bits in position order.  Two byte-wise dot products per pair of
+// dwords (v_dot4_u32_u8: weights 1, 2, 4, 8 on the first dword, 16 .. 128 on the second, the first sum as the addend) give the
+// pair's eight flags times 128: seven vector instructions for sixteen flags, where shifts, masks and a 24-bit multiply per dword
+// took about thirty (this kernel is bound by the vector ALU's issue rate: DESIGN.md 4.1).
+__device__ __forceinline__ uint32_t pack8x128(uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_udot4(b, 0x80402010u, __builtin_amdgcn_udot4(a, 0x08040201u, 0u, false), false);
+}
 __device__ __forceinline__ uint32_t pack16(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
-    return pack4(a) | (pack4(b) << 4) | (pack4(c) << 8) | (pack4(d) << 12);
+    return (pack8x128(a, b) >> 7) | (pack8x128(c, d) << 1);
 }
 // bit 7 of each byte of w: the byte is a tab (0x09) or a newline (0x0a).  y = byte ^ 8 maps them to 1 and 2; of the
 // low seven bits m, m + 0x7f carries into bit 7 iff m >= 1 and m + 0x7d iff m >= 3 (no carry leaves a byte); bytes >= 0x80 are out.
