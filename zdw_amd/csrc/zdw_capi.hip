@@ -1406,8 +1406,10 @@ int Pass1Job::window_and_rows()
         StageScope ts(c, ZDW_STAGE_SCAN_ROWS);
         // span size by block size: visits cost a few microseconds of start-up latency each, so large blocks take
         // 64 KiB spans; small ones keep 16 KiB so that there are enough spans for every resident wave
+        // (measured in round 4, the benchmark's table: 1 GB best at 64 KiB spans, 4 GB at 128 KiB, 10 GB at 256 KiB -- the largest span that
+        // still leaves about 20 000 of them, three to each resident wave; until then: 80 000 spans, at most 64 KiB: 4 % slower at 10 GB)
         span_shift = SPAN_SHIFT_MIN;
-        while (span_shift < SPAN_SHIFT_MAX && ((hi - lo) >> (span_shift + 1)) >= 80000) ++span_shift;
+        while (span_shift < SPAN_SHIFT_MAX && ((hi - lo) >> (span_shift + 1)) >= 20000) ++span_shift;
         {
             // ... and by row length: a visit skips what is left of the row its span starts in and follows its last row
             // past the span's end, i.e. tokenises about one row more than it owns.  Spans of at least 8 average rows

@@ -9,7 +9,7 @@ namespace zdw {
 
 constexpr uint32_t WAVE = 64;
 constexpr uint32_t ROUND_BYTES = 256;   // bytes classified per wave step: one dword per lane
-constexpr uint32_t SPAN_SHIFT_MIN = 14, SPAN_SHIFT_MAX = 16;   // a span = 2^shift input bytes whose row starts one wave visit owns (16-64 KiB, by block size)
+constexpr uint32_t SPAN_SHIFT_MIN = 14, SPAN_SHIFT_MAX = 18;   // a span = 2^shift input bytes whose row starts one wave visit owns (16-256 KiB, by block size)
 constexpr uint32_t FIRST_ROW_CAP = 16384;
 
 // column type ids (cplusplus/zdw_column_type_constants.h:17-35)
