@@ -72,3 +72,30 @@ def test_cli_argument_errors_match_reference(capfd):
     assert "code=5 (MISSING_SQL_FILE)" in err
     assert cli.main_inprocess(["/nonexistent/file.sql"]) == 2
     assert "code=4 (MISSING_DESC_FILE)" in capfd.readouterr().err
+
+
+def test_the_row_form_of_pass_1_keeps_its_loads_in_flight_to_itself():
+    """csrc/k_rows.hip keeps loads in flight across unrolled steps in accumulation registers a[0:47] that only its own asm statements
+    name (global_load ... a[..] to fill them, v_accvgpr_read to take them); the register allocator must use none of them for anything
+    else, and the kernel must not spill (scratch) -- checked on the ISA hipcc writes for gfx950, which is what ships."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zdw_amd", "csrc", "k_rows.hip")
+    asm = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", "-", src],
+                         check=True, capture_output=True, text=True).stdout
+    kernels = re.findall(r"^(_ZN3zdw12k_pass1_rows\w+):[^\n]*\n(.*?)s_endpgm", asm, flags=re.S | re.M)
+    assert len(kernels) == 4                      # <TRACK, FIND> x 2 x 2
+    for name, body in kernels:
+        assert "scratch_" not in body, name
+        stray = []
+        for line in body.split("\n"):
+            t = line.strip()
+            if not t or t.startswith(";") or t.startswith("."):
+                continue
+            for m in re.finditer(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]", t):
+                lo = int(m.group(1) if m.group(1) else m.group(2))
+                if lo < 48 and not (t.startswith("global_load_dwordx4 a[") or t.startswith("v_accvgpr_read_b32")):
+                    stray.append(t)
+        assert not stray, (name, stray[:5])

@@ -88,6 +88,10 @@ def make_case(rnd):
         env["ZDW_P1_ALL_IN_ONE"] = "1"
     if rnd.random() < 0.15:
         env["ZDW_P1_WPB"] = rnd.choice(["4", "12", "16"])
+    if rnd.random() < 0.3:
+        env["ZDW_P1_ROWS"] = "2"                                 # pass 1's second form (a lane per row) wherever it can run
+        if rnd.random() < 0.5:
+            env["ZDW_P1_ROWS_PER_LANE"] = rnd.choice(["1", "2", "7"])
     shards = rnd.choice([2, 3, 5]) if rnd.random() < 0.3 else 0
     return dict(desc=desc, types=types, tsv=tsv, trim=trim, split=split, env=env, ncols=ncols, nrows=nrows, shards=shards)
 

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void k_row_index(const RowIndexArgs a)
             const RxChunk c = q[r % RX_AHEAD];
             if (r + RX_AHEAD < RX_ROUNDS) q[r % RX_AHEAD] = rx_load64(a.in, s0 + (r + RX_AHEAD) * RX_ROUND, lane, a.n);
             uint64_t s64 = 0, e64 = 0;
-            if (pos < se) {
+            if (pos < se && pos + RX_ROUND > ss) {      // (rounds of the span that lie before the block's start or behind its end: nothing, and prev_term stays)
                 const uint32_t H = 0x80808080u, L1 = 0x01010101u;
                 uint32_t t16[4], anybs = 0, anynul = 0;
 #pragma unroll
@@ -211,8 +211,11 @@ __global__ __launch_bounds__(64) void k_row_index(const RowIndexArgs a)
         }
         __hip_atomic_store(a.span_state + si, (2ull << 62) | (before + rows_here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (si + 1 == a.nspans) {
-            stp->rows_total = before + rows_here + 1;
-            if (before + rows_here <= a.rows_cap) a.rowidx[2 * (before + rows_here)] = a.hi;
+            const uint64_t starts = before + rows_here, ends = before - open + (tot2 >> 16);
+            stp->rows_total = starts + 1;
+            if (starts < a.rows_cap + 2) a.rowidx[2 * starts] = a.hi;
+            // (a block that is looked at through a window may end inside a row: that row has no terminator in view -- `hi` says so)
+            if (ends < starts && starts - 1 < a.rows_cap + 2) a.rowidx[2 * (starts - 1) + 1] = a.hi;
         }
         if (give_up) continue;
         // ---- the positions ----
@@ -230,14 +233,14 @@ __global__ __launch_bounds__(64) void k_row_index(const RowIndexArgs a)
             while (s64) {
                 const uint32_t i = (uint32_t)__builtin_ctzll(s64);
                 s64 &= s64 - 1;
-                if (k < a.rows_cap) a.rowidx[2 * k] = lp + i;
+                if (k < a.rows_cap + 2) a.rowidx[2 * k] = lp + i;
                 ++k;
             }
             k = ebase + (ex >> 16);
             while (e64) {
                 const uint32_t i = (uint32_t)__builtin_ctzll(e64);
                 e64 &= e64 - 1;
-                if (k < a.rows_cap) a.rowidx[2 * k + 1] = lp + i;
+                if (k < a.rows_cap + 2) a.rowidx[2 * k + 1] = lp + i;
                 ++k;
             }
             sbase += t2 & 0xffffu; ebase += t2 >> 16;
@@ -554,6 +557,9 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
             if (!actm) break;
             uint64_t S = 0, T = 0, NX = 0;
             if (act) { S = ra.rowidx[2 * row]; T = ra.rowidx[2 * row + 1]; NX = ra.rowidx[2 * row + 2]; }
+            // (what the index says is checked before anything is addressed by it: a row lies inside the block, its successor behind it)
+            const bool sane = act && S >= RW_COLD(lo) && S < RW_COLD(hi) && NX > S && NX <= RW_COLD(hi);
+            if (act && !sane) { S = RW_COLD(lo); T = S; NX = S + 1; }
             // does a backslash lie anywhere in [S, NX)?  (the row index says so per 16 KiB)
             bool careful = false;
             if (act) {
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
             const uint64_t carefulm = __ballot(careful);
             const uint32_t my_cols = act ? (row < nstore ? ncols : a.partial_fields) : 0u;         // fields of this row that count
             const uint64_t fullm = __ballot(my_cols == ncols);        // (all but a block's last, partial row)
-            uint64_t deadm = ~actm;                                     // lanes that take no part in the rest of this row
+            uint64_t deadm = ~actm | __ballot(act && !sane);            // lanes that take no part in the rest of this row
             cursor = (uint32_t)(S - gbase);
             avail = (int32_t)(fill - cursor);
             {
@@ -754,6 +760,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                             if (kill) len = 0x40000000u;                    // (marks the lane dead below)
                         }
                         deadm |= scanm & BAL(len == 0x40000000u);
+                        slowm &= ~deadm;                                    // (a lane that ran into the block's end has no field to queue)
                     }
                     cursor = fs + len + 1u;
                     avail -= (int32_t)(len + 1u);
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                     if (row + 1 == a.row_limit) stp->split_pos = T + 1;             // the next block starts after this row
                 }
                 const uint64_t rl = T + 1 - S;                                       // rows that can grow the reference's line buffer (m_LongestLine)
-                if (rl >= FIRST_ROW_CAP - 1) {
+                if (T >= S && T < RW_COLD(hi) && rl >= FIRST_ROW_CAP - 1) {
                     const uint32_t li = atomicAdd(&stp->long_count, 1u);
                     if (li < RW_COLD(long_cap)) { LongRow *lr = RW_COLD(long_rows); lr[li].start = S; lr[li].len = rl; }
                 }
