@@ -125,7 +125,14 @@ __device__ __forceinline__ uint4 load_round16(const uint8_t *in, uint64_t pos, u
     const uint64_t room = last - base;
     const uint32_t maxoff = room < WROUND - 16 ? (uint32_t)room : WROUND - 16;
     const uint32_t off = 16u * lane < maxoff ? 16u * lane : maxoff;
+#ifdef ZDW_P1_COUNT_PLAIN_LOADS
     return *reinterpret_cast<const uint4 *>(in + base + off);
+#else
+    // (read once per pass: a non-temporal load -- the count's stream does not push the table's hot slots and the records' lines out of the caches)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in + base + off));
+    return make_uint4(x.x, x.y, x.z, x.w);
+#endif
 }
 
 // bits i of a lane whose absolute position lp + i lies in [vlo, vhi)
@@ -278,16 +285,21 @@ __device__ __forceinline__ uint32_t count_row_starts(const uint8_t *__restrict__
             nul |= eq16(v, 0u) & vm;
             prev_term = lane_value(nl >> 15, 63);
         };
-        uint4 q0 = load_round16(in, pos0, lane, n), q1 = load_round16(in, pos0 + WROUND, lane, n), q2 = load_round16(in, pos0 + 2 * WROUND, lane, n),
-              q3 = load_round16(in, pos0 + 3 * WROUND, lane, n);
-        for (uint64_t pos = pos0; pos < se; pos += 4 * WROUND) {
-            const uint4 c0 = q0, c1 = q1, c2 = q2, c3 = q3;
-            q0 = load_round16(in, pos + 4 * WROUND, lane, n); q1 = load_round16(in, pos + 5 * WROUND, lane, n);
-            q2 = load_round16(in, pos + 6 * WROUND, lane, n); q3 = load_round16(in, pos + 7 * WROUND, lane, n);
-            round(pos, c0);
-            if (pos + WROUND < se) round(pos + WROUND, c1);
-            if (pos + 2 * WROUND < se) round(pos + 2 * WROUND, c2);
-            if (pos + 3 * WROUND < se) round(pos + 3 * WROUND, c3);
+#ifndef P1_COUNT_AHEAD
+#define P1_COUNT_AHEAD 4          // rounds of the count in flight (and as many more requested before these are counted)
+#endif
+        uint4 q[P1_COUNT_AHEAD];
+#pragma unroll
+        for (uint32_t k = 0; k < P1_COUNT_AHEAD; ++k) q[k] = load_round16(in, pos0 + k * WROUND, lane, n);
+        for (uint64_t pos = pos0; pos < se; pos += P1_COUNT_AHEAD * WROUND) {
+            uint4 c[P1_COUNT_AHEAD];
+#pragma unroll
+            for (uint32_t k = 0; k < P1_COUNT_AHEAD; ++k) c[k] = q[k];
+#pragma unroll
+            for (uint32_t k = 0; k < P1_COUNT_AHEAD; ++k) q[k] = load_round16(in, pos + (P1_COUNT_AHEAD + k) * WROUND, lane, n);
+#pragma unroll
+            for (uint32_t k = 0; k < P1_COUNT_AHEAD; ++k)
+                if (k == 0 || pos + k * WROUND < se) round(pos + k * WROUND, c[k]);
         }
     }
     nul_out = nul;

@@ -969,8 +969,13 @@ void launch_pass1_rows(const Pass1Args &a, const RowsArgs &ra, hipStream_t s)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     typedef void (*Fn)(const Pass1Args, const RowsArgs);
+#ifdef ZDW_EXPERIMENTS
+    // (the look-up-only variant exists for one measurement of the profiling tools: DESIGN.md 4.1b)
     const Fn kfn = ra.find_only ? (a.track_first ? k_pass1_rows<true, true> : k_pass1_rows<false, true>)
                                 : (a.track_first ? k_pass1_rows<true, false> : k_pass1_rows<false, false>);
+#else
+    const Fn kfn = a.track_first ? k_pass1_rows<true, false> : k_pass1_rows<false, false>;
+#endif
     uint32_t wpb = RW_WPB_MAX;
     if (const char *e = test_hook("ZDW_P1_ROWS_WPB")) wpb = (uint32_t)atoi(e);
     if (wpb < 1) wpb = 1;
