@@ -198,6 +198,7 @@ struct zdw_ctx {
     uint32_t nz_stride = 0;       // 32-bit words per row of the map (a bit per column; a multiple of 4 words)
     uint32_t nrows_written = 0;   // rows of the matrix pass 1 may have written (the block may have been cut back since)
     bool no_fold = false;         // pass 1 counts its own rows unless that went wrong for this input
+    bool no_rows_form = false;    // the lane-per-row form's row index gave up its look-back once (cannot happen): the field form from then on
     DevBuf span_state;
     DevBuf rowidx, rx_bsmap;               // pass 1 with a lane per row: the row index (start and terminator of every row), backslashes per 16 KiB span
     bool dense_boundaries = false; // ... and whether fields are so short that pass 1 takes its large descriptor ring
@@ -1528,7 +1529,7 @@ int Pass1Job::parse()
         init.bad_row = 0xFFFFFFFFu; init.split_pos = c->n;
         HIP_TRY(c, hipMemcpyAsync(c->status.p, &init, sizeof init, hipMemcpyHostToDevice, s));
         c->nslots = nslots;
-        bool defer_used = false;
+        bool defer_used = false, rows_used = false;
         uint32_t dq_cap_used = 0;
         if (hi > lo && total_rows) {
             StageScope ts(c, ZDW_STAGE_PASS1);
@@ -1604,7 +1605,8 @@ int Pass1Job::parse()
             const bool rows_can = defer && !a.trim && !a.skip_empty && !a.dense_boundaries && pass1_rows_lds_bytes(c->ncols, c->nnum, 1) <= 160u * 1024u;
             bool rows_form = false;
             // (tests: 0 never, 1 where it is expected to pay, 2 wherever it can run)
-            if (const char *e = test_hook("ZDW_P1_ROWS")) rows_form = rows_can && (atoi(e) >= 2 || (atoi(e) == 1 && c->ncols >= 16 && c->avg_row >= 256));
+            if (const char *e = test_hook("ZDW_P1_ROWS")) rows_form = rows_can && !c->no_rows_form && (atoi(e) >= 2 || (atoi(e) == 1 && c->ncols >= 16 && c->avg_row >= 256));
+            rows_used = rows_form;
             if (rows_form) {
                 const uint64_t rx0 = lo >> 16, rxn = ((hi + 65535) >> 16) - rx0;              // the row index's spans: 64 KiB
                 const uint64_t rows_cap = fold ? fold_rows_cap : total_rows;
@@ -1639,6 +1641,13 @@ int Pass1Job::parse()
         }
         HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
+        if (rows_used && st.fold_abort) {
+            // (the row index never came together: its rows mean nothing -- the field form, which counts for itself)
+            c->no_rows_form = true;
+            if (++reruns > 40) return fail(c, ZDW_UNKNOWN_ERROR, "pass 1: the row index keeps failing");
+            --attempt;
+            continue;
+        }
         if (defer_used) {
             if (st.deferred_lost) {
                 if (experiment("ZDW_DEBUG_RETRY")) fprintf(stderr, "[pass1] deferred queue of %u entries lost fields (%u queued): again\n", dq_cap_used, st.deferred);
