@@ -265,6 +265,13 @@ int zdw_shard_positions(zdw_ctx *ctx, uint64_t base, const void **d_pos);
 int zdw_owner_import(zdw_ctx *ctx, const void *d_lens, const void *d_bytes, const void *d_pos /* NULL: no positions */, uint64_t count, uint64_t nbytes);
 int zdw_owner_first_flags(zdw_ctx *ctx, const void **d_flags);
 int zdw_owner_finish(zdw_ctx *ctx, uint64_t last_pos, uint64_t *slice_bytes);
+/* Row lengths beside the owners' sort.  A text column's width is the byte width of the dictionary's SIZE, not of its order:
+ *   zdw_owner_size           (owner, after zdw_owner_import) the bytes its range will take (sum of len + 1 of its deduplicated strings);
+ *   zdw_shard_rows_early     (requester) told the whole dictionary's size (1 + the owners' figures), starts its row lengths on the
+ *                            context's second stream, as if no row preceded its first; zdw_shard_set_prev_row has that row done again.
+ * Both are optional: without them the row lengths are computed when the rows are asked for (ConvertToZDW.cpp:486-606 has no such order). */
+int zdw_owner_size(zdw_ctx *ctx, uint64_t *bytes);
+int zdw_shard_rows_early(zdw_ctx *ctx, uint64_t dict_size);
 int zdw_shard_model_walk(zdw_ctx *ctx, const void *d_flags, uint64_t count, double limit_mb, zdw_model_state *state, uint32_t *found,
                          uint32_t *row, uint32_t *fields, uint64_t *row_start, uint64_t *trip_pos);
 int zdw_shard_trim(zdw_ctx *ctx, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res);

@@ -109,6 +109,8 @@ def lib():
         L.zdw_owner_import.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64]
         L.zdw_owner_first_flags.argtypes = [vp, C.POINTER(vp)]
         L.zdw_owner_finish.argtypes = [vp, C.c_uint64, u64p]
+        L.zdw_owner_size.argtypes = [vp, u64p]
+        L.zdw_shard_rows_early.argtypes = [vp, C.c_uint64]
         L.zdw_shard_model_walk.argtypes = [vp, vp, C.c_uint64, C.c_double, C.POINTER(ModelState), u32p, u32p, u32p, u64p, u64p]
         L.zdw_shard_trim.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(Pass1Result)]
         L.zdw_multi_next.argtypes = [vp]
@@ -547,6 +549,16 @@ class Encoder:
         out = C.c_uint64()
         self._chk(self.L.zdw_owner_finish(self.h, (1 << 64) - 1 if last_pos is None else last_pos, C.byref(out)))
         return out.value
+
+    def owner_size(self):
+        """(owner, after owner_import) the bytes this range will take in the dictionary: known before the range is sorted"""
+        out = C.c_uint64()
+        self._chk(self.L.zdw_owner_size(self.h, C.byref(out)))
+        return out.value
+
+    def rows_early(self, dict_size):
+        """(requester) the dictionary's size is known: the row lengths start on the context's second stream, beside the owners' sort"""
+        self._chk(self.L.zdw_shard_rows_early(self.h, dict_size))
 
     def owner_section(self, dict_size, first_range):
         self._chk(self.L.zdw_owner_section(self.h, dict_size, 1 if first_range else 0))

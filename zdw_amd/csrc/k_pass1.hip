@@ -822,14 +822,22 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
         uint64_t tstorem = ftm & ~slowm & inblkm;
         if (P1_ABLATE(a, 4u)) tstorem = 0;
         if (lane_in(tstorem)) {
+#ifdef ZDW_P1_NT_REC
+            __builtin_nontemporal_store(t_id, reinterpret_cast<uint32_t *>(recp_of()));
+#else
             *reinterpret_cast<uint32_t *>(recp_of()) = t_id;
+#endif
             if (SKIP && a.nz && t_id) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }
     // the integer fields' records
     if (nstorem) {
         if (lane_in(nstorem)) {
+#ifdef ZDW_P1_NT_REC
+            __builtin_nontemporal_store(n_rec, reinterpret_cast<uint64_t *>(recp_of()));
+#else
             *reinterpret_cast<uint64_t *>(recp_of()) = n_rec;
+#endif
             if (SKIP && a.nz && n_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }

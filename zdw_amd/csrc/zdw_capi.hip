@@ -176,6 +176,10 @@ struct zdw_ctx {
     uint64_t next_lo = 0;                  // start of the next block (set by pass 1)
     // block state
     bool p1_done = false, dict_size_done = false, dict_done = false, stats_done = false, p2_size_done = false, p2_done = false, is_last = true;
+    // a shard's row lengths started early (zdw_shard_rows_early): computed as if no row preceded its first one, for the dictionary size
+    // p2_early_size; the first row is done again once the row before it is known (zdw_shard_set_prev_row)
+    bool p2_size_early = false, p2_row0_stale = false;
+    uint64_t p2_early_size = 0;
     uint32_t dict_max_len = 24;
     uint32_t nrows = 0;
     uint64_t nslots = 0;
@@ -298,6 +302,7 @@ void reset_block(zdw_ctx *c)
 {
     c->st_known = false;
     c->p1_done = c->dict_size_done = c->dict_done = c->stats_done = c->p2_size_done = c->p2_done = false;
+    c->p2_size_early = c->p2_row0_stale = false;
     c->uniques_sorted = c->own_built = c->own_imported = false;
     c->nrows = 0; c->nuniq = 0; c->nids = 0; c->dict_size = 0; c->rows_len = 0; c->extra_bytes = 0;
     c->have_prev = false;
@@ -839,9 +844,13 @@ int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zd
 }
 
 // the block's ranges, dictionary or halo row have changed: row lengths computed ahead (start_pass2_size) are void
-void invalidate_pass2(zdw_ctx *c)
+// keep_early: the caller changes nothing the early row lengths of a shard depend on (zdw_shard_rows_early)
+void invalidate_pass2(zdw_ctx *c, bool keep_early = false)
 {
-    if (c->p2_size_done) { (void)hipStreamSynchronize(c->stream2); c->p2_size_done = false; }
+    if (c->p2_size_done && !(keep_early && c->p2_size_early)) {
+        (void)hipStreamSynchronize(c->stream2);
+        c->p2_size_done = c->p2_size_early = c->p2_row0_stale = false;
+    }
     c->p2_done = false;
 }
 
@@ -990,6 +999,15 @@ int run_pass2(zdw_ctx *c)
         StageScope ts(c, ZDW_STAGE_PASS2_SIZE);
         launch_pass2_size(a, s);
         launch_scan_u32_to_u64(a.row_len, c->row_off.as<uint64_t>(), c->nrows, c->scan_tmp2.p, nullptr, s);
+    } else if (c->p2_row0_stale) {
+        // the row lengths were computed early, as if nothing preceded the shard's first row: that row again, against the row before it,
+        // and the offsets once more
+        StageScope ts(c, ZDW_STAGE_PASS2_SIZE);
+        Pass2Args b = a;
+        b.nrows = 1; b.background = 0;
+        launch_pass2_size(b, s);
+        launch_scan_u32_to_u64(a.row_len, c->row_off.as<uint64_t>(), c->nrows, c->scan_tmp2.p, nullptr, s);
+        c->p2_row0_stale = false;
     }
     uint64_t total = 0;
     HIP_TRY(c, hipMemcpyAsync(&total, c->row_off.as<uint64_t>() + c->nrows, 8, hipMemcpyDeviceToHost, s));
@@ -2024,7 +2042,8 @@ int zdw_shard_set_prev_row(zdw_ctx *c, const uint64_t *stored)
     if (!c) return ZDW_UNKNOWN_ERROR;
     c->have_prev = stored != nullptr;
     if (stored) c->prev_row.assign(stored, stored + c->ncols);
-    invalidate_pass2(c);
+    if (c->p2_size_early && stored) c->p2_row0_stale = true;
+    invalidate_pass2(c, true);
     return ZDW_OK;
 }
 
@@ -2371,7 +2390,46 @@ int zdw_owner_section(zdw_ctx *c, uint64_t dict_size, int first_range)
     if (!c->uniques_sorted) c->nuniq = dict_size > 1 ? 1 : 0;          // (no rows of this block here: only "is the section empty" is ever asked)
     c->dict_size_done = c->dict_done = true;
     c->stats_done = false;
-    invalidate_pass2(c);
+    invalidate_pass2(c, c->p2_size_early && c->p2_early_size == dict_size);      // (row lengths started early for this very size stay)
+    return ZDW_OK;
+}
+
+// (owner) the bytes this range will take in the dictionary -- the sum of len + 1 over its strings -- known once the arrivals are
+// deduplicated, BEFORE they are sorted: with every owner's figure the requesters know the dictionary's size (the width of the text
+// columns) and start their row lengths while the owners sort (zdw_shard_rows_early)
+int zdw_owner_size(zdw_ctx *c, uint64_t *bytes)
+{
+    if (!c || !c->own_imported) return c ? fail(c, ZDW_UNKNOWN_ERROR, "zdw_owner_import has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    uint64_t total = 0;
+    if (c->own_nids) {
+        HIP_TRY(c, c->scan_tmp.ensure(std::max<size_t>(scan_tmp_bytes(c->own_nids + 1), DICT_TOTAL_BLOCKS * 8)));
+        const uint32_t nb = launch_dict_total(c->own_ulen.as<uint32_t>(), c->own_nids, static_cast<uint64_t *>(c->scan_tmp.p), s);
+        std::vector<uint64_t> part(nb);
+        HIP_TRY(c, hipMemcpyAsync(part.data(), c->scan_tmp.p, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (uint64_t v : part) total += v;
+    }
+    if (bytes) *bytes = total;
+    return ZDW_OK;
+}
+
+// (requester) the block's dictionary will be dict_size bytes (origin byte included): the row lengths of this shard's rows start now, on
+// the context's second stream, as if no row preceded its first one; zdw_shard_set_prev_row later has that one row done again.  The
+// column ranges must be the block's (zdw_shard_import_ranges) already.
+int zdw_shard_rows_early(zdw_ctx *c, uint64_t dict_size)
+{
+    if (!c || !c->p1_done) return c ? fail(c, ZDW_UNKNOWN_ERROR, "pass 1 has not run") : ZDW_UNKNOWN_ERROR;
+    (void)hipSetDevice(c->device);
+    if (c->have_prev || c->p2_size_done || c->p2_done || dict_size == 0 || dict_size >= (1ull << 32)) return ZDW_OK;      // (nothing to gain, or not representable: the ordinary way later)
+    c->dict_size = dict_size;
+    c->index_size = (uint8_t)bytes_for(dict_size);
+    c->dict_size_done = true;
+    c->stats_done = false;
+    const int rc = start_pass2_size(c);
+    if (rc) return rc;
+    if (c->p2_size_done) { c->p2_size_early = true; c->p2_early_size = dict_size; }
     return ZDW_OK;
 }
 

@@ -577,8 +577,20 @@ int zdw_multi_encode(zdw_multi *m, zdw_multi_block *blk)
     }
 
     // ---- 2. the owners sort and lay out what belongs to the block; every string's offset travels back ----
+    // (When no string is dropped -- the block takes everything its shards sent -- the dictionary's size is known before the owners
+    // sort: the sum of what their deduplicated ranges take.  The requesters then start their row lengths beside that sort.)
+    uint64_t early_size = 0;
+    if (!tripped) {
+        early_size = 1;
+        for (size_t i = 0; i < n && early_size; ++i) {
+            uint64_t b = 0;
+            if (zdw_owner_size(m->sh[i].ctx, &b) != ZDW_OK) early_size = 0; else early_size += b;
+        }
+        if (early_size >= (1ull << 32)) early_size = 0;
+    }
     for_shards(m, [&](size_t i) {
         Shard &s = m->sh[i];
+        if (early_size && i >= first && i <= end_shard) (void)zdw_shard_rows_early(s.ctx, early_size);      // (optional: a failure only means the ordinary order)
         s.rc = zdw_owner_finish(s.ctx, tripped ? trip_gpos : ~0ull, &s.slice);
         if (s.rc) s.err = zdw_last_error(s.ctx);
     });

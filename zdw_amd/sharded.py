@@ -402,6 +402,11 @@ def _local(fn):
         return None, (e.code or 20), e
 
 
+def capi_error(code, text):
+    from . import capi
+    return capi.ZdwError(code, text)
+
+
 def _raise_together(rcs, mine, err, what):
     """rcs: every rank's code for the same step (the same list on every rank).  Raises on all of them when one failed."""
     from . import capi
@@ -442,16 +447,29 @@ def partitioned_dictionary(enc, rank, world, device, group=None):
     got_byts = alltoallv(byts, nb, rbytes, group=group)
     _torch_done()
     laps.mark("strings all-to-all")
-    # (an owner whose build fails still reports: the size all-gather carries its code, so nobody waits for it in vain)
-    slice_bytes, rc_own, err = _local(lambda: enc.owner_build(got_lens.data_ptr() if got_lens.numel() else 0, got_byts.data_ptr() if got_byts.numel() else 0,
-                                                              got_lens.numel(), got_byts.numel()))
+    # The owner's build in two halves.  First the arrivals are deduplicated: that fixes the bytes the range takes in the dictionary, so
+    # the gather of those figures can come BEFORE the sort -- every rank then knows the dictionary's size, i.e. the width of its text
+    # columns, and starts its row lengths on its second stream while the owners sort (the first row again once the halo row is known).
+    # (an owner whose import fails still reports: the size all-gather carries its code, so nobody waits for it in vain)
+    def _import():
+        enc.owner_import(got_lens.data_ptr() if got_lens.numel() else 0, got_byts.data_ptr() if got_byts.numel() else 0, 0, got_lens.numel(), got_byts.numel())
+        return enc.owner_size()
+    slice_bytes, rc_own, err = _local(_import)
     gathered = allgather_i64([slice_bytes or 0, rc_own], device, group=group)
     _raise_together([a[1] for a in gathered], rc_own, err, "building a dictionary range")
     slices = [a[0] for a in gathered]
-    laps.mark("owner build")
+    laps.mark("owner import")
     bases, total = range_bases(slices)
-    # (the last two rank-local steps: their codes go to the caller, whose next collective carries them)
-    d_offs, rc_tail, err_tail = _local(lambda: enc.owner_offsets(bases[rank]))
+    # (rank-local steps from here on: their codes go to the caller, whose next collective carries them)
+    def _finish():
+        if total < (1 << 32):
+            enc.rows_early(total)
+        got = enc.owner_finish(None)
+        if got != slices[rank]:
+            raise capi_error(20, "the range took %d bytes where %d were announced" % (got, slices[rank]))
+        return enc.owner_offsets(bases[rank])
+    d_offs, rc_tail, err_tail = _local(_finish)
+    laps.mark("owner sort")
     if d_offs is not None:
         offs = _wrap(d_offs, sum(rcounts) * 4, "<i4", device).clone()
         _torch_done()
