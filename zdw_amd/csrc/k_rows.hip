@@ -19,10 +19,15 @@
 //     a backslash at all; a row that touches such a span is walked byte by byte by its lane and its fields go to the general form.
 // What it costs: rows lie ~2 KB apart, so a wave's 64 cursors touch 64 different cache lines per step.  Each lane therefore keeps a
 // ring of its row's bytes in LDS (dword-transposed: dword j of lane l at (j * 64 + l) * 4, conflict-free for any mix of j), refilled
-// 64 bytes at a time by its own 16-byte loads two steps ahead of need; records are staged in LDS per row and written out as whole
-// 16-byte pieces by neighbouring lanes (a 4- or 8-byte store per lane and step to 64 different lines would be bound by the L2's
-// request rate: 250 G/s, tools/probe_rate.hip).  LDS (18 KiB of ring per wave) bounds the kernel at 6 waves per CU; with wave-uniform
-// control flow and the probe of one step resolved behind the next step's window that is enough to keep the vector ALUs busy.
+// 64 bytes at a time by its own 16-byte loads well ahead of need; the bytes are classified once, when they arrive (a boundary bitmap
+// beside the ring); records are staged in LDS per row and written out as whole 16-byte pieces by neighbouring lanes (a 4- or 8-byte
+// store per lane and step to 64 different lines would be bound by the L2's request rate: 250 G/s, tools/probe_rate.hip).
+//
+// STATUS (round 4): exact -- every reference vector, the fuzz campaign -- and SLOWER than k_pass1.hip (10 GB: 16.0 ms +
+// 4.0 ms for the row index against 10.8 ms), so zdw_capi.hip runs it only when asked to (ZDW_P1_ROWS).  The LDS it needs (26 KiB per
+// wave) leaves 6 waves per CU; at 1.5 waves per SIMD the ~300 instructions of a step issue one every four to five cycles and every
+// dependent LDS round trip and memory wait shows, and half of all text steps hold a lane whose slot needs a second look or an insert,
+// which is handled synchronously.  What it would take is in DESIGN.md; what it proved useful for is there too.
 #include "zdw_dev.h"
 #include "zdw_knobs.h"
 #include "zdw_kernels.h"
