@@ -940,6 +940,9 @@ void launch_locate_field(const uint8_t *in, uint64_t lo, uint64_t p, uint64_t *o
 // -- leave behind is rebuilt from their records: the strings they refer to (every other unique id becomes a hole), the columns they
 // fill, the ranges of their numbers.  A record holds what pass 2 writes; the range takes a char(1) field's first byte alone unless
 // that byte is a backslash (zdw_field_dev.h, ConvertToZDW.cpp:358-361 against :543-547).
+// MARK: the ids the kept records hold are marked in `live` (otherwise k_trim_ids goes by the strings' first positions and this kernel
+// only reads: eight rows' loads in flight per thread).
+template <bool MARK>
 __global__ __launch_bounds__(256) void k_trim_scan(const uint8_t *__restrict__ rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *__restrict__ col_kind,
                                                    const uint32_t *__restrict__ col_recoff, uint32_t rows, uint32_t partial, uint8_t *__restrict__ live,
                                                    uint64_t *__restrict__ col_min, uint64_t *__restrict__ col_max, uint8_t *__restrict__ col_seen,
@@ -954,16 +957,33 @@ __global__ __launch_bounds__(256) void k_trim_scan(const uint8_t *__restrict__ r
         const uint64_t stop = (r1 > rows && col >= partial) ? rows : r1;       // the partial row: its first fields only
         uint64_t mn = ~0ull, mx = 0;
         bool seen = false;
-        for (uint64_t r = r0; r < stop; ++r) {
-            if (nz && !((nz[r * nz_stride + (col >> 5)] >> (col & 31u)) & 1u)) continue;               // (a matrix written through the map of non-zero records: zero elsewhere)
-            const uint8_t *p = rec + r * rec_stride + off;
+        if (!MARK && !nz) {
+            const uint8_t *p = rec + r0 * rec_stride + off;
             if (kind == K_TEXT) {
-                const uint32_t id1 = *reinterpret_cast<const uint32_t *>(p);
-                if (id1) { live[id1 - 1u] = 1; seen = true; }
+                uint32_t any = 0;
+#pragma unroll 8
+                for (uint64_t r = r0; r < stop; ++r, p += rec_stride) any |= *reinterpret_cast<const uint32_t *>(p);
+                seen = any != 0;
             } else {
-                uint64_t v = *reinterpret_cast<const uint64_t *>(p);
-                if (kind == K_CHAR && (v & 0xffu) != (uint64_t)'\\') v = (uint64_t)(int64_t)(int8_t)(v & 0xffu);
-                if (v) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+#pragma unroll 8
+                for (uint64_t r = r0; r < stop; ++r, p += rec_stride) {
+                    uint64_t v = *reinterpret_cast<const uint64_t *>(p);
+                    if (kind == K_CHAR && (v & 0xffu) != (uint64_t)'\\') v = (uint64_t)(int64_t)(int8_t)(v & 0xffu);
+                    mn = v && v < mn ? v : mn; mx = v > mx ? v : mx;
+                }
+            }
+        } else {
+            for (uint64_t r = r0; r < stop; ++r) {
+                if (nz && !((nz[r * nz_stride + (col >> 5)] >> (col & 31u)) & 1u)) continue;           // (a matrix written through the map of non-zero records: zero elsewhere)
+                const uint8_t *p = rec + r * rec_stride + off;
+                if (kind == K_TEXT) {
+                    const uint32_t id1 = *reinterpret_cast<const uint32_t *>(p);
+                    if (id1) { if (MARK) live[id1 - 1u] = 1; seen = true; }
+                } else {
+                    uint64_t v = *reinterpret_cast<const uint64_t *>(p);
+                    if (kind == K_CHAR && (v & 0xffu) != (uint64_t)'\\') v = (uint64_t)(int64_t)(int8_t)(v & 0xffu);
+                    if (v) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+                }
             }
         }
         if (kind == K_TEXT) {
@@ -974,26 +994,38 @@ __global__ __launch_bounds__(256) void k_trim_scan(const uint8_t *__restrict__ r
         }
     }
 }
-// unique ids no kept row refers to become holes; *entries = the strings that stay
-__global__ __launch_bounds__(256) void k_trim_ids(const uint8_t *__restrict__ live, uint32_t *__restrict__ uniq_len, uint32_t n, uint32_t *__restrict__ entries)
+// unique ids no kept row refers to become holes; *entries = the strings that stay.  Which ones stay: `live` (k_trim_scan marked the
+// ids the kept records hold), or -- live == nullptr, the block was parsed with Pass1Args.track_first -- those whose first occurrence
+// lies at or before last_pos, the tripping field's start (a kept field starts at or before it, any other behind it).
+// A workgroup adds what it kept with one atomic (one per wave: 600 000 of them on one word took 6.7 of C5's 72 ms per block).
+__global__ __launch_bounds__(256) void k_trim_ids(const uint8_t *__restrict__ live, const uint64_t *__restrict__ uniq_pos, uint64_t last_pos,
+                                                  uint32_t *__restrict__ uniq_len, uint32_t n, uint32_t *__restrict__ entries)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool keep = false;
-    if (i < n && uniq_len[i]) {
-        keep = live[i] != 0;
-        if (!keep) uniq_len[i] = 0;
+    __shared__ uint32_t kept_of_wave[4];
+    uint32_t kept = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        if (!uniq_len[i]) continue;
+        const bool keep = live ? live[i] != 0 : (uniq_pos[i] & POS_MASK) <= last_pos;
+        if (keep) ++kept; else uniq_len[i] = 0;
     }
-    const uint32_t k = popc64(__ballot(keep));
-    if (k && lane_id() == 0) atomicAdd(entries, k);
+    kept = wave_incl_sum(kept);
+    if (lane_id() == 63) kept_of_wave[threadIdx.x >> 6] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t k = kept_of_wave[0] + kept_of_wave[1] + kept_of_wave[2] + kept_of_wave[3];
+        if (k) atomicAdd(entries, k);
+    }
 }
 void launch_trim_block(const uint8_t *rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff, uint32_t rows,
-                       uint32_t partial, uint8_t *live, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids,
-                       uint32_t *entries, const uint32_t *nz, uint32_t nz_stride, hipStream_t s)
+                       uint32_t partial, uint8_t *live, const uint64_t *uniq_pos, uint64_t last_pos, uint64_t *col_min, uint64_t *col_max,
+                       uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids, uint32_t *entries, const uint32_t *nz, uint32_t nz_stride, hipStream_t s)
 {
     const uint64_t last = (uint64_t)rows + (partial ? 1u : 0u);
-    if (last) hipLaunchKernelGGL(k_trim_scan, dim3((uint32_t)((last + 31) / 32)), dim3(256), 0, s, rec, rec_stride, ncols, col_kind, col_recoff, rows, partial,
-                                 live, col_min, col_max, col_seen, nz, nz_stride);
-    if (nids) hipLaunchKernelGGL(k_trim_ids, dim3((nids + 255) / 256), dim3(256), 0, s, live, uniq_len, nids, entries);
+    if (last && live) hipLaunchKernelGGL(k_trim_scan<true>, dim3((uint32_t)((last + 31) / 32)), dim3(256), 0, s, rec, rec_stride, ncols, col_kind, col_recoff, rows,
+                                         partial, live, col_min, col_max, col_seen, nz, nz_stride);
+    else if (last) hipLaunchKernelGGL(k_trim_scan<false>, dim3((uint32_t)((last + 31) / 32)), dim3(256), 0, s, rec, rec_stride, ncols, col_kind, col_recoff, rows,
+                                      partial, live, col_min, col_max, col_seen, nz, nz_stride);
+    if (nids) hipLaunchKernelGGL(k_trim_ids, dim3(std::min<uint32_t>((nids + 255) / 256, 2048u)), dim3(256), 0, s, live, uniq_pos, last_pos, uniq_len, nids, entries);
 }
 
 // Persistent waves: a wave keeps its chunk of unique ids across the groups of 64 strings it handles (one

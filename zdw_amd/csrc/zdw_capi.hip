@@ -221,6 +221,7 @@ struct zdw_ctx {
     DevBuf own_pos, own_minpos, own_flags;  // ... where a memory limit may end the block: every arrival's first position, the smallest per string
     DevBuf model_len, exp_pos;             // requester side of that: lengths as the arena walk sees them, positions of the exported strings
     bool track_first_opt = false;          // zdw_opts.track_first_occurrence
+    bool last_track = false;               // the last pass 1 kept every string's first position (Pass1Args.track_first)
     bool defer_bad_row = false;            // zdw_opts.defer_bad_row
     bool p1_all_in_one = false;            // the deferred-field queue would outgrow its budget: use the all-in-one kernel
     uint64_t dq_learned = 0;               // queue entries an earlier pass of this context needed
@@ -710,7 +711,7 @@ constexpr uint64_t MODEL_ARENA = 64ull << 20;
 
 int locate_occurrence(zdw_ctx *c, uint64_t pos, uint32_t span_shift, uint64_t span0, uint32_t *row, uint32_t *fields, uint64_t *row_start);
 
-int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uint32_t *row, uint32_t *fields, uint64_t *row_start)
+int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uint32_t *row, uint32_t *fields, uint64_t *row_start, uint64_t *trip_pos)
 {
     *found = false;
     hipStream_t s = c->stream;
@@ -753,6 +754,7 @@ int model_trip(zdw_ctx *c, uint32_t span_shift, uint64_t span0, bool *found, uin
     pos &= POS_MASK;
     if (pos >= EXTRA_BASE) return ZDW_OK;                  // an imported string (multi-GPU merge): no position in this image
     *found = true;
+    *trip_pos = pos;
     return locate_occurrence(c, pos, span_shift, span0, row, fields, row_start);
 }
 
@@ -793,16 +795,22 @@ int ensure_dense_rec(zdw_ctx *c);
 // has a record: row < the rows pass 1 kept).  Instead of a second pass 1 up to there, what the rows beyond that point added is
 // taken back (k_trim_scan: launch_trim_block): strings only they hold become holes among the unique ids, ranges and used columns
 // are rebuilt from the records that stay, the line buffer is replayed up to the new end.
-int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res, bool allow_no_rows = false)
+// trip_pos: where the field that ends the block starts, when the caller knows it (~0: not).  With every string's first position at
+// hand (the model's pass 1 keeps them) the strings that stay are those first met at or before it, and the scan of the records
+// need not mark them one by one (58 M single-byte stores all over a 40 MB array per block of C5).
+int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zdw_pass1_result *res, bool allow_no_rows = false, uint64_t trip_pos = ~0ull)
 {
     hipStream_t s = c->stream;
     const bool sparse = c->nz_mode && !c->rec_dense;      // (the matrix means something only where the map says so: the scan goes by the map too)
+    const bool by_pos = trip_pos != ~0ull && c->last_track && !test_hook("ZDW_TRIM_BY_SCAN");      // (tests: the other form)
     P1Status st{};
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     const uint32_t u = st.id_next;
-    HIP_TRY(c, c->lenp1.ensure((uint64_t)u + 64));                   // a byte per unique id: some kept row refers to it
-    HIP_TRY(c, hipMemsetAsync(c->lenp1.p, 0, (uint64_t)u + 64, s));
+    if (!by_pos) {
+        HIP_TRY(c, c->lenp1.ensure((uint64_t)u + 64));               // a byte per unique id: some kept row refers to it
+        HIP_TRY(c, hipMemsetAsync(c->lenp1.p, 0, (uint64_t)u + 64, s));
+    }
     HIP_TRY(c, hipMemsetAsync(c->col_min.p, 0xFF, c->ncols * 8 + 8, s));
     HIP_TRY(c, hipMemsetAsync(c->col_max.p, 0, c->ncols * 8 + 8, s));
     HIP_TRY(c, hipMemsetAsync(c->col_seen.p, 0, c->ncols + 8, s));
@@ -812,7 +820,8 @@ int trim_block(zdw_ctx *c, uint32_t row, uint32_t fields, uint64_t row_start, zd
     {
         StageScope ts(c, ZDW_STAGE_PASS1);
         launch_trim_block(c->rec.as<uint8_t>(), c->rec_stride, c->ncols, c->d_kind.as<uint8_t>(), c->d_recoff.as<uint32_t>(), row, fields,
-                          c->lenp1.as<uint8_t>(), c->col_min.as<uint64_t>(), c->col_max.as<uint64_t>(), c->col_seen.as<uint8_t>(),
+                          by_pos ? nullptr : c->lenp1.as<uint8_t>(), c->uniq_pos.as<uint64_t>(), trip_pos,
+                          c->col_min.as<uint64_t>(), c->col_max.as<uint64_t>(), c->col_seen.as<uint8_t>(),
                           c->uniq_len.as<uint32_t>(), u, d_entries, sparse ? c->nz.as<uint32_t>() : nullptr, c->nz_stride, s);
     }
     HIP_TRY(c, hipMemcpyAsync(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost, s));
@@ -1270,9 +1279,9 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
         const double t1 = now_ms();
         bool found = false;
         uint32_t row = 0, fields = 0;
-        uint64_t row_start = 0;
+        uint64_t row_start = 0, trip_pos = ~0ull;
         c->model_vsize_end = 0.0;
-        rc = model_trip(c, c->last_span_shift, c->last_span0, &found, &row, &fields, &row_start);
+        rc = model_trip(c, c->last_span_shift, c->last_span0, &found, &row, &fields, &row_start, &trip_pos);
         if (rc) return rc;
         if (dbg) fprintf(stderr, "[model] window %llu rows: pass 1 %.1f ms, model %.1f ms (alloc so far %.1f)\n", (unsigned long long)window, t1 - t0, now_ms() - t1, g_alloc_ms);
         if (found && row <= res->num_rows) {
@@ -1280,7 +1289,7 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
             c->model_rows_prev = row;
             // the rows beyond the end are taken back out of what pass 1 left (trim_block); ZDW_MODEL_RERUN=1 (tests) or an end
             // on the window's last row, which has no record: a second pass 1 up to exactly there instead
-            if (row < res->num_rows && !test_hook("ZDW_MODEL_RERUN")) return trim_block(c, row, fields, row_start, res);
+            if (row < res->num_rows && !test_hook("ZDW_MODEL_RERUN")) return trim_block(c, row, fields, row_start, res, false, trip_pos);
             zdw_split_hint e = {row, fields};
             return pass1_impl(c, &e, res);
         }
@@ -1576,6 +1585,7 @@ int Pass1Job::parse()
             a.track_first = (c->model_max_slots || c->track_first_opt) ? 1u : 0u;
             if (const char *e = test_hook("ZDW_P1_TRACK_FIRST")) a.track_first = atoi(e) != 0;      // tests
             if (a.track_first) HIP_TRY(c, hipMemsetAsync(c->uniq_pos.p, 0xFF, (uint64_t)c->id_cap * 8, s));
+            c->last_track = a.track_first != 0;
             a.dense_boundaries = c->dense_boundaries ? 1u : 0u;
             if (const char *e = test_hook("ZDW_P1_LARGE_RING")) a.dense_boundaries = atoi(e) != 0;      // tests
             a.skip_empty = c->skip_empty ? 1u : 0u;

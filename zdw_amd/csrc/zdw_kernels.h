@@ -192,8 +192,8 @@ void launch_owner_minpos(const uint32_t *ids, const uint64_t *pos, uint64_t n, u
 void launch_owner_first(const uint32_t *ids, const uint64_t *pos, uint64_t n, const uint64_t *minpos, uint32_t *flags, hipStream_t s);
 void launch_owner_filter(const uint64_t *minpos, uint32_t *ulen, uint32_t n, uint64_t last_pos, hipStream_t s);
 void launch_trim_block(const uint8_t *rec, uint32_t rec_stride, uint32_t ncols, const uint8_t *col_kind, const uint32_t *col_recoff, uint32_t rows,
-                       uint32_t partial, uint8_t *live, uint64_t *col_min, uint64_t *col_max, uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids,
-                       uint32_t *entries, const uint32_t *nz, uint32_t nz_stride, hipStream_t s);
+                       uint32_t partial, uint8_t *live, const uint64_t *uniq_pos, uint64_t last_pos, uint64_t *col_min, uint64_t *col_max,
+                       uint8_t *col_seen, uint32_t *uniq_len, uint32_t nids, uint32_t *entries, const uint32_t *nz, uint32_t nz_stride, hipStream_t s);
 // range-partitioned dictionary (multi-GPU)
 void launch_key16_at(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
                      const uint32_t *order, const uint32_t *idx, uint32_t n, uint64_t *keys, hipStream_t s);
