@@ -93,6 +93,8 @@ def make_case(rnd):
         if rnd.random() < 0.5:
             env["ZDW_P1_ROWS_PER_LANE"] = rnd.choice(["1", "2", "7"])
     shards = rnd.choice([2, 3, 5]) if rnd.random() < 0.3 else 0
+    if rnd.random() < 0.35:
+        env["ZDW_SORT_PACK"] = "1"                               # the sort's packed first round wherever 8 characters fit one key
     return dict(desc=desc, types=types, tsv=tsv, trim=trim, split=split, env=env, ncols=ncols, nrows=nrows, shards=shards)
 
 

@@ -14,6 +14,8 @@
 #include "zdw_dict_dev.h"
 
 #include <algorithm>
+#include <array>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 
@@ -186,17 +188,112 @@ __global__ __launch_bounds__(256) void k_sort_init(uint32_t *order, uint32_t *ac
     if (i < n) { order[i] = i; active[i] = i; group[i] = 0; }
 }
 
+// ---- the first round's key, packed -------------------------------------------------------------------------------------------
+// Tables hold strings whose characters vary little at a given place (date-times: a digit, a colon; ids with a common prefix): when the
+// byte at place i of (nearly) all strings lies in one aligned block of 2^w values, only its low w bits decide the order.  A dictionary
+// holds the strings of all text columns, so this is looked at per FIRST BYTE, on a sample of the strings (plan_packed_round, on the
+// host): for each first byte and each of the places 1..23 kept by id (Pass1Args.uniq_key) the narrowest block that holds 98 % of the
+// sample's bytes.  A string CONFORMS when every one of its places lies in its first byte's blocks (exact, on the device, for every
+// string: k_sort_classes); the others -- names among 67 M date-times, a date-time cut short -- are EXCEPTIONS.  Then
+//   * the ids are grouped: holes, conforming strings, exceptions (one radix pass on the class);
+//   * the conforming strings' first round sorts by  1 | first byte (8 bits) | the low w bits of places 1 .. nchars - 1 (P bits):
+//     16 or 24 characters in one round instead of 8, on ceil((P + 9) / 8) radix passes instead of 8.  (The reference's movie_tickets
+//     table times 128: the date-times' 23 places take 39 bits -- one round of 6 passes instead of three rounds of 8 and their
+//     tie-group passes.)  Order-preserving: strings with different first bytes differ above bit P; two conforming strings of one
+//     first byte that first differ at place i agree in that place's dropped bits and in every bit before.  What is still tied goes
+//     on in ordinary rounds behind the characters every first byte's key covered;
+//   * the exceptions (few, or the plan is dropped) are sorted by ordinary rounds;
+//   * the two sorted lists are merged: every exception finds its place among the conforming strings by bisection on whole strings.
+struct PackedBucket {
+    uint64_t w[2];          // 4 bits per place 1..23: its width
+    uint64_t himask[3];     // per byte of the string's three words: the bits above the width (none for place 0 and places >= nchars)
+    uint64_t hival[3];      // ... and what a conforming string holds there
+    uint32_t nchars, pad;   // 8, 16 or 24; 0: no string of this first byte conforms
+};
+static_assert(sizeof(PackedBucket) == 72, "SORT_SPARE_WORDS counts on it");
+struct PackedKeySpec {
+    const PackedBucket *table;      // by first byte (nullptr: the round takes 8 bytes as they are)
+    uint32_t rest_bits;             // P
+};
+constexpr uint32_t SORT_SAMPLE = 4096;
+
+// out[4 t ..]: the three words and the length of string floor(t n / S)
+__global__ __launch_bounds__(256) void k_sort_sample(const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ uniq_len, uint32_t n, uint32_t S,
+                                                     uint64_t *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S) return;
+    const uint64_t u = (uint64_t)t * n / S;
+    const uint32_t len = uniq_len[u];
+    out[4 * t] = len ? uniq_key[3 * u] : 0; out[4 * t + 1] = len ? uniq_key[3 * u + 1] : 0; out[4 * t + 2] = len ? uniq_key[3 * u + 2] : 0;
+    out[4 * t + 3] = len;
+}
+
+__device__ __forceinline__ bool conforms(uint64_t k0, uint64_t k1, uint64_t k2, const PackedBucket &pb)
+{
+    return pb.nchars && (k0 & pb.himask[0]) == pb.hival[0] && (k1 & pb.himask[1]) == pb.hival[1] && (k2 & pb.himask[2]) == pb.hival[2];
+}
+
+// keys[u] = 0 hole, 1 conforming, 2 exception; vals[u] = u; counts[c] += the strings of class c
+__global__ __launch_bounds__(256) void k_sort_classes(const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ uniq_len, uint32_t n,
+                                                      const PackedBucket *__restrict__ table, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                      uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t sc[3];
+    if (threadIdx.x < 3) sc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cls = 3;
+    if (u < n) {
+        cls = 0;
+        if (uniq_len[u]) {
+            const uint64_t k0 = uniq_key[3ull * u], k1 = uniq_key[3ull * u + 1], k2 = uniq_key[3ull * u + 2];
+            cls = conforms(k0, k1, k2, table[(uint32_t)k0 & 255u]) ? 1u : 2u;
+        }
+        keys[u] = cls; vals[u] = u;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+        const uint32_t k = popc64(__ballot(cls == c));
+        if (k && lane_id() == 0) atomicAdd(&sc[c], k);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && sc[threadIdx.x]) atomicAdd(counts + threadIdx.x, sc[threadIdx.x]);
+}
+
+// (k0, k1, k2: a conforming string's first 24 bytes as kept by id -- its first character is the low byte of k0)
+__device__ __forceinline__ uint64_t packed_key(uint64_t k0, uint64_t k1, uint64_t k2, const PackedKeySpec &ps)
+{
+    const uint32_t b = (uint32_t)k0 & 255u;
+    const PackedBucket pb = ps.table[b];
+    uint64_t rest = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < 24; ++i) {
+        if (i >= pb.nchars) break;
+        const uint32_t w = (uint32_t)(pb.w[i >> 4] >> (4 * (i & 15u))) & 15u;
+        const uint64_t word = i < 8 ? k0 : (i < 16 ? k1 : k2);
+        const uint32_t byte = (uint32_t)(word >> (8 * (i & 7u))) & 255u;
+        rest = (rest << w) | (byte & ((1u << w) - 1u));
+    }
+    return ((uint64_t)(256u + b) << ps.rest_bits) | rest;
+}
+
 // keys[j] = 8 bytes at depth d of the string now at position active[j]; vals[j] = j
 __global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
                                                     const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
                                                     const uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     uint32_t m, uint32_t depth, uint64_t *__restrict__ keys,
-                                                    uint32_t *__restrict__ vals, const uint64_t *__restrict__ uniq_key)
+                                                    uint32_t *__restrict__ vals, const uint64_t *__restrict__ uniq_key, const PackedKeySpec ps)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t u = order ? order[active[j]] : j;          // first round: everything is in place (order = active = identity)
     const uint32_t len = uniq_len[u];
+    if (ps.table) {
+        keys[j] = packed_key(uniq_key[3ull * u], uniq_key[3ull * u + 1], uniq_key[3ull * u + 2], ps);      // (only conforming strings get here)
+        vals[j] = j;
+        return;
+    }
     if (uniq_key && depth < 3) {
         // the first 24 bytes were kept by id when the string entered the table: in the first round a streaming read
         // instead of a visit to the image per string
@@ -383,6 +480,133 @@ __global__ __launch_bounds__(256) void k_sort_place(uint32_t *__restrict__ order
     order[active[k]] = tmp[k];
 }
 
+// ---- the merge of the conforming strings' list and the exceptions' ----
+// a < b as whole strings (both real): the words kept by id, then the image
+__device__ inline bool string_less(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len,
+                                   const uint64_t *uniq_key, uint32_t a, uint32_t b)
+{
+    const uint32_t la = uniq_len[a], lb = uniq_len[b];
+    for (uint32_t d = 0; d < 3; ++d) {
+        const uint64_t ka = __builtin_bswap64(uniq_key[3ull * a + d]), kb = __builtin_bswap64(uniq_key[3ull * b + d]);
+        if (ka != kb) return ka < kb;
+    }
+    const uint64_t pa = uniq_pos[a], pb = uniq_pos[b];
+    const uint8_t *sa = string_at(in, extra, pa), *sb = string_at(in, extra, pb);
+    for (uint32_t d = 3; 8u * d < la || 8u * d < lb; ++d) {
+        const uint64_t ka = sort_key8(sa, la, d, pa >= EXTRA_BASE ? sa + la + 16 : in + in_bytes);
+        const uint64_t kb = sort_key8(sb, lb, d, pb >= EXTRA_BASE ? sb + lb + 16 : in + in_bytes);
+        if (ka != kb) return ka < kb;
+    }
+    return false;
+}
+// rank[j] = how many of the sorted strings A[0 .. na) sort before the j-th of the sorted strings B
+__global__ __launch_bounds__(256) void k_merge_ranks(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
+                                                     const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
+                                                     const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ A, uint32_t na,
+                                                     const uint32_t *__restrict__ B, uint32_t nb, uint32_t *__restrict__ rank)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    const uint32_t u = B[j];
+    uint32_t lo = 0, hi = na;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (string_less(in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, A[mid], u)) lo = mid + 1; else hi = mid;
+    }
+    rank[j] = lo;
+}
+// out[0 .. na + nb): the two lists as one.  B's j-th string lands at rank[j] + j; A's i-th behind the exceptions that sort before it
+// (rank <= i; the ranks ascend: bisection).
+__global__ __launch_bounds__(256) void k_merge_place(const uint32_t *__restrict__ A, uint32_t na, const uint32_t *__restrict__ B, uint32_t nb,
+                                                     const uint32_t *__restrict__ rank, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na + nb) return;
+    if (i >= na) { const uint32_t j = i - na; out[rank[j] + j] = B[j]; return; }
+    uint32_t lo = 0, hi = nb;                        // the first j with rank[j] > i
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (rank[mid] <= i) lo = mid + 1; else hi = mid;
+    }
+    out[i + lo] = A[i];
+}
+__global__ __launch_bounds__(256) void k_sort_init_range(uint32_t *active, uint32_t *group, uint32_t off, uint32_t m)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) { active[off + i] = off + i; group[off + i] = 0; }
+}
+
+// What the packed first round would look like, from a sample of the strings (SORT_SAMPLE x {three words, length}).  force (tests):
+// a plan whenever one exists, however little it saves and however many strings it leaves out.
+struct PackPlan { bool use = false; uint32_t P = 0, depth_after = 0, chars = 0; double exceptions = 0.0; std::vector<PackedBucket> table; };
+static void plan_packed_round(const uint64_t *sample, uint32_t S, bool force, PackPlan &pl)
+{
+    auto byte_of = [&](uint32_t t, uint32_t i) { return (uint32_t)(sample[4 * t + (i >> 3)] >> (8 * (i & 7u))) & 255u; };
+    std::vector<std::vector<uint32_t>> by(256);
+    uint32_t real = 0;
+    for (uint32_t t = 0; t < S; ++t) if (sample[4 * t + 3]) { by[byte_of(t, 0)].push_back(t); ++real; }
+    if (real < (force ? 2u : 256u)) return;
+    std::vector<std::array<uint32_t, 24>> w(256);
+    std::vector<std::array<uint32_t, 25>> W(256);
+    std::vector<std::array<uint8_t, 24>> base(256);
+    std::vector<uint32_t> judged;
+    for (uint32_t b = 0; b < 256; ++b) {
+        const uint32_t cnt = (uint32_t)by[b].size();
+        if (cnt < (force ? 1u : 16u)) continue;                    // too few to judge: exceptions
+        W[b][0] = W[b][1] = 0; w[b][0] = 0; base[b][0] = 0;
+        const uint32_t need = cnt - cnt / 50;                      // 98 % of them
+        for (uint32_t i = 1; i < 24; ++i) {
+            uint32_t upto[257] = {0};                               // upto[v]: the strings whose byte here is below v
+            for (uint32_t t : by[b]) ++upto[byte_of(t, i) + 1];
+            for (uint32_t v = 0; v < 256; ++v) upto[v + 1] += upto[v];
+            uint32_t wi = 8, bs = 0;
+            for (uint32_t k = 0; k < 8 && wi == 8; ++k)            // the narrowest aligned block of 2^k values that holds them
+                for (uint32_t lo = 0; lo < 256; lo += 1u << k)
+                    if (upto[lo + (1u << k)] - upto[lo] >= need) { wi = k; bs = lo; break; }
+            w[b][i] = wi; base[b][i] = (uint8_t)bs;
+            W[b][i + 1] = W[b][i] + wi;
+        }
+        judged.push_back(b);
+    }
+    if (judged.empty()) return;
+    std::sort(judged.begin(), judged.end(), [&](uint32_t x, uint32_t y) { return by[x].size() != by[y].size() ? by[x].size() > by[y].size() : x < y; });
+    // P: what the first bytes that hold 98 % of the sample need for 24, 16 or 8 characters (the key has 63 - 9 bits for them)
+    uint32_t nmajor = 0;
+    for (uint64_t seen = 0; nmajor < judged.size() && seen * 50 < (uint64_t)real * 49; ++nmajor) seen += by[judged[nmajor]].size();
+    uint32_t kmaj = 0, P = 0;
+    for (uint32_t k : {24u, 16u, 8u}) {
+        uint32_t need = 0;
+        for (uint32_t i = 0; i < nmajor; ++i) need = std::max(need, W[judged[i]][k]);
+        if (need + 9 <= 63) { kmaj = k; P = need; break; }
+    }
+    if (!kmaj) return;
+    pl.table.assign(256, PackedBucket{});
+    pl.depth_after = 3;
+    for (uint32_t b : judged) {
+        PackedBucket &pb = pl.table[b];
+        pb.nchars = W[b][24] <= P ? 24u : (W[b][16] <= P ? 16u : (W[b][8] <= P ? 8u : 0u));
+        for (uint32_t i = 1; i < pb.nchars; ++i) {
+            pb.w[i >> 4] |= (uint64_t)w[b][i] << (4 * (i & 15u));
+            const uint64_t hm = (0xFFu << w[b][i]) & 0xFFu;
+            pb.himask[i >> 3] |= hm << (8 * (i & 7u));
+            pb.hival[i >> 3] |= ((uint64_t)base[b][i] & hm) << (8 * (i & 7u));
+        }
+        if (pb.nchars) pl.depth_after = std::min(pl.depth_after, pb.nchars / 8);
+    }
+    uint32_t exc = 0;
+    for (uint32_t t = 0; t < S; ++t) {
+        if (!sample[4 * t + 3]) continue;
+        const PackedBucket &pb = pl.table[byte_of(t, 0)];
+        const bool ok = pb.nchars && (sample[4 * t] & pb.himask[0]) == pb.hival[0] && (sample[4 * t + 1] & pb.himask[1]) == pb.hival[1] &&
+                        (sample[4 * t + 2] & pb.himask[2]) == pb.hival[2];
+        if (!ok) ++exc;
+    }
+    pl.P = P; pl.chars = kmaj; pl.exceptions = (double)exc / (double)real;
+    // worth it: few exceptions (they are sorted the ordinary way and then found their places one by one), and more than 8 characters
+    // in the round or 6 passes at most
+    pl.use = force ? exc < real : (exc * 32ull <= real && (kmaj > 8 || P + 9 <= 48));
+}
+
 // Sort n unique strings.  Buffers: see SortBuffers.  Returns 0 or a hipError_t.
 int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n64,
               SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len, const uint64_t *uniq_key)
@@ -392,75 +616,142 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     if (n == 0) { if (rounds_out) *rounds_out = 0; return 0; }
     const uint32_t nb256 = (n + 255) / 256;
     hipLaunchKernelGGL(k_sort_init, dim3(nb256), dim3(256), 0, s, b.order, b.active_a, b.group, n);
-    uint32_t *active = b.active_a, *active_alt = b.active_b;
-    // group labels per active index live in val-sized scratch: group (current) and flags-derived next
-    uint32_t *group = b.group;
-    uint32_t m = n, max_label = 0;                 // max_label: the largest tie-group label of the round (0 in the first: one group)
     // scratch carved from flags: head[m], still[m], head_scan[m+1], still_scan[m+1], tmp[m], group_next[m]
     uint32_t *head = b.flags;
     uint32_t *still = head + n;
     uint32_t *head_scan = still + n;
     uint32_t *still_scan = head_scan + n + 1;
     uint32_t *tmp = still_scan + n + 1;
-    uint32_t *group_next = tmp + n;
-    // four spare words behind the histograms: [0] runs longer than SMALL_RUN that stay tied after the round, [1] an error flag,
-    // [2], [3] where the one long run lies in the next working set (k_sort_finish_small)
+    uint32_t *group_next0 = tmp + n;
+    // spare words behind the histograms (SORT_SPARE_WORDS): [0] runs longer than SMALL_RUN that stay tied after the round, [1] an
+    // error flag, [2], [3] where the one long run lies in the next working set (k_sort_finish_small); [4..6] the classes' counts;
+    // from [8]: the sample, then the packed key's table
     uint32_t *d_big = b.hist + 2 * ((size_t)256 * sort_blocks(n) + 1);
-    HIPCHK(hipMemsetAsync(d_big, 0, 16, s));
-    uint32_t off = 0;                              // the working set is [off, off + m) of the active list (off > 0: one long run alone)
-    for (uint32_t depth = 0; m > 1; ++depth) {
-        ++rounds;
-        if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] depth %u: m = %u of n = %u\n", depth, m, n);
-        const uint32_t gb = (m + 255) / 256;
+    uint64_t *d_sample = reinterpret_cast<uint64_t *>(d_big + 8);
+    PackedBucket *d_table = reinterpret_cast<PackedBucket *>(d_sample + 4 * SORT_SAMPLE);
+
+    // One list of positions [off0, off0 + m0) of `order` sorted: rounds of 8 bytes per string (the first one packed when pk is given:
+    // the rounds behind it go on at byte 8 * depth_after), tie groups, the finishing kernels.  identity: order[i] = i still holds
+    // (a sort of all ids from the start).
+    auto sort_region = [&](uint32_t off0, uint32_t m0, bool identity, const PackedKeySpec *pk, uint32_t depth_after) -> int {
+        uint32_t *active = b.active_a, *active_alt = b.active_b;
+        uint32_t *group = b.group, *group_next = group_next0;      // tie-group labels per active index
+        uint32_t m = m0, off = off0, max_label = 0;   // max_label: the largest tie-group label of the round (0 in the first: one group)
+        bool packed = pk != nullptr, first = true;
+        const PackedKeySpec no_pack{};
+        HIPCHK(hipMemsetAsync(d_big, 0, 16, s));
+        // the working set is [off, off + m) of the active list (off > 0: the region's first round, or one long run alone)
+        for (uint32_t depth = 0; m > 1; ++depth) {
+            ++rounds;
+            if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] depth %u%s: m = %u of n = %u\n", depth, packed ? " (packed)" : "", m, n);
+            const uint32_t gb = (m + 255) / 256;
+            uint64_t *keys = b.key_a, *keys_alt = b.key_b;
+            uint32_t *vals = b.val_a, *vals_alt = b.val_b;
+            const uint32_t *order_in = (first && identity) ? nullptr : b.order;
+            hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active + off, m, depth, keys, vals, uniq_key,
+                               packed ? *pk : no_pack);
+            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, packed ? (pk->rest_bits + 9 + 7) & ~7u : 64u, b.hist, b.scan_tmp, s);
+            if (!first && max_label > 1) {
+                // stable, more significant key: the tie group of the element's old position (labels are < m + 1)
+                // (labels are 1 .. the number of runs that stayed in the working set: read back with the round's count)
+                uint32_t bits = 1;
+                while (bits < 32 && (1ull << bits) <= (uint64_t)max_label) ++bits;
+                radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group + off, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
+            }
+            hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active + off, vals, m, tmp, d_big);
+            hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active + off, group + off, tmp, (const uint64_t *)keys, m, still, d_big);
+            launch_scan_two_flags(still, still_scan, head_scan, m, b.scan_tmp, s);
+            uint32_t *run_start = reinterpret_cast<uint32_t *>(keys == b.key_a ? b.key_b : b.key_a);      // (the pairs' other buffer: free behind the radix passes)
+            hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active + off, still, head_scan, still_scan, m, active_alt,
+                               group_next, run_start);
+            uint32_t m_next = 0, nbig = 0;
+            HIPCHK(hipMemcpyAsync(&m_next, still_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(&max_label, head_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(&nbig, d_big, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            uint32_t *t = active; active = active_alt; active_alt = t;
+            t = group; group = group_next; group_next = t;
+            m = m_next;
+            off = 0;
+            if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort]   -> %u still tied in %u runs, %u of them longer than %u\n", m, max_label, nbig, SMALL_RUN);
+            if (m > 1 && nbig <= 1 && max_label > nbig && !test_hook("ZDW_SORT_NO_FINISH")) {
+                // Every run that is still tied is small, or all but one are: a wave each finishes the small ones.  What remains is nothing,
+                // or the one long run -- contiguous in the working set, so the next round takes it alone and needs no tie-group passes.
+                // (The benchmark's table after its first round: 1.7 M date-times that all begin "2024-01-" among 0.3 M pairs and triples.)
+                // (runs of a few strings: a thread per string; runs of dozens: a wave per run)
+                if (nbig || m / max_label < 8)
+                    hipLaunchKernelGGL(k_sort_finish_tiny, dim3((m + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order,
+                                       active, group, run_start, max_label, m, tmp, d_big + 1);
+                else
+                    hipLaunchKernelGGL(k_sort_finish_small, dim3((max_label + 3) / 4), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order,
+                                       active, run_start, max_label, m, tmp, d_big + 1);
+                hipLaunchKernelGGL(k_sort_place, dim3((m + 255) / 256), dim3(256), 0, s, b.order, active, tmp, m, nbig ? d_big + 2 : (const uint32_t *)nullptr);
+                uint32_t res[3] = {0, 0, 0};
+                HIPCHK(hipMemcpyAsync(res, d_big + 1, sizeof res, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (res[0]) return (int)hipErrorUnknown;
+                if (!nbig) break;
+                if (res[2] <= res[1] || res[2] > m) return (int)hipErrorUnknown;
+                off = res[1]; m = res[2] - res[1]; max_label = 1;
+            }
+            if (depth > max_len / 8 + 2) return (int)hipErrorUnknown;   // cannot happen: two distinct strings differ within max_len bytes
+            if (packed) { depth = depth_after - 1u; packed = false; }   // on behind the characters every first byte's packed key covered
+            first = false;
+        }
+        return 0;
+    };
+
+    // a packed first round?  (dictionaries of millions: the sample and its verdict cost ~0.1 ms)
+    PackPlan pl;
+    const bool force = test_hook("ZDW_SORT_PACK") != nullptr;
+    if (uniq_key && n > 1 && !test_hook("ZDW_SORT_NO_PACK") && (force || n >= (8u << 20))) {
+        const uint32_t S = std::min(n, SORT_SAMPLE);
+        std::vector<uint64_t> sample(4 * (size_t)S);
+        hipLaunchKernelGGL(k_sort_sample, dim3((S + 255) / 256), dim3(256), 0, s, uniq_key, uniq_len, n, S, d_sample);
+        HIPCHK(hipMemcpyAsync(sample.data(), d_sample, sample.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        plan_packed_round(sample.data(), S, force, pl);
+        if (experiment("ZDW_SORT_DEBUG"))
+            fprintf(stderr, "[sort] packed first round: %s (%u characters in %u + 9 bits, %.2f %% of the sample left out, the next round at byte %u)\n",
+                    pl.use ? "yes" : "no", pl.chars, pl.P, 100.0 * pl.exceptions, 8 * pl.depth_after);
+    }
+    if (!pl.use) {
+        const int e = sort_region(0, n, true, nullptr, 0);
+        if (e) return e;
+        if (rounds_out) *rounds_out = rounds;
+        return 0;
+    }
+    // holes | conforming strings | exceptions, each list by id
+    uint32_t *d_counts = d_big + 4;
+    uint32_t counts[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(d_table, pl.table.data(), 256 * sizeof(PackedBucket), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_counts, 0, 12, s));
+    {
         uint64_t *keys = b.key_a, *keys_alt = b.key_b;
         uint32_t *vals = b.val_a, *vals_alt = b.val_b;
-        const uint32_t *order_in = depth ? b.order : nullptr;      // identity in the first round
-        hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active + off, m, depth, keys, vals, uniq_key);
-        radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, 64, b.hist, b.scan_tmp, s);
-        if (depth > 0 && max_label > 1) {
-            // stable, more significant key: the tie group of the element's old position (labels are < m + 1)
-            // (labels are 1 .. the number of runs that stayed in the working set: read back with the round's count)
-            uint32_t bits = 1;
-            while (bits < 32 && (1ull << bits) <= (uint64_t)max_label) ++bits;
-            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group + off, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
+        hipLaunchKernelGGL(k_sort_classes, dim3(nb256), dim3(256), 0, s, uniq_key, uniq_len, n, d_table, keys, vals, d_counts);
+        radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, n, 0, 8, b.hist, b.scan_tmp, s);
+        HIPCHK(hipMemcpyAsync(b.order, vals, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(counts, d_counts, 12, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));                            // (also: pl.table has been read)
+    }
+    const uint32_t nh = counts[0], na = counts[1], nx = counts[2];
+    if ((uint64_t)nh + na + nx != n) return (int)hipErrorUnknown;   // (cannot happen)
+    if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] %u holes, %u conforming strings, %u exceptions\n", nh, na, nx);
+    const PackedKeySpec ps{d_table, pl.P};
+    int e = sort_region(nh, na, false, &ps, pl.depth_after);
+    if (e) return e;
+    if (nx) {
+        hipLaunchKernelGGL(k_sort_init_range, dim3((nx + 255) / 256), dim3(256), 0, s, b.active_a, b.group, nh + na, nx);
+        e = sort_region(nh + na, nx, false, nullptr, 0);
+        if (e) return e;
+        if (na) {
+            uint32_t *rank = still;
+            hipLaunchKernelGGL(k_merge_ranks, dim3((nx + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order + nh, na,
+                               b.order + nh + na, nx, rank);
+            hipLaunchKernelGGL(k_merge_place, dim3((na + nx + 255) / 256), dim3(256), 0, s, b.order + nh, na, b.order + nh + na, nx, rank, tmp);
+            HIPCHK(hipMemcpyAsync(b.order + nh, tmp, (size_t)(na + nx) * 4, hipMemcpyDeviceToDevice, s));
         }
-        hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active + off, vals, m, tmp, d_big);
-        hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active + off, group + off, tmp, (const uint64_t *)keys, m, still, d_big);
-        launch_scan_two_flags(still, still_scan, head_scan, m, b.scan_tmp, s);
-        uint32_t *run_start = reinterpret_cast<uint32_t *>(keys == b.key_a ? b.key_b : b.key_a);      // (the pairs' other buffer: free behind the radix passes)
-        hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active + off, still, head_scan, still_scan, m, active_alt,
-                           group_next, run_start);
-        uint32_t m_next = 0, nbig = 0;
-        HIPCHK(hipMemcpyAsync(&m_next, still_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(&max_label, head_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(&nbig, d_big, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        uint32_t *t = active; active = active_alt; active_alt = t;
-        t = group; group = group_next; group_next = t;
-        m = m_next;
-        off = 0;
-        if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort]   -> %u still tied in %u runs, %u of them longer than %u\n", m, max_label, nbig, SMALL_RUN);
-        if (m > 1 && nbig <= 1 && max_label > nbig && !test_hook("ZDW_SORT_NO_FINISH")) {
-            // Every run that is still tied is small, or all but one are: a wave each finishes the small ones.  What remains is nothing,
-            // or the one long run -- contiguous in the working set, so the next round takes it alone and needs no tie-group passes.
-            // (The benchmark's table after its first round: 1.7 M date-times that all begin "2024-01-" among 0.3 M pairs and triples.)
-            // (runs of a few strings: a thread per string; runs of dozens: a wave per run)
-            if (nbig || m / max_label < 8)
-                hipLaunchKernelGGL(k_sort_finish_tiny, dim3((m + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order,
-                                   active, group, run_start, max_label, m, tmp, d_big + 1);
-            else
-                hipLaunchKernelGGL(k_sort_finish_small, dim3((max_label + 3) / 4), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order,
-                                   active, run_start, max_label, m, tmp, d_big + 1);
-            hipLaunchKernelGGL(k_sort_place, dim3((m + 255) / 256), dim3(256), 0, s, b.order, active, tmp, m, nbig ? d_big + 2 : (const uint32_t *)nullptr);
-            uint32_t res[3] = {0, 0, 0};
-            HIPCHK(hipMemcpyAsync(res, d_big + 1, sizeof res, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-            if (res[0]) return (int)hipErrorUnknown;
-            if (!nbig) break;
-            if (res[2] <= res[1] || res[2] > m) return (int)hipErrorUnknown;
-            off = res[1]; m = res[2] - res[1]; max_label = 1;
-        }
-        if (depth > max_len / 8 + 2) return (int)hipErrorUnknown;   // cannot happen: two distinct strings differ within max_len bytes
     }
     if (rounds_out) *rounds_out = rounds;
     return 0;

@@ -587,7 +587,7 @@ int sort_buffers(zdw_ctx *c, uint64_t u, SortBuffers &b)
     HIP_TRY(c, c->order.ensure((u + 1) * 4)); HIP_TRY(c, c->group.ensure((u + 1) * 4));
     HIP_TRY(c, c->active_a.ensure((u + 1) * 4)); HIP_TRY(c, c->active_b.ensure((u + 1) * 4));
     HIP_TRY(c, c->flags.ensure((6 * u + 8) * 4));
-    HIP_TRY(c, c->hist.ensure((2 * (256 * nb + 1) + 8) * 4));
+    HIP_TRY(c, c->hist.ensure((2 * (256 * nb + 1) + SORT_SPARE_WORDS) * 4));      // (+ dict_sort's spare words)
     HIP_TRY(c, c->scan_tmp.ensure(scan_tmp_bytes(std::max<uint64_t>(256 * nb + 1, std::max<uint64_t>(u + 1, c->nrows + 1ull)))));
     b.key_a = c->key_a.as<uint64_t>(); b.key_b = c->key_b.as<uint64_t>();
     b.val_a = c->val_a.as<uint32_t>(); b.val_b = c->val_b.as<uint32_t>();

@@ -160,6 +160,7 @@ struct SortBuffers {   // all sized for n elements unless noted
     uint32_t *counter;     // small device scratch (>= 4 u32)
 };
 uint32_t sort_blocks(uint64_t n);
+constexpr uint32_t SORT_SPARE_WORDS = 8 + 4096 * 8 + 256 * 18;      // behind the histograms: dict_sort's flags and counts, its sample (4096 x 32 B), the packed key's table (256 x 72 B)
 // sorts unique strings into strcmp order; returns through `order`.  Host-driven loop (synchronises on s).
 int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const uint64_t *uniq_pos, const uint32_t *uniq_len, uint64_t n,
               SortBuffers &b, hipStream_t s, uint32_t *rounds_out, uint32_t max_len, const uint64_t *uniq_key = nullptr);
