@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--out", default="gpurun_out/c2.json")
     ap.add_argument("--no-ratios", action="store_true")
+    ap.add_argument("--pass1-only", action="store_true", help="time pass 1 alone, check nothing (ablations with the experiments build: ZDW_DEBUG_SKIP)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -104,6 +105,18 @@ def main():
     rows = rows1 * args.copies
     enc = capi.Encoder(types, device=0)
     enc.set_input_device(buf.data_ptr(), n, keepalive=buf)
+    if args.pass1_only:
+        ms = []
+        for step in range(args.steps + 1):
+            enc.set_input_device(buf.data_ptr(), n, keepalive=buf)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc, p1 = enc.pass1()
+            torch.cuda.synchronize()
+            if step:
+                ms.append(round((time.perf_counter() - t0) * 1e3, 3))
+        print(json.dumps({"pass1_only_ms": ms, "rc": rc, "rows": int(p1.num_rows), "dict_entries": int(p1.dict_entries)}))
+        return
     times, stages = [], None
     for step in range(args.steps + 1):
         if step == 1:

@@ -713,17 +713,28 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
     // (set and read by the lanes of wantm only: no zeroes moved into ten registers for the others)
     uint64_t c0, c1, c2, acc, slot_i;
     SlotLoad w0;
+    // The column's flag in LDS: 1 = a string has been seen, 3 = ... and the workgroup's last probe for this column found an empty slot
+    // (a column of mostly new strings: ids, time stamps).  Such a column's probes read at agent scope straight away
+    // (request_slot_scoped): one access to the table less per new string.
+    uint32_t col_flag = 0;
+    uint64_t agentm = 0;
     if (ftm) {
         const uint64_t wantm = ftm & BAL(len != 0u);                              // empty fields are skipped (:340-341)
         if (lane_in(wantm)) {
-            if (!zdw_lds[t.seen + col]) zdw_lds[t.seen + col] = 1;
+            col_flag = zdw_lds[t.seen + col];
+            if (!col_flag) zdw_lds[t.seen + col] = 1;
+        }
+#ifndef ZDW_P1_NO_SCOPE_HINT          // (A/B: tools/build_variant.sh)
+        agentm = wantm & BAL((col_flag & 2u) != 0u);
+#endif
+        if (lane_in(wantm)) {
             const uint32_t lo = L.lut + 32u * len;
             uint32_t fw[6];
             lds_bytes<6>(ra, fw);
             c0 = u64_of(fw[0], fw[1]) & lds_u64(lo); c1 = u64_of(fw[2], fw[3]) & lds_u64(lo + 8); c2 = u64_of(fw[4], fw[5]) & lds_u64(lo + 16);
             acc = nh24(c0, c1, c2);
             slot_i = hash_place(acc) & a.slot_mask;
-            if (!P1_ABLATE(a, 2u)) request_slot(a.slots + 4 * slot_i, w0);
+            if (!P1_ABLATE(a, 2u)) request_slot_scoped(a.slots + 4 * slot_i, w0, agentm);
         }
         if (!P1_ABLATE(a, 2u)) pendm = wantm;
     }
@@ -790,7 +801,8 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (probe == 0) {
                 w = await_slot(w0);                                               // (lanes that requested nothing hold nothing: every mask below lies within pendm)
                 // that was an ordinary load, possibly from this CU's L1: only a complete slot can be taken at its word (request_slot)
-                const uint64_t againm = pendm & (BAL(w.key == 0) | BAL(w.s0 == 0));
+                // (the lanes of agentm have read at agent scope already)
+                const uint64_t againm = pendm & ~agentm & (BAL(w.key == 0) | BAL(w.s0 == 0));
                 if (againm) { if (lane_in(againm)) w = load_slot(slot); }
             } else if (lane_in(pendm)) w = load_slot(slot);
             const uint64_t samem = pendm & BAL(w.s0 == c0) & BAL(w.s1 == c1) & BAL(w.s2 == c2) & BAL((((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len);
@@ -800,6 +812,10 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             }
             pendm &= ~samem;
             const uint64_t freem = pendm & BAL(w.key == 0);                       // an empty slot: the string is new (inserts are rare: one string in eighty of the benchmark's table)
+            if (probe == 0) {                                                     // the column's flag follows what its probes find
+                if (lane_in(samem & agentm)) zdw_lds[t.seen + col] = 1;
+                if (lane_in(freem & ~agentm)) zdw_lds[t.seen + col] = 3;
+            }
             if (freem) {
                 const uint32_t nid = alloc_ids(ws.ids, freem, COLD(st), ID_CHUNK);
                 uint32_t won = 0;                                                 // 1: the slot is ours, 2: another wave took it first

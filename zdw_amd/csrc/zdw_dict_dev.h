@@ -128,6 +128,31 @@ __device__ __forceinline__ void request_slot(const uint64_t *slot, SlotLoad &w)
                  "global_load_dwordx4 %1, %2, off offset:16"
                  : "=&v"(w.lo), "=&v"(w.hi) : "v"(slot) : "memory");
 }
+// The same request with the scope chosen per lane: the lanes of `agentm` (wave-uniform mask) read at agent scope -- what comes back
+// is the slot as it is, an empty one included, and needs no second look -- the others as above.  For columns whose strings are mostly
+// new (pass 1 keeps a flag per column): their probes find an empty slot, and an ordinary read of an empty slot only buys the second
+// read.  Every lane's registers are written by exactly one of the two pairs of loads.
+__device__ __forceinline__ void request_slot_scoped(const uint64_t *slot, SlotLoad &w, uint64_t agentm)
+{
+    uint64_t all;
+    // (no lane of agentm -- tables whose strings repeat: the two ordinary loads and nothing else)
+    asm volatile("s_cmp_eq_u64 %4, 0\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 "s_mov_b64 %2, exec\n\t"
+                 "s_andn2_b64 exec, %2, %4\n\t"
+                 "global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "s_and_b64 exec, %2, %4\n\t"
+                 "global_load_dwordx4 %0, %3, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+                 "s_mov_b64 exec, %2\n\t"
+                 "s_branch 2f\n"
+                 "1:\n\t"
+                 "global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n"
+                 "2:"
+                 : "=&v"(w.lo), "=&v"(w.hi), "=&s"(all) : "v"(slot), "s"(agentm) : "memory", "scc");
+}
 __device__ __forceinline__ SlotWords await_slot(SlotLoad &l)
 {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(l.lo), "+v"(l.hi) : : "memory");
