@@ -698,7 +698,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                         if (lane_in(freem)) {
                             if (nid >= RW_COLD(id_cap)) { stp->overflow = 1; }
                             else {
-                                const uint64_t old = claim_slot<false, false>(slot, make_slot_key(P.tag, P.len, nid), nid, gbase + P.fs, P.len, RW_COLD(uniq_pos), RW_COLD(uniq_len), P.c0, P.c1, P.c2, TRACK, RW_COLD(uniq_key));
+                                const uint64_t old = claim_slot<false, false, false>(slot, make_slot_key(P.tag, P.len, nid), nid, gbase + P.fs, P.len, RW_COLD(uniq_pos), RW_COLD(uniq_len), P.c0, P.c1, P.c2, TRACK, RW_COLD(uniq_key));
                                 if (old == 0) { won = 1u; t_id = nid + 1; } else won = 2u;
                             }
                         }

@@ -212,7 +212,9 @@ __device__ __forceinline__ void retire_ids(const IdAlloc &al, uint32_t *uniq_len
 // LATE: the claimer does not wait for its copy's words 2-3 and publish word 1 here; it calls publish_slot() later (pass 1's register
 // form does, behind the batch's other memory operations: the wait then costs little, and until then the slot reads as "claimed, not
 // complete", which sends anybody else who wants it to the general form).
-template <bool FACTS_AT_AGENT_SCOPE, bool LATE = false>
+// WIDE: the copy's words 2-3 go out as one 16-byte store (four consecutive registers: the lane-per-row kernel, which keeps its own
+// loads in flight in registers the allocator must leave alone, has none to spare and stores them one by one).
+template <bool FACTS_AT_AGENT_SCOPE, bool LATE = false, bool WIDE = true>
 __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uint32_t id, uint64_t pos, uint32_t len, uint64_t *uniq_pos,
                                                uint32_t *uniq_len, uint64_t c0, uint64_t c1, uint64_t c2, bool track_first = false,
                                                uint64_t *uniq_key = nullptr)
@@ -234,8 +236,21 @@ __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uin
     }
     const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), 0ull, (unsigned long long)key);
     if (old == 0) {
-        if (c2) __hip_atomic_store(slot + 3, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c1) __hip_atomic_store(slot + 2, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ZDW_CLAIM_TWO_STORES          // (A/B: tools/build_variant.sh)
+        constexpr bool wide = false;
+#else
+        constexpr bool wide = WIDE;
+#endif
+        if (!wide) {
+            if (c2) __hip_atomic_store(slot + 3, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c1) __hip_atomic_store(slot + 2, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (c1) {
+            // words 2-3 in one 16-byte store at agent scope (sc1, as the compiler emits for the stores above): one access to the
+            // table instead of two for a string of 17 to 24 bytes
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = {(uint32_t)c1, (uint32_t)(c1 >> 32), (uint32_t)c2, (uint32_t)(c2 >> 32)};
+            asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1" : : "v"(slot), "v"(v) : "memory");
+        }
         if (!LATE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(slot + 1, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
