@@ -802,7 +802,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 w = await_slot(w0);                                               // (lanes that requested nothing hold nothing: every mask below lies within pendm)
                 // that was an ordinary load, possibly from this CU's L1: only a complete slot can be taken at its word (request_slot)
                 // (the lanes of agentm have read at agent scope already)
-                const uint64_t againm = pendm & ~agentm & (BAL(w.key == 0) | BAL(w.s0 == 0));
+                const uint64_t againm = pendm & ~agentm & (BAL(w.key == 0) | BAL(slot_incomplete(w)));
                 if (againm) { if (lane_in(againm)) w = load_slot(slot); }
             } else if (lane_in(pendm)) w = load_slot(slot);
             const uint64_t samem = pendm & BAL(w.s0 == c0) & BAL(w.s1 == c1) & BAL(w.s2 == c2) & BAL((((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) == len);
@@ -822,7 +822,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 if (lane_in(freem)) {
                     if (nid >= COLD(id_cap)) { COLD(st)->overflow = 1; }
                     else {
-                        const uint64_t old = claim_slot<false, true>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start_of(), len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK, COLD(uniq_key));
+                        const uint64_t old = claim_slot<false>(slot, make_slot_key(hash_tag(acc), len, nid), nid, abs_start_of(), len, COLD(uniq_pos), COLD(uniq_len), c0, c1, c2, TRACK, COLD(uniq_key));
                         if (old == 0) { won = 1u; t_id = nid + 1; } else won = 2u;
                     }
                 }
@@ -830,7 +830,7 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
                 slowm |= BAL(won == 2u);                                          // lost the race: general form
                 pendm &= ~freem;
             }
-            const uint64_t halfm = pendm & BAL(w.s0 == 0);                        // claimed, inline copy not complete yet: general form
+            const uint64_t halfm = pendm & BAL(slot_incomplete(w));               // claimed, inline copy not complete yet: general form
             slowm |= halfm; pendm &= ~halfm;
             if (lane_in(pendm)) slot_i = (slot_i + 1) & a.slot_mask;              // somebody else's: the next slot
         }
@@ -857,10 +857,6 @@ __device__ __forceinline__ uint32_t consume(const Pass1Args &a, const ColTables 
             if (SKIP && a.nz && n_rec) atomicOr(a.nz + (uint64_t)row * a.nz_stride + (col >> 5), 1u << (col & 31u));
         }
     }
-
-    // the strings this batch put into the table: their slots' word 1 now, behind the batch's stores (claim_slot<.., LATE>) -- and
-    // before the general form below, which may wait for exactly such a slot
-    if (newm) publish_slot(a.slots + 4 * slot_i, c0, lane_in(newm));
 
     // ---- everything else: the general form, from global memory ----
     const uint64_t sm = slowm;

@@ -668,8 +668,8 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                 // (a refill requested before this slot has arrived with it -- loads return in order: it costs no wait of its own)
                 if (pendm && (int32_t)(U.mark - pend_mark) > 0) land(true);
                 SlotWords sw;
-                sw.key = ((uint64_t)s_lo.y << 32) | s_lo.x; sw.s0 = ((uint64_t)s_lo.w << 32) | s_lo.z;
-                sw.s1 = ((uint64_t)s_hi.y << 32) | s_hi.x; sw.s2 = ((uint64_t)s_hi.w << 32) | s_hi.z;
+                sw.key = ((uint64_t)s_lo.y << 32) | s_lo.x; sw.s2 = ((uint64_t)s_lo.w << 32) | s_lo.z;
+                sw.s0 = ((uint64_t)s_hi.y << 32) | s_hi.x; sw.s1 = ((uint64_t)s_hi.w << 32) | s_hi.z;
                 uint64_t pm = U.wantm, slowm = 0, newm = 0;
                 uint32_t t_id = 0;
                 uint64_t *const slots = a.slots;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                         // (nobody inserts while this kernel runs: what the ordinary load showed is what the table holds)
                     } else if (probe == 0) {
                         // that was an ordinary load, possibly from this CU's L1: only a complete slot can be taken at its word (zdw_dict_dev.h, request_slot)
-                        const uint64_t againm = pm & (BAL(sw.key == 0) | BAL(sw.s0 == 0));
+                        const uint64_t againm = pm & (BAL(sw.key == 0) | BAL(slot_incomplete(sw)));
                         if (againm) { if (lane_in(againm)) sw = load_slot(slot); }
                     } else if (lane_in(pm)) sw = load_slot(slot);
                     const uint64_t samem = pm & BAL(sw.s0 == P.c0) & BAL(sw.s1 == P.c1) & BAL(sw.s2 == P.c2) & BAL((((uint32_t)(sw.key >> KEY_LEN_SHIFT)) & 0xffu) == P.len);
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                         if (lane_in(freem)) {
                             if (nid >= RW_COLD(id_cap)) { stp->overflow = 1; }
                             else {
-                                const uint64_t old = claim_slot<false, false, false>(slot, make_slot_key(P.tag, P.len, nid), nid, gbase + P.fs, P.len, RW_COLD(uniq_pos), RW_COLD(uniq_len), P.c0, P.c1, P.c2, TRACK, RW_COLD(uniq_key));
+                                const uint64_t old = claim_slot<false, false>(slot, make_slot_key(P.tag, P.len, nid), nid, gbase + P.fs, P.len, RW_COLD(uniq_pos), RW_COLD(uniq_len), P.c0, P.c1, P.c2, TRACK, RW_COLD(uniq_key));
                                 if (old == 0) { won = 1u; t_id = nid + 1; } else won = 2u;
                             }
                         }
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
                         slowm |= BAL(won == 2u);                        // lost the race: general form
                         pm &= ~freem;
                     }
-                    const uint64_t halfm = pm & BAL(sw.s0 == 0);         // claimed, inline copy not complete yet: general form
+                    const uint64_t halfm = pm & BAL(slot_incomplete(sw));  // claimed, inline copy not complete yet: general form
                     slowm |= halfm; pm &= ~halfm;
                     if (lane_in(pm)) P.slot = (P.slot + 1) & a.slot_mask;
                 }

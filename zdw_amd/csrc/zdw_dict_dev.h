@@ -93,10 +93,17 @@ __device__ inline uint64_t nh_string(const uint8_t *p, uint32_t len, const uint8
     return acc;
 }
 
+// A slot's 32 bytes: word 0 the key (tag, length byte, id + 1: claimed by compare-and-swap), word 1 the string's bytes 16..23 (s2),
+// words 2-3 its bytes 0..15 (s0, s1: one 16-byte store).  Every word is written once.  The slot is COMPLETE when s0 is set and --
+// for a string of more than 16 bytes, which the key's length byte tells -- s2 as well: the two stores need no order between them.
 struct SlotWords { uint64_t key, s0, s1, s2; };
+__device__ __forceinline__ bool slot_incomplete(const SlotWords &w)
+{
+    return w.s0 == 0 || ((((uint32_t)(w.key >> KEY_LEN_SHIFT)) & 0xffu) > 16u && w.s2 == 0);
+}
 
 // one asm block: the two loads issue in program order and return in order; sc1 = served at agent scope
-// (coherent across CUs), so a set word 1 implies words 2-3 stored before it are seen as well
+// (coherent across CUs): the slot as it is
 __device__ __forceinline__ SlotWords load_slot(const uint64_t *slot)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -106,8 +113,8 @@ __device__ __forceinline__ SlotWords load_slot(const uint64_t *slot)
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(lo), "=&v"(hi) : "v"(slot) : "memory");
     SlotWords w;
-    w.key = ((uint64_t)lo.y << 32) | lo.x; w.s0 = ((uint64_t)lo.w << 32) | lo.z;
-    w.s1 = ((uint64_t)hi.y << 32) | hi.x; w.s2 = ((uint64_t)hi.w << 32) | hi.z;
+    w.key = ((uint64_t)lo.y << 32) | lo.x; w.s2 = ((uint64_t)lo.w << 32) | lo.z;
+    w.s0 = ((uint64_t)hi.y << 32) | hi.x; w.s1 = ((uint64_t)hi.w << 32) | hi.z;
     return w;
 }
 
@@ -117,10 +124,9 @@ __device__ __forceinline__ SlotWords load_slot(const uint64_t *slot)
 struct SlotLoad { uint32_t lo __attribute__((ext_vector_type(4))); uint32_t hi __attribute__((ext_vector_type(4))); };
 // These loads are ORDINARY ones (no sc1): they may be served from the CU's own vector L1, which other CUs' stores never refresh.
 // A slot only ever goes empty -> claimed -> complete and then never changes (the table is cleared by another kernel, and a kernel
-// starts with its L1 invalid), and a slot's 32 bytes lie in one cache line whose content at any time is a prefix of the claimer's
-// stores (words 3, 2, then -- drained -- word 1).  So a read that shows a COMPLETE slot (key and word 1 set) is right however old
-// it is; anything else (empty, or claimed and not complete) says nothing and is read again at agent scope (load_slot) before it is
-// acted on.  Measured (tools/probe_rate.hip): random 32-byte probes of an L2-resident table 252 G/s plain vs 130 G/s sc1, of an
+// starts with its L1 invalid), and every word of a slot is written once.  So a read that shows a COMPLETE slot (slot_incomplete)
+// is right however old it is; anything else (empty, or claimed and not complete) says nothing and is read again at agent scope
+// (load_slot) before it is acted on.  Measured (tools/probe_rate.hip): random 32-byte probes of an L2-resident table 252 G/s plain vs 130 G/s sc1, of an
 // L1-resident one 440-540 vs 140-200, of a 1 GiB one 54 vs 46.
 __device__ __forceinline__ void request_slot(const uint64_t *slot, SlotLoad &w)
 {
@@ -157,8 +163,8 @@ __device__ __forceinline__ SlotWords await_slot(SlotLoad &l)
 {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(l.lo), "+v"(l.hi) : : "memory");
     SlotWords w;
-    w.key = ((uint64_t)l.lo.y << 32) | l.lo.x; w.s0 = ((uint64_t)l.lo.w << 32) | l.lo.z;
-    w.s1 = ((uint64_t)l.hi.y << 32) | l.hi.x; w.s2 = ((uint64_t)l.hi.w << 32) | l.hi.z;
+    w.key = ((uint64_t)l.lo.y << 32) | l.lo.x; w.s2 = ((uint64_t)l.lo.w << 32) | l.lo.z;
+    w.s0 = ((uint64_t)l.hi.y << 32) | l.hi.x; w.s1 = ((uint64_t)l.hi.w << 32) | l.hi.z;
     return w;
 }
 
@@ -206,15 +212,15 @@ __device__ __forceinline__ void retire_ids(const IdAlloc &al, uint32_t *uniq_len
         if (id < id_cap) uniq_len[id] = 0;
 }
 
-// claim an empty slot for unique `id`: the unique's facts (in flight while the CAS travels: their lines
-// are cold), the CAS, the inline copy, then (all of those drained) word 1; returns the previous key word
-// (0 = claimed).  A lost race leaves the id a hole.
-// LATE: the claimer does not wait for its copy's words 2-3 and publish word 1 here; it calls publish_slot() later (pass 1's register
-// form does, behind the batch's other memory operations: the wait then costs little, and until then the slot reads as "claimed, not
-// complete", which sends anybody else who wants it to the general form).
-// WIDE: the copy's words 2-3 go out as one 16-byte store (four consecutive registers: the lane-per-row kernel, which keeps its own
-// loads in flight in registers the allocator must leave alone, has none to spare and stores them one by one).
-template <bool FACTS_AT_AGENT_SCOPE, bool LATE = false, bool WIDE = true>
+// claim an empty slot for unique `id`: the unique's facts (in flight while the CAS travels: their lines are cold), the CAS, then the
+// inline copy -- bytes 16..23 (if any) and bytes 0..15, in that order but without a wait between them (slot_incomplete looks at
+// both).  Returns the previous key word (0 = claimed).  A lost race leaves the id a hole.
+// FACTS_AT_AGENT_SCOPE (the general form: strings of more than 24 bytes are compared against their first occurrence while the pass
+// runs, through uniq_pos / uniq_len): the facts must be seen by whoever sees the slot complete, so the wave waits for them (and for
+// bytes 16..23) before the store that completes it.
+// WIDE: bytes 0..15 go out as one 16-byte store.  Four consecutive registers: the lane-per-row kernel, which keeps its own loads in
+// flight in registers the allocator must leave alone, has none to spare -- it stores bytes 8..15, waits, and completes with bytes 0..7.
+template <bool FACTS_AT_AGENT_SCOPE, bool WIDE = true>
 __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uint32_t id, uint64_t pos, uint32_t len, uint64_t *uniq_pos,
                                                uint32_t *uniq_len, uint64_t c0, uint64_t c1, uint64_t c2, bool track_first = false,
                                                uint64_t *uniq_key = nullptr)
@@ -236,24 +242,17 @@ __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uin
     }
     const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), 0ull, (unsigned long long)key);
     if (old == 0) {
-#ifdef ZDW_CLAIM_TWO_STORES          // (A/B: tools/build_variant.sh)
-        constexpr bool wide = false;
-#else
-        constexpr bool wide = WIDE;
-#endif
-        if (!wide) {
-            if (c2) __hip_atomic_store(slot + 3, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c1) __hip_atomic_store(slot + 2, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (c1) {
-            // words 2-3 in one 16-byte store at agent scope (sc1, as the compiler emits for the stores above): one access to the
-            // table instead of two for a string of 17 to 24 bytes
+        if (c2) __hip_atomic_store(slot + 1, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (WIDE) {
+            if (FACTS_AT_AGENT_SCOPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (sc1: agent scope, as the compiler emits for the store above)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = {(uint32_t)c1, (uint32_t)(c1 >> 32), (uint32_t)c2, (uint32_t)(c2 >> 32)};
+            const u32x4 v = {(uint32_t)c0, (uint32_t)(c0 >> 32), (uint32_t)c1, (uint32_t)(c1 >> 32)};
             asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1" : : "v"(slot), "v"(v) : "memory");
-        }
-        if (!LATE) {
+        } else {
+            if (c1) __hip_atomic_store(slot + 3, c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(slot + 1, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 2, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else if (FACTS_AT_AGENT_SCOPE) {
         __hip_atomic_store(uniq_len + id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -261,13 +260,6 @@ __device__ __forceinline__ uint64_t claim_slot(uint64_t *slot, uint64_t key, uin
         uniq_len[id] = 0u;
     }
     return old;
-}
-
-// the second half of a LATE claim: every lane of the wave calls it (the wait is the wave's), the claimers with `mine`
-__device__ __forceinline__ void publish_slot(uint64_t *slot, uint64_t c0, bool mine)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // words 2-3 (and everything else the wave has in flight) have landed
-    if (mine) __hip_atomic_store(slot + 1, c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Does the stored occurrence at image position `pos` (same first `len` bytes as the candidate) END
@@ -362,10 +354,10 @@ __device__ inline uint32_t dict_insert(const uint8_t *p, const uint8_t *end, con
             w.key = old; w.s0 = 0;                        // somebody else just claimed it
         }
         if (((uint32_t)(w.key >> KEY_TAG_SHIFT) & 0xffffu) == tag && ((uint32_t)(w.key >> KEY_LEN_SHIFT) & 0xffu) == len8) {
-            // a candidate whose claimer has not finished publishing: wait for word 1 (the claimer waits for
+            // a candidate whose claimer has not finished its copy: wait for it (the claimer waits for
             // nobody, and a claimer in this very wave has finished before its rivals get here)
-            for (uint32_t spin = 0; w.s0 == 0 && spin < (1u << 22); ++spin) w = load_slot(slot);
-            if (w.s0 == 0) { d.st->overflow = 1; searching = false; continue; }      // cannot happen; never hang on it
+            for (uint32_t spin = 0; slot_incomplete(w) && spin < (1u << 22); ++spin) w = load_slot(slot);
+            if (slot_incomplete(w)) { d.st->overflow = 1; searching = false; continue; }      // cannot happen; never hang on it
             const uint32_t from = 24;                     // bytes [0, 24) are decided by the inline copy
             if (w.s0 == c0 && w.s1 == c1 && w.s2 == c2) {
                 if (from >= len) {                                                             // len <= 24, equal length bytes: the slot decides
