@@ -131,6 +131,82 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict
     }
 }
 
+// The same pass with the chunk put in order in LDS first (keys as digits: no DSRC).  Where a chunk's 2048 elements spread over all 256
+// digits, the kernel above writes every element on its own -- 8 + 4 bytes into a 32-byte sector of its own: 1.0-1.3 ms per pass over
+// 67 M pairs against 0.33 ms where a chunk holds one or two digits.  Here an element first goes to its place within the chunk (the
+// chunk's own count of every digit is the difference of two neighbours of the scanned histogram), then the chunk is written out in
+// that order: the ~8 elements of a digit lie side by side in LDS and go to consecutive addresses.  Stable like the other (an
+// element's place among its digit's is its rank in chunk order).
+__global__ __launch_bounds__(64) void k_radix_scatter_local(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                            uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
+                                                            const uint32_t *__restrict__ rows, const uint32_t *__restrict__ row_tot, uint32_t nblocks)
+{
+    __shared__ uint64_t lkey[SORT_CHUNK];
+    __shared__ uint32_t lval[SORT_CHUNK];
+    __shared__ uint32_t lofs[256];            // where the digit's next element goes within the chunk
+    __shared__ uint32_t gofs[256];            // the digit's first global place minus its first place within the chunk
+    const uint32_t lane = threadIdx.x;
+    {
+        const bool last = blockIdx.x + 1 == nblocks;
+        uint32_t t[4], r[4], c[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t d = 4 * lane + k;
+            t[k] = row_tot[d];
+            r[k] = rows[d * nblocks + blockIdx.x];
+            c[k] = (last ? t[k] : rows[d * nblocks + blockIdx.x + 1]) - r[k];      // this chunk's elements of digit d
+        }
+        uint32_t tot, ctot;
+        uint32_t before = wave_excl_sum(t[0] + t[1] + t[2] + t[3], lane, tot);      // elements of smaller digits, all chunks
+        uint32_t cbefore = wave_excl_sum(c[0] + c[1] + c[2] + c[3], lane, ctot);    // ... of this chunk
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            lofs[4 * lane + k] = cbefore;
+            gofs[4 * lane + k] = before + r[k] - cbefore;
+            before += t[k]; cbefore += c[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();          // (one wave per block: its LDS operations execute in order)
+    const uint32_t beg = blockIdx.x * SORT_CHUNK;
+    const uint32_t end = beg + SORT_CHUNK < n ? beg + SORT_CHUNK : n;
+    for (uint32_t hb = beg; hb < end; hb += 64 * SORT_STEPS) {
+        uint64_t key[SORT_STEPS];
+        uint32_t val[SORT_STEPS];
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_STEPS; ++k) {
+            const uint32_t i = hb + 64 * k + lane;
+            key[k] = i < end ? keys_in[i] : 0ull;
+            val[k] = i < end ? vals_in[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_STEPS; ++k) {
+            const bool valid = hb + 64 * k + lane < end;
+            const uint32_t digit = (uint32_t)(key[k] >> shift) & 255u;
+            uint64_t mm = __ballot(valid);                 // lanes holding the same digit as this lane
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (digit >> bit) & 1u;
+                const uint64_t vote = __ballot(one);
+                mm &= one ? vote : ~vote;
+            }
+            uint32_t at = 0;
+            if (valid) at = lofs[digit] + popc64(mm & mask_lt((int)lane));
+            __builtin_amdgcn_wave_barrier();
+            if (valid && lane == (uint32_t)highest_bit(mm)) lofs[digit] += popc64(mm);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) { lkey[at] = key[k]; lval[at] = val[k]; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t cnt = end - beg;
+#pragma unroll 8
+    for (uint32_t p = lane; p < cnt; p += 64) {
+        const uint64_t k = lkey[p];
+        const uint32_t dst = gofs[(uint32_t)(k >> shift) & 255u] + p;
+        keys_out[dst] = k; vals_out[dst] = lval[p];
+    }
+}
+
 // one block per digit: exclusive scan, in place, of the digit's per-block counts; the digit's total goes to row_tot.
 // A thread owns up to 16 consecutive counts, all requested before any is used (one latency per 4096 counts).
 __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t *__restrict__ hist, uint32_t nblocks, uint32_t *__restrict__ row_tot)
@@ -167,12 +243,18 @@ static void radix_sort_pairs(uint64_t **keys, uint32_t **vals, uint64_t **keys_a
                              uint32_t bit_lo, uint32_t bit_hi, uint32_t *hist, void *scan_tmp, hipStream_t s)
 {
     const uint32_t nb = sort_blocks(n);
+    // (ZDW_SORT_SCATTER: 0 = every element straight to its place, 1 = chunks put in order in LDS first; tests run both)
+    // (measured: 67 M pairs, a packed round's six passes 12.3 -> 10.0 ms; C5's 36 M ids per block 7.4 -> 6.2 ms; the benchmark's 5.6 M
+    // strings 2.14 -> 2.36 ms -- too few chunks to keep the chip busy at six waves per CU)
+    bool local = n >= (1u << 24);
+    if (const char *e = test_hook("ZDW_SORT_SCATTER")) local = atoi(e) != 0;
     for (uint32_t shift = bit_lo; shift < bit_hi; shift += 8) {
         if (dsrc) hipLaunchKernelGGL(k_radix_hist<true>, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, n, shift, hist, nb);
         else hipLaunchKernelGGL(k_radix_hist<false>, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, n, shift, hist, nb);
         uint32_t *row_tot = hist + (size_t)256 * nb;
         hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, hist, nb, row_tot);
         if (dsrc) hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, *keys_alt, *vals_alt, n, shift, hist, row_tot, nb);
+        else if (local) hipLaunchKernelGGL(k_radix_scatter_local, dim3(nb), dim3(64), 0, s, *keys, *vals, *keys_alt, *vals_alt, n, shift, hist, row_tot, nb);
         else hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nb), dim3(64), 0, s, *keys, *vals, dsrc, *keys_alt, *vals_alt, n, shift, hist, row_tot, nb);
         uint64_t *tk = *keys; *keys = *keys_alt; *keys_alt = tk;
         uint32_t *tv = *vals; *vals = *vals_alt; *vals_alt = tv;
@@ -234,7 +316,8 @@ __device__ __forceinline__ bool conforms(uint64_t k0, uint64_t k1, uint64_t k2, 
     return pb.nchars && (k0 & pb.himask[0]) == pb.hival[0] && (k1 & pb.himask[1]) == pb.hival[1] && (k2 & pb.himask[2]) == pb.hival[2];
 }
 
-// keys[u] = 0 hole, 1 conforming, 2 exception; vals[u] = u; counts[c] += the strings of class c
+// keys[u] = 0 hole, 1 conforming, 2 exception; vals[u] = u; counts[c] += the strings of class c (a workgroup walks its share of the
+// ids and adds what it counted once: three atomics per 256 ids on three words took 3 ms at 67 M ids)
 __global__ __launch_bounds__(256) void k_sort_classes(const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ uniq_len, uint32_t n,
                                                       const PackedBucket *__restrict__ table, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                       uint32_t *__restrict__ counts)
@@ -242,21 +325,32 @@ __global__ __launch_bounds__(256) void k_sort_classes(const uint64_t *__restrict
     __shared__ uint32_t sc[3];
     if (threadIdx.x < 3) sc[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t cls = 3;
-    if (u < n) {
-        cls = 0;
-        if (uniq_len[u]) {
-            const uint64_t k0 = uniq_key[3ull * u], k1 = uniq_key[3ull * u + 1], k2 = uniq_key[3ull * u + 2];
-            cls = conforms(k0, k1, k2, table[(uint32_t)k0 & 255u]) ? 1u : 2u;
+    uint32_t mine0 = 0, mine1 = 0, mine2 = 0;
+    const uint64_t per_block = (((uint64_t)n + gridDim.x - 1) / gridDim.x + 255) & ~255ull;
+    const uint64_t beg = per_block * blockIdx.x, end = beg + per_block < n ? beg + per_block : n;
+    for (uint64_t base = beg; base < end; base += 256) {
+        const uint64_t u = base + threadIdx.x;
+        const bool real = u < end && uniq_len[u] != 0;
+        uint64_t k0 = 0, k1 = 0, k2 = 0;
+        if (real) { k0 = uniq_key[3 * u]; k1 = uniq_key[3 * u + 1]; k2 = uniq_key[3 * u + 2]; }
+        uint32_t cls = 0;
+        const uint64_t rm = __ballot(real);
+        if (rm) {
+            // one first byte in the whole wave (a column of date-times): its entry of the table through scalar loads, once, instead of
+            // nine gathers of 64 addresses
+            const uint32_t b = (uint32_t)k0 & 255u;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lane_value(b, lowest_bit(rm)));
+            if (__ballot(real && b != b0) == 0) {
+                const PackedBucket pb = table[b0];
+                if (real) cls = conforms(k0, k1, k2, pb) ? 1u : 2u;
+            } else if (real) {
+                cls = conforms(k0, k1, k2, table[b]) ? 1u : 2u;
+            }
         }
-        keys[u] = cls; vals[u] = u;
+        if (u < end) { keys[u] = cls; vals[u] = (uint32_t)u; mine0 += cls == 0u; mine1 += cls == 1u; mine2 += cls == 2u; }
     }
-#pragma unroll
-    for (uint32_t c = 0; c < 3; ++c) {
-        const uint32_t k = popc64(__ballot(cls == c));
-        if (k && lane_id() == 0) atomicAdd(&sc[c], k);
-    }
+    const uint32_t t0 = wave_incl_sum(mine0), t1 = wave_incl_sum(mine1), t2 = wave_incl_sum(mine2);
+    if (lane_id() == 63) { if (t0) atomicAdd(&sc[0], t0); if (t1) atomicAdd(&sc[1], t1); if (t2) atomicAdd(&sc[2], t2); }
     __syncthreads();
     if (threadIdx.x < 3 && sc[threadIdx.x]) atomicAdd(counts + threadIdx.x, sc[threadIdx.x]);
 }
@@ -530,6 +624,26 @@ __global__ __launch_bounds__(256) void k_merge_place(const uint32_t *__restrict_
     }
     out[i + lo] = A[i];
 }
+// A list of up to SORT_TINY strings (the exceptions beside a packed round; a dictionary of a few hundred strings): one workgroup,
+// every string compared with every other as whole strings, its rank is where it goes -- one launch instead of the ~30 a round of
+// radix passes takes whatever its size.  list[0 .. m) -> out[0 .. m) sorted (out may not alias list).
+constexpr uint32_t SORT_TINY = 1024;
+__global__ __launch_bounds__(256) void k_sort_tiny(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
+                                                   const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
+                                                   const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ list, uint32_t m,
+                                                   uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t ids[SORT_TINY];
+    for (uint32_t i = threadIdx.x; i < m; i += 256) ids[i] = list[i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += 256) {
+        const uint32_t u = ids[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; ++j)
+            if (j != i && string_less(in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, ids[j], u)) ++rank;
+        out[rank] = u;
+    }
+}
 __global__ __launch_bounds__(256) void k_sort_init_range(uint32_t *active, uint32_t *group, uint32_t off, uint32_t m)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -729,7 +843,7 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     {
         uint64_t *keys = b.key_a, *keys_alt = b.key_b;
         uint32_t *vals = b.val_a, *vals_alt = b.val_b;
-        hipLaunchKernelGGL(k_sort_classes, dim3(nb256), dim3(256), 0, s, uniq_key, uniq_len, n, d_table, keys, vals, d_counts);
+        hipLaunchKernelGGL(k_sort_classes, dim3(std::min<uint32_t>(nb256, 4096u)), dim3(256), 0, s, uniq_key, uniq_len, n, d_table, keys, vals, d_counts);
         radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, n, 0, 8, b.hist, b.scan_tmp, s);
         HIPCHK(hipMemcpyAsync(b.order, vals, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(counts, d_counts, 12, hipMemcpyDeviceToHost, s));
@@ -742,9 +856,15 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     int e = sort_region(nh, na, false, &ps, pl.depth_after);
     if (e) return e;
     if (nx) {
-        hipLaunchKernelGGL(k_sort_init_range, dim3((nx + 255) / 256), dim3(256), 0, s, b.active_a, b.group, nh + na, nx);
-        e = sort_region(nh + na, nx, false, nullptr, 0);
-        if (e) return e;
+        if (nx > 1 && nx <= SORT_TINY && uniq_key) {
+            hipLaunchKernelGGL(k_sort_tiny, dim3(1), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order + nh + na, nx, tmp);
+            HIPCHK(hipMemcpyAsync(b.order + nh + na, tmp, (size_t)nx * 4, hipMemcpyDeviceToDevice, s));
+            ++rounds;
+        } else {
+            hipLaunchKernelGGL(k_sort_init_range, dim3((nx + 255) / 256), dim3(256), 0, s, b.active_a, b.group, nh + na, nx);
+            e = sort_region(nh + na, nx, false, nullptr, 0);
+            if (e) return e;
+        }
         if (na) {
             uint32_t *rank = still;
             hipLaunchKernelGGL(k_merge_ranks, dim3((nx + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order + nh, na,
