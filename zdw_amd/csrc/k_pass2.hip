@@ -723,7 +723,10 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
             const EmitFn fn = fns[R == 16 ? 1 : (R == 4 ? 2 : 0)][mode];
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)fn, 256, lds) != hipSuccess || occ < 1) occ = 1;
             // measured (10 GB x 200 columns): staged 8-row chunks 5 / 6 / 7 / 8 workgroups per CU = 5.5 / 4.9 / 4.5 / 6.7 ms
-            uint32_t per_cu = std::min(mode ? 7u : 6u, (uint32_t)occ);
+            // (rows read straight from HBM -- 1000 columns, 8 GB with ids in every 20th: 2 / 3 / 4 / 5 / 6 / 7 / 8 / 10 / 12 / 16 workgroups
+            // per CU = 8.0 / 5.7 / 4.5 / 6.7 / 5.8 / 5.1 / 4.6 / 5.4 / 4.6 / 4.6 ms, five of them resident: multiples of four, whatever
+            // is resident -- tools/ab_c5_pass2.sh; it was min(6, resident) = 5)
+            uint32_t per_cu = mode ? std::min(7u, (uint32_t)occ) : ((uint32_t)occ >= 4u ? 4u : (uint32_t)occ);
             if (const char *e = experiment("ZDW_P2_WGS")) per_cu = std::max(1u, (uint32_t)atoi(e));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)cus * per_cu);
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a);
