@@ -1244,7 +1244,8 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     // inside the window, what the rows beyond that point added is taken back out of pass 1's results (trim_block): one pass-1
     // launch per block, another one only when the window turns out too short.
     // The window, in rows.  After a block the model ended: the rows of that block plus a quarter -- plus a tenth when the two blocks
-    // before were of one size (tables of id-like columns end their blocks every N rows).  For an input's first block: the rows
+    // before were of one size (tables of id-like columns end their blocks every N rows), plus a thirty-second when they differed by
+    // less than one row in 512 (C5: by one in 10 000).  For an input's first block: the rows
     // that four times the limit's bytes of input hold (C5: a row's id fields cost 0.44 bytes of the modelled process per input
     // byte); when the limit does not trip inside a window, the next one is sized from the process size the model saw at its end.
     if (c->in_stream && c->n == 0) {         // a streamed input's first bytes: the row length the first window is sized by
@@ -1255,8 +1256,9 @@ int zdw_block_pass1(zdw_ctx *c, const zdw_split_hint *hint, zdw_pass1_result *re
     uint64_t window;
     if (c->model_rows_prev) {
         const uint64_t a = c->model_rows_prev, b = c->model_rows_prev2;
-        const bool steady = b && (a > b ? a - b : b - a) <= a / 32;
-        window = a + (steady ? a / 10 : a / 4) + 1000;
+        const uint64_t diff = a > b ? a - b : b - a;
+        const bool steady = b && diff <= a / 32, very_steady = b && diff <= a / 512;
+        window = a + (very_steady ? a / 32 : (steady ? a / 10 : a / 4)) + 1000;
     } else {
         const double bytes = 4.0 * c->mem_limit_mb * 1048576.0;
         window = (uint64_t)(bytes / (double)(c->avg_row ? c->avg_row : 1)) + 1000;
