@@ -95,6 +95,8 @@ def make_case(rnd):
     shards = rnd.choice([2, 3, 5]) if rnd.random() < 0.3 else 0
     if rnd.random() < 0.35:
         env["ZDW_SORT_PACK"] = "1"                               # the sort's packed first round wherever 8 characters fit one key
+    if rnd.random() < 0.35:
+        env["ZDW_SORT_SCATTER"] = "1"                            # the radix passes' second form (chunks put in order in LDS)
     return dict(desc=desc, types=types, tsv=tsv, trim=trim, split=split, env=env, ncols=ncols, nrows=nrows, shards=shards)
 
 

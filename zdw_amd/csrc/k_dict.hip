@@ -930,9 +930,13 @@ __global__ __launch_bounds__(256) void k_dict_emit(const uint8_t *__restrict__ i
     if (r == 0) blob[0] = 0;                                     // origin byte (dictionary.cpp:96)
     if (r >= n) return;
     const uint32_t u = order[r];
-    const uint32_t len = uniq_len[u];
-    if (!len) return;                                            // hole
-    const uint64_t off = 1 + off_excl[r];
+    // (its length from the offsets -- the scan's n + 1 outputs, read in sequence -- instead of another gather by id: 36 M of them per
+    // block of C5)
+    const uint64_t at = off_excl[r];
+    const uint32_t len1 = (uint32_t)(off_excl[r + 1] - at);
+    if (!len1) return;                                           // hole
+    const uint32_t len = len1 - 1u;
+    const uint64_t off = 1 + at;
     uint8_t *q = blob + off;
     id_off[u] = (uint32_t)off;
     if (uniq_key && len <= 24u) {
