@@ -121,6 +121,74 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
     if (!EMIT && row_ok && sub == 0) a.row_len[row] = nflag + running;
 }
 
+// The same for schemas of up to G used columns (one column per lane: all of them but those of more than 64 columns), with a loop: a
+// wave takes P2N_ITERS groups of 64 / G consecutive rows.  The kernel above starts a wave per 64 / G rows -- 2.1 M workgroups for the
+// 67 M rows of the C2 shape, each with three dependent round trips (the column's facts, the records, the row's offset) and nothing to
+// cover them: 1 TB/s.  Here the column's facts are loaded once per wave, and the records and the offset of the next group are
+// requested before the current one is worked on.
+constexpr uint32_t P2N_ITERS = 16;
+template <uint32_t G, bool EMIT>
+__global__ __launch_bounds__(256) void k_pass2_loop(const Pass2Args a)
+{
+    constexpr uint32_t ROWS_PER_WAVE = 64 / G;
+    const uint32_t lane = lane_id();
+    const uint32_t sub = lane & (G - 1), grp = lane / G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nflag = (a.nused + 7) >> 3;
+    const uint32_t u = sub;
+    const bool col_ok = u < a.nused;
+    bool text = false;
+    uint32_t off = 0, sz = 0;
+    if (col_ok) { text = a.used_kind[u] == K_TEXT; off = a.used_recoff[u]; sz = a.used_size[u]; }
+    const uint64_t first = wave * (ROWS_PER_WAVE * P2N_ITERS) + grp;
+    // the group in flight: this row's record, the record of the row above, where the row's output begins
+    uint64_t cur = 0, above = 0, out_row = 0;
+    auto request = [&](uint64_t row64) {
+        cur = above = 0; out_row = 0;
+        if (row64 < a.nrows && col_ok) {
+            cur = raw_value(a, (uint32_t)row64, off, text);
+            if (row64) above = raw_value(a, (uint32_t)row64 - 1u, off, text);
+        }
+        if (EMIT && row64 < a.nrows) out_row = a.row_off[row64];
+    };
+    request(first);
+    for (uint32_t it = 0; it < P2N_ITERS; ++it) {
+        const uint64_t row64 = first + (uint64_t)it * ROWS_PER_WAVE;
+        if (row64 - grp >= a.nrows) break;                      // (wave-uniform: the group's first row)
+        const uint64_t c = cur, ab = above, orow = out_row;
+        if (it + 1 < P2N_ITERS) request(row64 + ROWS_PER_WAVE);
+        const bool ok = row64 < a.nrows && col_ok;
+        bool flag = false;
+        if (ok) flag = row64 ? c != ab : first_row_flag(a, c, u, text);
+        const uint32_t mine = flag ? sz : 0u;
+        uint32_t inc = mine;                                    // inclusive prefix over the G lanes of the group
+#pragma unroll
+        for (uint32_t d = 1; d < G; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, d, G);
+            if (sub >= d) inc += t;
+        }
+        const uint32_t tot = (uint32_t)__shfl((int)inc, G - 1, G);
+        if (EMIT) {
+            const uint64_t bal = __ballot(flag);
+            uint64_t bits = bal;
+            if constexpr (G < 64) bits = (bal >> (grp * G)) & ((1ull << G) - 1ull);
+            constexpr uint32_t FB = G >= 8 ? G / 8 : 1;                  // flag bytes of the row
+            if (row64 < a.nrows && sub < FB && 8 * sub < a.nused) a.out[orow + sub] = (uint8_t)(bits >> (8 * sub));
+            if (flag) {
+                const uint64_t v = stored_from_raw(a, c, u, text);
+                uint8_t *q = a.out + orow + nflag + (inc - mine);
+                if (sz == 8) { reinterpret_cast<PackedW64 *>(q)->v = v; }
+                else {
+                    uint64_t r = v;
+                    if (sz & 4u) { reinterpret_cast<PackedW32 *>(q)->v = (uint32_t)r; q += 4; r >>= 32; }
+                    if (sz & 2u) { reinterpret_cast<PackedW16 *>(q)->v = (uint16_t)r; q += 2; r >>= 16; }
+                    if (sz & 1u) *q = (uint8_t)r;
+                }
+            }
+        } else if (row64 < a.nrows && sub == 0) a.row_len[row64] = nflag + tot;
+    }
+}
+
 // Records stream through once and the rows leave once: non-temporal loads and stores, so that they do not push the dictionary offsets
 // (id_off: the emit kernel's gather, a few KB of it hot) out of the CU's vector L1.
 typedef uint32_t p2_u32x4 __attribute__((ext_vector_type(4)));
@@ -734,6 +802,22 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
         return;
     }
     const uint64_t rows_per_block = (256 / 64) * (64 / g);
+    bool loop = a.nrows >= (1u << 16);                     // (small blocks: the plain kernel's more waves win)
+    if (const char *e = test_hook("ZDW_P2_LOOP")) loop = atoi(e) != 0;      // tests
+    if (loop && a.nused <= g) {
+        const uint64_t per_block = rows_per_block * P2N_ITERS;
+        const uint32_t grid = (uint32_t)((a.nrows + per_block - 1) / per_block);
+        switch (g) {
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<1, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<2, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<4, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<8, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<16, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<32, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<64, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+        }
+        return;
+    }
     const uint32_t grid = (uint32_t)((a.nrows + rows_per_block - 1) / rows_per_block);
     switch (g) {
     case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2<1, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
