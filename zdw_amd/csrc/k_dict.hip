@@ -316,11 +316,28 @@ __device__ __forceinline__ bool conforms(uint64_t k0, uint64_t k1, uint64_t k2, 
     return pb.nchars && (k0 & pb.himask[0]) == pb.hival[0] && (k1 & pb.himask[1]) == pb.hival[1] && (k2 & pb.himask[2]) == pb.hival[2];
 }
 
-// keys[u] = 0 hole, 1 conforming, 2 exception; vals[u] = u; counts[c] += the strings of class c (a workgroup walks its share of the
-// ids and adds what it counted once: three atomics per 256 ids on three words took 3 ms at 67 M ids)
-__global__ __launch_bounds__(256) void k_sort_classes(const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ uniq_len, uint32_t n,
-                                                      const PackedBucket *__restrict__ table, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                      uint32_t *__restrict__ counts)
+// (k0, k1, k2: a conforming string's first 24 bytes as kept by id -- its first character is the low byte of k0)
+__device__ __forceinline__ uint64_t packed_key(uint64_t k0, uint64_t k1, uint64_t k2, const PackedBucket &pb, uint32_t rest_bits)
+{
+    uint64_t rest = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < 24; ++i) {
+        if (i >= pb.nchars) break;
+        const uint32_t w = (uint32_t)(pb.w[i >> 4] >> (4 * (i & 15u))) & 15u;
+        const uint64_t word = i < 8 ? k0 : (i < 16 ? k1 : k2);
+        const uint32_t byte = (uint32_t)(word >> (8 * (i & 7u))) & 255u;
+        rest = (rest << w) | (byte & ((1u << w) - 1u));
+    }
+    return ((uint64_t)(256u + ((uint32_t)k0 & 255u)) << rest_bits) | rest;
+}
+
+// The packed round's keys, for all ids in place (vals[u] = u): a hole's key is 0, a conforming string's its packed key (bit P + 8
+// set), an exception's 2^(P + 9) -- so the round leaves holes | conforming strings in order | exceptions, and k_sort_ties calls
+// neither two holes nor two exceptions tied.  counts[c] += the ids of class c (0 hole, 1 conforming, 2 exception: a workgroup
+// walks its share of the ids and adds what it counted once -- three atomics per 256 ids on three words took 3 ms at 67 M ids).
+__global__ __launch_bounds__(256) void k_sort_keys_packed(const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ uniq_len, uint32_t n,
+                                                          const PackedKeySpec ps, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                          uint32_t *__restrict__ counts)
 {
     __shared__ uint32_t sc[3];
     if (threadIdx.x < 3) sc[threadIdx.x] = 0;
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(256) void k_sort_classes(const uint64_t *__restrict
         const bool real = u < end && uniq_len[u] != 0;
         uint64_t k0 = 0, k1 = 0, k2 = 0;
         if (real) { k0 = uniq_key[3 * u]; k1 = uniq_key[3 * u + 1]; k2 = uniq_key[3 * u + 2]; }
-        uint32_t cls = 0;
+        uint64_t key = 0;
         const uint64_t rm = __ballot(real);
         if (rm) {
             // one first byte in the whole wave (a column of date-times): its entry of the table through scalar loads, once, instead of
@@ -341,13 +358,18 @@ __global__ __launch_bounds__(256) void k_sort_classes(const uint64_t *__restrict
             const uint32_t b = (uint32_t)k0 & 255u;
             const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lane_value(b, lowest_bit(rm)));
             if (__ballot(real && b != b0) == 0) {
-                const PackedBucket pb = table[b0];
-                if (real) cls = conforms(k0, k1, k2, pb) ? 1u : 2u;
+                const PackedBucket pb = ps.table[b0];
+                if (real) key = conforms(k0, k1, k2, pb) ? packed_key(k0, k1, k2, pb, ps.rest_bits) : 1ull << (ps.rest_bits + 9);
             } else if (real) {
-                cls = conforms(k0, k1, k2, table[b]) ? 1u : 2u;
+                const PackedBucket pb = ps.table[b];
+                key = conforms(k0, k1, k2, pb) ? packed_key(k0, k1, k2, pb, ps.rest_bits) : 1ull << (ps.rest_bits + 9);
             }
         }
-        if (u < end) { keys[u] = cls; vals[u] = (uint32_t)u; mine0 += cls == 0u; mine1 += cls == 1u; mine2 += cls == 2u; }
+        if (u < end) {
+            keys[u] = key; vals[u] = (uint32_t)u;
+            const uint32_t cls = key == 0 ? 0u : (key >> (ps.rest_bits + 9) ? 2u : 1u);
+            mine0 += cls == 0u; mine1 += cls == 1u; mine2 += cls == 2u;
+        }
     }
     const uint32_t t0 = wave_incl_sum(mine0), t1 = wave_incl_sum(mine1), t2 = wave_incl_sum(mine2);
     if (lane_id() == 63) { if (t0) atomicAdd(&sc[0], t0); if (t1) atomicAdd(&sc[1], t1); if (t2) atomicAdd(&sc[2], t2); }
@@ -355,39 +377,17 @@ __global__ __launch_bounds__(256) void k_sort_classes(const uint64_t *__restrict
     if (threadIdx.x < 3 && sc[threadIdx.x]) atomicAdd(counts + threadIdx.x, sc[threadIdx.x]);
 }
 
-// (k0, k1, k2: a conforming string's first 24 bytes as kept by id -- its first character is the low byte of k0)
-__device__ __forceinline__ uint64_t packed_key(uint64_t k0, uint64_t k1, uint64_t k2, const PackedKeySpec &ps)
-{
-    const uint32_t b = (uint32_t)k0 & 255u;
-    const PackedBucket pb = ps.table[b];
-    uint64_t rest = 0;
-#pragma unroll
-    for (uint32_t i = 1; i < 24; ++i) {
-        if (i >= pb.nchars) break;
-        const uint32_t w = (uint32_t)(pb.w[i >> 4] >> (4 * (i & 15u))) & 15u;
-        const uint64_t word = i < 8 ? k0 : (i < 16 ? k1 : k2);
-        const uint32_t byte = (uint32_t)(word >> (8 * (i & 7u))) & 255u;
-        rest = (rest << w) | (byte & ((1u << w) - 1u));
-    }
-    return ((uint64_t)(256u + b) << ps.rest_bits) | rest;
-}
-
 // keys[j] = 8 bytes at depth d of the string now at position active[j]; vals[j] = j
 __global__ __launch_bounds__(256) void k_sort_keys(const uint8_t *__restrict__ in, uint64_t in_bytes, const uint8_t *__restrict__ extra,
                                                     const uint64_t *__restrict__ uniq_pos, const uint32_t *__restrict__ uniq_len,
                                                     const uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     uint32_t m, uint32_t depth, uint64_t *__restrict__ keys,
-                                                    uint32_t *__restrict__ vals, const uint64_t *__restrict__ uniq_key, const PackedKeySpec ps)
+                                                    uint32_t *__restrict__ vals, const uint64_t *__restrict__ uniq_key)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t u = order ? order[active[j]] : j;          // first round: everything is in place (order = active = identity)
     const uint32_t len = uniq_len[u];
-    if (ps.table) {
-        keys[j] = packed_key(uniq_key[3ull * u], uniq_key[3ull * u + 1], uniq_key[3ull * u + 2], ps);      // (only conforming strings get here)
-        vals[j] = j;
-        return;
-    }
     if (uniq_key && depth < 3) {
         // the first 24 bytes were kept by id when the string entered the table: in the first round a streaming read
         // instead of a visit to the image per string
@@ -420,15 +420,17 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint32_t *__restrict_
 __global__ __launch_bounds__(256) void k_sort_ties(uint32_t *__restrict__ order, const uint32_t *__restrict__ active,
                                                     const uint32_t *__restrict__ group, const uint32_t *__restrict__ tmp,
                                                     const uint64_t *__restrict__ sorted_keys, uint32_t m,
-                                                    uint32_t *__restrict__ still, uint32_t *__restrict__ max_run)
+                                                    uint32_t *__restrict__ still, uint32_t *__restrict__ max_run, uint64_t untied_from)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     order[active[j]] = tmp[j];
     const uint64_t k = sorted_keys[j];
     const uint32_t g = group[j];
-    const bool tie_prev = j > 0 && group[j - 1] == g && sorted_keys[j - 1] == k;
-    const bool tie_next = j + 1 < m && group[j + 1] == g && sorted_keys[j + 1] == k;
+    // (a packed round, k_sort_keys_packed: holes share key 0, exceptions the key untied_from, and neither are tied with anybody)
+    const bool may_tie = !untied_from || (k != 0 && k < untied_from);
+    const bool tie_prev = may_tie && j > 0 && group[j - 1] == g && sorted_keys[j - 1] == k;
+    const bool tie_next = may_tie && j + 1 < m && group[j + 1] == g && sorted_keys[j + 1] == k;
     // run labels must stay dense (1..#runs) because the next round radix-sorts them on as few bits
     // as the number of still-tied strings needs: count a head only for runs that stay in the working set
     still[j] = ((tie_prev || tie_next) ? 1u : 0u) | ((!tie_prev && tie_next) ? 2u : 0u);
@@ -744,15 +746,15 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     uint64_t *d_sample = reinterpret_cast<uint64_t *>(d_big + 8);
     PackedBucket *d_table = reinterpret_cast<PackedBucket *>(d_sample + 4 * SORT_SAMPLE);
 
-    // One list of positions [off0, off0 + m0) of `order` sorted: rounds of 8 bytes per string (the first one packed when pk is given:
-    // the rounds behind it go on at byte 8 * depth_after), tie groups, the finishing kernels.  identity: order[i] = i still holds
-    // (a sort of all ids from the start).
+    // One list of positions [off0, off0 + m0) of `order` sorted: rounds of 8 bytes per string, tie groups, the finishing kernels.
+    // identity: order[i] = i still holds (a sort of all ids from the start).  pk (with identity, over all ids): the first round is the
+    // packed one -- it leaves holes | conforming strings | exceptions (the exceptions in no order yet), the rounds behind it go on
+    // with the conforming strings still tied, at byte 8 * depth_after.
     auto sort_region = [&](uint32_t off0, uint32_t m0, bool identity, const PackedKeySpec *pk, uint32_t depth_after) -> int {
         uint32_t *active = b.active_a, *active_alt = b.active_b;
         uint32_t *group = b.group, *group_next = group_next0;      // tie-group labels per active index
         uint32_t m = m0, off = off0, max_label = 0;   // max_label: the largest tie-group label of the round (0 in the first: one group)
         bool packed = pk != nullptr, first = true;
-        const PackedKeySpec no_pack{};
         HIPCHK(hipMemsetAsync(d_big, 0, 16, s));
         // the working set is [off, off + m) of the active list (off > 0: the region's first round, or one long run alone)
         for (uint32_t depth = 0; m > 1; ++depth) {
@@ -762,9 +764,9 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
             uint64_t *keys = b.key_a, *keys_alt = b.key_b;
             uint32_t *vals = b.val_a, *vals_alt = b.val_b;
             const uint32_t *order_in = (first && identity) ? nullptr : b.order;
-            hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active + off, m, depth, keys, vals, uniq_key,
-                               packed ? *pk : no_pack);
-            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, packed ? (pk->rest_bits + 9 + 7) & ~7u : 64u, b.hist, b.scan_tmp, s);
+            if (packed) hipLaunchKernelGGL(k_sort_keys_packed, dim3(std::min<uint32_t>(gb, 4096u)), dim3(256), 0, s, uniq_key, uniq_len, m, *pk, keys, vals, d_big + 4);
+            else hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active + off, m, depth, keys, vals, uniq_key);
+            radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, packed ? (pk->rest_bits + 10 + 7) & ~7u : 64u, b.hist, b.scan_tmp, s);
             if (!first && max_label > 1) {
                 // stable, more significant key: the tie group of the element's old position (labels are < m + 1)
                 // (labels are 1 .. the number of runs that stayed in the working set: read back with the round's count)
@@ -773,7 +775,8 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
                 radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, group + off, m, 0, (bits + 7) & ~7u, b.hist, b.scan_tmp, s);
             }
             hipLaunchKernelGGL(k_sort_gather, dim3(gb), dim3(256), 0, s, order_in, active + off, vals, m, tmp, d_big);
-            hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active + off, group + off, tmp, (const uint64_t *)keys, m, still, d_big);
+            hipLaunchKernelGGL(k_sort_ties, dim3(gb), dim3(256), 0, s, b.order, active + off, group + off, tmp, (const uint64_t *)keys, m, still, d_big,
+                               packed ? 1ull << (pk->rest_bits + 9) : 0ull);
             launch_scan_two_flags(still, still_scan, head_scan, m, b.scan_tmp, s);
             uint32_t *run_start = reinterpret_cast<uint32_t *>(keys == b.key_a ? b.key_b : b.key_a);      // (the pairs' other buffer: free behind the radix passes)
             hipLaunchKernelGGL(k_sort_compact, dim3(gb), dim3(256), 0, s, active + off, still, head_scan, still_scan, m, active_alt,
@@ -835,26 +838,20 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
         if (rounds_out) *rounds_out = rounds;
         return 0;
     }
-    // holes | conforming strings | exceptions, each list by id
+    // the packed round over all ids, then the rounds the conforming strings still need
     uint32_t *d_counts = d_big + 4;
     uint32_t counts[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(d_table, pl.table.data(), 256 * sizeof(PackedBucket), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(d_counts, 0, 12, s));
-    {
-        uint64_t *keys = b.key_a, *keys_alt = b.key_b;
-        uint32_t *vals = b.val_a, *vals_alt = b.val_b;
-        hipLaunchKernelGGL(k_sort_classes, dim3(std::min<uint32_t>(nb256, 4096u)), dim3(256), 0, s, uniq_key, uniq_len, n, d_table, keys, vals, d_counts);
-        radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, n, 0, 8, b.hist, b.scan_tmp, s);
-        HIPCHK(hipMemcpyAsync(b.order, vals, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(counts, d_counts, 12, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));                            // (also: pl.table has been read)
-    }
+    HIPCHK(hipStreamSynchronize(s));                                // (pl.table has been read)
+    const PackedKeySpec ps{d_table, pl.P};
+    int e = sort_region(0, n, true, &ps, pl.depth_after);
+    if (e) return e;
+    HIPCHK(hipMemcpyAsync(counts, d_counts, 12, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     const uint32_t nh = counts[0], na = counts[1], nx = counts[2];
     if ((uint64_t)nh + na + nx != n) return (int)hipErrorUnknown;   // (cannot happen)
     if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] %u holes, %u conforming strings, %u exceptions\n", nh, na, nx);
-    const PackedKeySpec ps{d_table, pl.P};
-    int e = sort_region(nh, na, false, &ps, pl.depth_after);
-    if (e) return e;
     if (nx) {
         if (nx > 1 && nx <= SORT_TINY && uniq_key) {
             hipLaunchKernelGGL(k_sort_tiny, dim3(1), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order + nh + na, nx, tmp);
