@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(256) void k_import_strings(const uint8_t *in, uint6
     const uint32_t lane = lane_id();
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     IdAlloc al;
-    al.cur = al.end = 0;
+    al.cur = al.end = al.taken = 0;
     uint32_t created = 0;
     for (uint64_t g = wave * 64; g < count; g += nwaves * 64) {
         const uint64_t i = g + lane;

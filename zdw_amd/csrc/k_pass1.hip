@@ -951,7 +951,7 @@ __global__ __launch_bounds__(64 * P1_WPB_MAX, DEFER ? P1_MIN_WAVES : 1) void k_p
     ws.q_head = 0; ws.q_count = 0; ws.row_cur = 0; ws.col_cur = 0; ws.ring_lo = 0; ws.rel_se1 = 0; ws.first_pending = false; ws.vbase = 0;
     ws.ignoring = false; ws.prev_nl = false; ws.done = false; ws.row_start = 0; ws.last_e = 0;
     ws.last_ord = 255u; ws.tok_ord = 0; ws.tok_prevb = 0; ws.tok_bs = false; ws.far = false; ws.far_abs = 0; ws.pos_hi = 0;
-    ws.ids.cur = ws.ids.end = 0;
+    ws.ids.cur = ws.ids.end = ws.ids.taken = 0;
     if (lane < 2) *reinterpret_cast<uint32_t *>(zdw_lds + L.dqs + 8u * wv + 4u * lane) = 0;      // the wave's chunk of deferred-queue entries: [cur, end)
     DictTable d;
     d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.uniq_key = a.uniq_key; d.st = a.st; d.track_first = TRACK ? 1u : 0u;
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(256) void k_pass1_deferred(const Pass1Args a, uint3
     DictTable d;
     d.slots = a.slots; d.slot_mask = a.slot_mask; d.uniq_pos = a.uniq_pos; d.uniq_len = a.uniq_len; d.id_cap = a.id_cap; d.uniq_key = a.uniq_key; d.st = a.st; d.track_first = a.track_first;
     IdAlloc al;
-    al.cur = al.end = 0;
+    al.cur = al.end = al.taken = 0;
     uint32_t created = 0;
     for (uint32_t g = wave * 64; g < count; g += nwaves * 64) {
         const uint32_t i = g + lane;

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64 * RW_WPB_MAX, 1) void k_pass1_rows(const Pass1Ar
     }
     const uint32_t K = ra.rows_per_lane;
     IdAlloc ids;
-    ids.cur = ids.end = 0;
+    ids.cur = ids.end = ids.taken = 0;
     uint32_t dq_cur = 0, dq_end = 0;                                  // this wave's chunk of deferred-queue entries
     uint32_t new_entries = 0;
     uint32_t vm_seq = 0;                                              // loads of the kind above issued so far

@@ -169,12 +169,19 @@ __device__ __forceinline__ SlotWords await_slot(SlotLoad &l)
 }
 
 // ---- unique ids -------------------------------------------------------------------------------
-struct IdAlloc { uint32_t cur, end; };     // wave-uniform: ids [cur, end) belong to this wave
-constexpr uint32_t ID_CHUNK = 64;          // ids a pass-1 wave takes beyond what it needs right now
+struct IdAlloc { uint32_t cur, end, taken; };     // wave-uniform: ids [cur, end) belong to this wave; taken: all it has taken so far
+#ifndef ZDW_ID_CHUNK
+#define ZDW_ID_CHUNK 64
+#endif
+constexpr uint32_t ID_CHUNK = ZDW_ID_CHUNK;          // ids a pass-1 wave takes beyond what it needs right now
 
 // One id for every active lane with `need` (call it with all lanes of the surrounding control flow).  Ids
 // come from the wave's chunk; when that runs out the wave takes what is missing plus `extra` more from
-// the global counter with one atomic.
+// the global counter with one atomic -- more than `extra` once it has taken thousands: a sixteenth of what it
+// has taken so far, up to 512 (the C2 shape, a new string per row: a million returning atomics on one word
+// with chunks of 64, 15.8 -> 15.0 ms; the benchmark's waves take ~900 ids each and stay at 64 -- what is left
+// of a chunk is holes among the ids, which the sort carries).
+constexpr uint32_t ID_CHUNK_MAX = 512;
 __device__ __forceinline__ uint32_t alloc_ids(IdAlloc &al, uint64_t m, P1Status *st, uint32_t extra);
 __device__ __forceinline__ uint32_t alloc_ids(IdAlloc &al, bool need, P1Status *st, uint32_t extra) { return alloc_ids(al, (uint64_t)__ballot(need), st, extra); }
 // ... for the lanes of mask m (wave-uniform)
@@ -187,7 +194,9 @@ __device__ __forceinline__ uint32_t alloc_ids(IdAlloc &al, uint64_t m, P1Status 
         al.cur += k;
     } else {
         const int first = lowest_bit(m);
-        const uint32_t grab = k - have + extra;
+        const uint32_t more = al.taken >> 4;
+        const uint32_t grab = k - have + (extra ? (more > extra ? (more < ID_CHUNK_MAX ? more : ID_CHUNK_MAX) : extra) : 0u);
+        al.taken += grab;
         uint32_t fresh = 0;
         if (lane_id() == (uint32_t)first) fresh = atomicAdd(&st->id_next, grab);
         fresh = lane_value(fresh, first);
@@ -204,6 +213,7 @@ __device__ __forceinline__ void adopt_ids(IdAlloc &al, uint64_t m)
     const int src = lowest_bit(m);
     al.cur = lane_value(al.cur, src);
     al.end = lane_value(al.end, src);
+    al.taken = lane_value(al.taken, src);
 }
 // ids left in the wave's chunk stay holes
 __device__ __forceinline__ void retire_ids(const IdAlloc &al, uint32_t *uniq_len, uint32_t id_cap)
