@@ -121,15 +121,34 @@ __global__ __launch_bounds__(256) void k_pass2(const Pass2Args a)
     if (!EMIT && row_ok && sub == 0) a.row_len[row] = nflag + running;
 }
 
+// Records stream through once and the rows leave once: non-temporal loads and stores, so that they do not push the dictionary offsets
+// (id_off: the emit kernel's gather, a few KB of it hot) out of the CU's vector L1.
+typedef uint32_t p2_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 stream_load16(const uint8_t *p)
+{
+    const p2_u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const p2_u32x4 *>(p));
+    return make_uint4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ void stream_store16(uint8_t *p, const uint4 &v)
+{
+    p2_u32x4 x;
+    x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    __builtin_nontemporal_store(x, reinterpret_cast<p2_u32x4 *>(p));
+}
+
 // The same for schemas of up to G used columns (one column per lane: all of them but those of more than 64 columns), with a loop: a
 // wave takes P2N_ITERS groups of 64 / G consecutive rows.  The kernel above starts a wave per 64 / G rows -- 2.1 M workgroups for the
 // 67 M rows of the C2 shape, each with three dependent round trips (the column's facts, the records, the row's offset) and nothing to
 // cover them: 1 TB/s.  Here the column's facts are loaded once per wave, and the records and the offset of the next group are
 // requested before the current one is worked on.
+// STAGE (emit): the wave's rows -- consecutive, so their bytes are one piece of the output -- are put together in LDS (at the byte
+// phase of their place in the output) and leave as aligned 16-byte stores, instead of every lane storing its 1 to 8 bytes on its own.
 constexpr uint32_t P2N_ITERS = 16;
-template <uint32_t G, bool EMIT>
+__host__ __device__ inline uint32_t p2n_image_bytes(uint32_t g, uint32_t out_row_max) { return ((64u / g) * P2N_ITERS * out_row_max + 32u + 15u) & ~15u; }
+template <uint32_t G, bool EMIT, bool STAGE = false>
 __global__ __launch_bounds__(256) void k_pass2_loop(const Pass2Args a)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t p2n_lds[];
     constexpr uint32_t ROWS_PER_WAVE = 64 / G;
     const uint32_t lane = lane_id();
     const uint32_t sub = lane & (G - 1), grp = lane / G;
@@ -141,6 +160,19 @@ __global__ __launch_bounds__(256) void k_pass2_loop(const Pass2Args a)
     uint32_t off = 0, sz = 0;
     if (col_ok) { text = a.used_kind[u] == K_TEXT; off = a.used_recoff[u]; sz = a.used_size[u]; }
     const uint64_t first = wave * (ROWS_PER_WAVE * P2N_ITERS) + grp;
+    // (STAGE) the wave's piece of the output: [obase, oend), its image in LDS from byte `shift` on
+    uint8_t *img = nullptr;
+    uint64_t obase = 0;
+    uint32_t shift = 0, onbytes = 0;
+    if (EMIT && STAGE) {
+        const uint64_t r0 = wave * (ROWS_PER_WAVE * P2N_ITERS);
+        if (r0 >= a.nrows) return;
+        const uint64_t r1 = r0 + ROWS_PER_WAVE * P2N_ITERS < a.nrows ? r0 + ROWS_PER_WAVE * P2N_ITERS : a.nrows;
+        obase = a.row_off[r0];
+        onbytes = (uint32_t)(a.row_off[r1] - obase);
+        shift = (uint32_t)obase & 15u;
+        img = p2n_lds + (threadIdx.x >> 6) * p2n_image_bytes(G, a.out_row_max);
+    }
     // the group in flight: this row's record, the record of the row above, where the row's output begins
     uint64_t cur = 0, above = 0, out_row = 0;
     auto request = [&](uint64_t row64) {
@@ -173,10 +205,11 @@ __global__ __launch_bounds__(256) void k_pass2_loop(const Pass2Args a)
             uint64_t bits = bal;
             if constexpr (G < 64) bits = (bal >> (grp * G)) & ((1ull << G) - 1ull);
             constexpr uint32_t FB = G >= 8 ? G / 8 : 1;                  // flag bytes of the row
-            if (row64 < a.nrows && sub < FB && 8 * sub < a.nused) a.out[orow + sub] = (uint8_t)(bits >> (8 * sub));
+            uint8_t *rowp = STAGE ? img + shift + (uint32_t)(orow - obase) : a.out + orow;      // (LDS stores are unaligned-capable too)
+            if (row64 < a.nrows && sub < FB && 8 * sub < a.nused) rowp[sub] = (uint8_t)(bits >> (8 * sub));
             if (flag) {
                 const uint64_t v = stored_from_raw(a, c, u, text);
-                uint8_t *q = a.out + orow + nflag + (inc - mine);
+                uint8_t *q = rowp + nflag + (inc - mine);
                 if (sz == 8) { reinterpret_cast<PackedW64 *>(q)->v = v; }
                 else {
                     uint64_t r = v;
@@ -187,21 +220,19 @@ __global__ __launch_bounds__(256) void k_pass2_loop(const Pass2Args a)
             }
         } else if (row64 < a.nrows && sub == 0) a.row_len[row64] = nflag + tot;
     }
-}
-
-// Records stream through once and the rows leave once: non-temporal loads and stores, so that they do not push the dictionary offsets
-// (id_off: the emit kernel's gather, a few KB of it hot) out of the CU's vector L1.
-typedef uint32_t p2_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 stream_load16(const uint8_t *p)
-{
-    const p2_u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const p2_u32x4 *>(p));
-    return make_uint4(x.x, x.y, x.z, x.w);
-}
-__device__ __forceinline__ void stream_store16(uint8_t *p, const uint4 &v)
-{
-    p2_u32x4 x;
-    x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
-    __builtin_nontemporal_store(x, reinterpret_cast<p2_u32x4 *>(p));
+    if (EMIT && STAGE) {
+        // the image leaves: whole 16-byte vectors where it covers them, bytes at its two ends
+        __builtin_amdgcn_wave_barrier();                         // (one wave per image: its LDS operations execute in order)
+        uint8_t *gdst = a.out + (obase - shift);                 // 16-byte aligned
+        const uint32_t endb = shift + onbytes;
+        for (uint32_t o = lane * 16u; o < endb; o += 64u * 16u) {
+            if (o >= shift && o + 16u <= endb) stream_store16(gdst + o, *reinterpret_cast<const uint4 *>(img + o));
+            else {
+                const uint32_t lo = o > shift ? o : shift, hi = o + 16u < endb ? o + 16u : endb;
+                for (uint32_t k = lo; k < hi; ++k) gdst[k] = img[k];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -807,15 +838,22 @@ static void launch_pass2(const Pass2Args &a, hipStream_t s)
     if (loop && a.nused <= g) {
         const uint64_t per_block = rows_per_block * P2N_ITERS;
         const uint32_t grid = (uint32_t)((a.nrows + per_block - 1) / per_block);
+        const uint32_t lds = 4u * p2n_image_bytes(g, a.out_row_max);
+        bool stage = EMIT && lds <= 48u * 1024u;
+        if (const char *e = test_hook("ZDW_P2_LOOP_STAGE")) stage = EMIT && atoi(e) != 0 && lds <= 60u * 1024u;      // tests
+#define P2N_LAUNCH(GG)                                                                                                              \
+        if (stage) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<GG, EMIT, EMIT>), dim3(grid), dim3(256), lds, s, a);              \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<GG, EMIT, false>), dim3(grid), dim3(256), 0, s, a)
         switch (g) {
-        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<1, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<2, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<4, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<8, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<16, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
-        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<32, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pass2_loop<64, EMIT>), dim3(grid), dim3(256), 0, s, a); break;
+        case 1: P2N_LAUNCH(1); break;
+        case 2: P2N_LAUNCH(2); break;
+        case 4: P2N_LAUNCH(4); break;
+        case 8: P2N_LAUNCH(8); break;
+        case 16: P2N_LAUNCH(16); break;
+        case 32: P2N_LAUNCH(32); break;
+        default: P2N_LAUNCH(64); break;
         }
+#undef P2N_LAUNCH
         return;
     }
     const uint32_t grid = (uint32_t)((a.nrows + rows_per_block - 1) / rows_per_block);
