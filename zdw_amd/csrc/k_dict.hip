@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <array>
+#include <functional>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -296,16 +297,19 @@ static_assert(sizeof(PackedBucket) == 72, "SORT_SPARE_WORDS counts on it");
 struct PackedKeySpec {
     const PackedBucket *table;      // by first byte (nullptr: the round takes 8 bytes as they are)
     uint32_t rest_bits;             // P
+    uint32_t p0;                    // the place of that "first byte": 0 for a whole dictionary; 8 or 16 for one long run of strings that
+                                    // are tied over their first p0 bytes (the packed key then holds places p0 + 1 .. nchars - 1)
 };
 constexpr uint32_t SORT_SAMPLE = 4096;
 
-// out[4 t ..]: the three words and the length of string floor(t n / S)
+// out[4 t ..]: the three words and the length of string floor(t n / S) -- of a list of ids when there is one
 __global__ __launch_bounds__(256) void k_sort_sample(const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ uniq_len, uint32_t n, uint32_t S,
-                                                     uint64_t *__restrict__ out)
+                                                     uint64_t *__restrict__ out, const uint32_t *__restrict__ list)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= S) return;
-    const uint64_t u = (uint64_t)t * n / S;
+    const uint64_t at = (uint64_t)t * n / S;
+    const uint64_t u = list ? list[at] : at;
     const uint32_t len = uniq_len[u];
     out[4 * t] = len ? uniq_key[3 * u] : 0; out[4 * t + 1] = len ? uniq_key[3 * u + 1] : 0; out[4 * t + 2] = len ? uniq_key[3 * u + 2] : 0;
     out[4 * t + 3] = len;
@@ -317,27 +321,33 @@ __device__ __forceinline__ bool conforms(uint64_t k0, uint64_t k1, uint64_t k2, 
 }
 
 // (k0, k1, k2: a conforming string's first 24 bytes as kept by id -- its first character is the low byte of k0)
-__device__ __forceinline__ uint64_t packed_key(uint64_t k0, uint64_t k1, uint64_t k2, const PackedBucket &pb, uint32_t rest_bits)
+__device__ __forceinline__ uint32_t byte_at(uint64_t k0, uint64_t k1, uint64_t k2, uint32_t i)
+{
+    const uint64_t word = i < 8 ? k0 : (i < 16 ? k1 : k2);
+    return (uint32_t)(word >> (8 * (i & 7u))) & 255u;
+}
+__device__ __forceinline__ uint64_t packed_key(uint64_t k0, uint64_t k1, uint64_t k2, const PackedBucket &pb, uint32_t rest_bits, uint32_t p0)
 {
     uint64_t rest = 0;
 #pragma unroll
     for (uint32_t i = 1; i < 24; ++i) {
+        if (i <= p0) continue;
         if (i >= pb.nchars) break;
         const uint32_t w = (uint32_t)(pb.w[i >> 4] >> (4 * (i & 15u))) & 15u;
-        const uint64_t word = i < 8 ? k0 : (i < 16 ? k1 : k2);
-        const uint32_t byte = (uint32_t)(word >> (8 * (i & 7u))) & 255u;
-        rest = (rest << w) | (byte & ((1u << w) - 1u));
+        rest = (rest << w) | (byte_at(k0, k1, k2, i) & ((1u << w) - 1u));
     }
-    return ((uint64_t)(256u + ((uint32_t)k0 & 255u)) << rest_bits) | rest;
+    return ((uint64_t)(256u + byte_at(k0, k1, k2, p0)) << rest_bits) | rest;
 }
 
 // The packed round's keys, for all ids in place (vals[u] = u): a hole's key is 0, a conforming string's its packed key (bit P + 8
 // set), an exception's 2^(P + 9) -- so the round leaves holes | conforming strings in order | exceptions, and k_sort_ties calls
 // neither two holes nor two exceptions tied.  counts[c] += the ids of class c (0 hole, 1 conforming, 2 exception: a workgroup
 // walks its share of the ids and adds what it counted once -- three atomics per 256 ids on three words took 3 ms at 67 M ids).
+// (order / active: the list's j-th id is order[active[j]]; nullptr: j itself)
 __global__ __launch_bounds__(256) void k_sort_keys_packed(const uint64_t *__restrict__ uniq_key, const uint32_t *__restrict__ uniq_len, uint32_t n,
                                                           const PackedKeySpec ps, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                          uint32_t *__restrict__ counts)
+                                                          uint32_t *__restrict__ counts, const uint32_t *__restrict__ order,
+                                                          const uint32_t *__restrict__ active)
 {
     __shared__ uint32_t sc[3];
     if (threadIdx.x < 3) sc[threadIdx.x] = 0;
@@ -346,8 +356,9 @@ __global__ __launch_bounds__(256) void k_sort_keys_packed(const uint64_t *__rest
     const uint64_t per_block = (((uint64_t)n + gridDim.x - 1) / gridDim.x + 255) & ~255ull;
     const uint64_t beg = per_block * blockIdx.x, end = beg + per_block < n ? beg + per_block : n;
     for (uint64_t base = beg; base < end; base += 256) {
-        const uint64_t u = base + threadIdx.x;
-        const bool real = u < end && uniq_len[u] != 0;
+        const uint64_t j = base + threadIdx.x;
+        const uint64_t u = j < end ? (order ? order[active[j]] : j) : 0;
+        const bool real = j < end && uniq_len[u] != 0;
         uint64_t k0 = 0, k1 = 0, k2 = 0;
         if (real) { k0 = uniq_key[3 * u]; k1 = uniq_key[3 * u + 1]; k2 = uniq_key[3 * u + 2]; }
         uint64_t key = 0;
@@ -355,18 +366,18 @@ __global__ __launch_bounds__(256) void k_sort_keys_packed(const uint64_t *__rest
         if (rm) {
             // one first byte in the whole wave (a column of date-times): its entry of the table through scalar loads, once, instead of
             // nine gathers of 64 addresses
-            const uint32_t b = (uint32_t)k0 & 255u;
+            const uint32_t b = byte_at(k0, k1, k2, ps.p0);
             const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lane_value(b, lowest_bit(rm)));
             if (__ballot(real && b != b0) == 0) {
                 const PackedBucket pb = ps.table[b0];
-                if (real) key = conforms(k0, k1, k2, pb) ? packed_key(k0, k1, k2, pb, ps.rest_bits) : 1ull << (ps.rest_bits + 9);
+                if (real) key = conforms(k0, k1, k2, pb) ? packed_key(k0, k1, k2, pb, ps.rest_bits, ps.p0) : 1ull << (ps.rest_bits + 9);
             } else if (real) {
                 const PackedBucket pb = ps.table[b];
-                key = conforms(k0, k1, k2, pb) ? packed_key(k0, k1, k2, pb, ps.rest_bits) : 1ull << (ps.rest_bits + 9);
+                key = conforms(k0, k1, k2, pb) ? packed_key(k0, k1, k2, pb, ps.rest_bits, ps.p0) : 1ull << (ps.rest_bits + 9);
             }
         }
-        if (u < end) {
-            keys[u] = key; vals[u] = (uint32_t)u;
+        if (j < end) {
+            keys[j] = key; vals[j] = (uint32_t)j;
             const uint32_t cls = key == 0 ? 0u : (key >> (ps.rest_bits + 9) ? 2u : 1u);
             mine0 += cls == 0u; mine1 += cls == 1u; mine2 += cls == 2u;
         }
@@ -655,12 +666,14 @@ __global__ __launch_bounds__(256) void k_sort_init_range(uint32_t *active, uint3
 // What the packed first round would look like, from a sample of the strings (SORT_SAMPLE x {three words, length}).  force (tests):
 // a plan whenever one exists, however little it saves and however many strings it leaves out.
 struct PackPlan { bool use = false; uint32_t P = 0, depth_after = 0, chars = 0; double exceptions = 0.0; std::vector<PackedBucket> table; };
-static void plan_packed_round(const uint64_t *sample, uint32_t S, bool force, PackPlan &pl)
+// p0: the strings of the sample are tied over their first p0 bytes (a long run behind round p0 / 8): the byte at place p0 takes the
+// first byte's part, the packed key holds the places behind it.
+static void plan_packed_round(const uint64_t *sample, uint32_t S, bool force, uint32_t p0, PackPlan &pl)
 {
     auto byte_of = [&](uint32_t t, uint32_t i) { return (uint32_t)(sample[4 * t + (i >> 3)] >> (8 * (i & 7u))) & 255u; };
     std::vector<std::vector<uint32_t>> by(256);
     uint32_t real = 0;
-    for (uint32_t t = 0; t < S; ++t) if (sample[4 * t + 3]) { by[byte_of(t, 0)].push_back(t); ++real; }
+    for (uint32_t t = 0; t < S; ++t) if (sample[4 * t + 3]) { by[byte_of(t, p0)].push_back(t); ++real; }
     if (real < (force ? 2u : 256u)) return;
     std::vector<std::array<uint32_t, 24>> w(256);
     std::vector<std::array<uint32_t, 25>> W(256);
@@ -669,9 +682,10 @@ static void plan_packed_round(const uint64_t *sample, uint32_t S, bool force, Pa
     for (uint32_t b = 0; b < 256; ++b) {
         const uint32_t cnt = (uint32_t)by[b].size();
         if (cnt < (force ? 1u : 16u)) continue;                    // too few to judge: exceptions
-        W[b][0] = W[b][1] = 0; w[b][0] = 0; base[b][0] = 0;
+        for (uint32_t i = 0; i <= p0; ++i) { W[b][i] = 0; w[b][i] = 0; base[b][i] = 0; }
+        W[b][p0 + 1] = 0;
         const uint32_t need = cnt - cnt / 50;                      // 98 % of them
-        for (uint32_t i = 1; i < 24; ++i) {
+        for (uint32_t i = p0 + 1; i < 24; ++i) {
             uint32_t upto[257] = {0};                               // upto[v]: the strings whose byte here is below v
             for (uint32_t t : by[b]) ++upto[byte_of(t, i) + 1];
             for (uint32_t v = 0; v < 256; ++v) upto[v + 1] += upto[v];
@@ -691,6 +705,7 @@ static void plan_packed_round(const uint64_t *sample, uint32_t S, bool force, Pa
     for (uint64_t seen = 0; nmajor < judged.size() && seen * 50 < (uint64_t)real * 49; ++nmajor) seen += by[judged[nmajor]].size();
     uint32_t kmaj = 0, P = 0;
     for (uint32_t k : {24u, 16u, 8u}) {
+        if (k <= p0) break;
         uint32_t need = 0;
         for (uint32_t i = 0; i < nmajor; ++i) need = std::max(need, W[judged[i]][k]);
         if (need + 9 <= 63) { kmaj = k; P = need; break; }
@@ -700,8 +715,8 @@ static void plan_packed_round(const uint64_t *sample, uint32_t S, bool force, Pa
     pl.depth_after = 3;
     for (uint32_t b : judged) {
         PackedBucket &pb = pl.table[b];
-        pb.nchars = W[b][24] <= P ? 24u : (W[b][16] <= P ? 16u : (W[b][8] <= P ? 8u : 0u));
-        for (uint32_t i = 1; i < pb.nchars; ++i) {
+        pb.nchars = W[b][24] <= P ? 24u : (W[b][16] <= P && p0 < 16 ? 16u : (W[b][8] <= P && p0 < 8 ? 8u : 0u));
+        for (uint32_t i = p0 + 1; i < pb.nchars; ++i) {
             pb.w[i >> 4] |= (uint64_t)w[b][i] << (4 * (i & 15u));
             const uint64_t hm = (0xFFu << w[b][i]) & 0xFFu;
             pb.himask[i >> 3] |= hm << (8 * (i & 7u));
@@ -712,7 +727,7 @@ static void plan_packed_round(const uint64_t *sample, uint32_t S, bool force, Pa
     uint32_t exc = 0;
     for (uint32_t t = 0; t < S; ++t) {
         if (!sample[4 * t + 3]) continue;
-        const PackedBucket &pb = pl.table[byte_of(t, 0)];
+        const PackedBucket &pb = pl.table[byte_of(t, p0)];
         const bool ok = pb.nchars && (sample[4 * t] & pb.himask[0]) == pb.hival[0] && (sample[4 * t + 1] & pb.himask[1]) == pb.hival[1] &&
                         (sample[4 * t + 2] & pb.himask[2]) == pb.hival[2];
         if (!ok) ++exc;
@@ -720,7 +735,7 @@ static void plan_packed_round(const uint64_t *sample, uint32_t S, bool force, Pa
     pl.P = P; pl.chars = kmaj; pl.exceptions = (double)exc / (double)real;
     // worth it: few exceptions (they are sorted the ordinary way and then found their places one by one), and more than 8 characters
     // in the round or 6 passes at most
-    pl.use = force ? exc < real : (exc * 32ull <= real && (kmaj > 8 || P + 9 <= 48));
+    pl.use = force ? exc < real : (exc * 32ull <= real && (kmaj - p0 > 8 || P + 9 <= 48));
 }
 
 // Sort n unique strings.  Buffers: see SortBuffers.  Returns 0 or a hipError_t.
@@ -750,21 +765,23 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     // identity: order[i] = i still holds (a sort of all ids from the start).  pk (with identity, over all ids): the first round is the
     // packed one -- it leaves holes | conforming strings | exceptions (the exceptions in no order yet), the rounds behind it go on
     // with the conforming strings still tied, at byte 8 * depth_after.
-    auto sort_region = [&](uint32_t off0, uint32_t m0, bool identity, const PackedKeySpec *pk, uint32_t depth_after) -> int {
+    std::function<int(uint32_t, uint32_t, bool, uint32_t)> sort_any;      // (below: a list sorted with a packed round where that pays)
+    auto sort_region = [&](uint32_t off0, uint32_t m0, bool identity, const PackedKeySpec *pk, uint32_t depth_after, uint32_t depth0) -> int {
         uint32_t *active = b.active_a, *active_alt = b.active_b;
         uint32_t *group = b.group, *group_next = group_next0;      // tie-group labels per active index
         uint32_t m = m0, off = off0, max_label = 0;   // max_label: the largest tie-group label of the round (0 in the first: one group)
         bool packed = pk != nullptr, first = true;
         HIPCHK(hipMemsetAsync(d_big, 0, 16, s));
         // the working set is [off, off + m) of the active list (off > 0: the region's first round, or one long run alone)
-        for (uint32_t depth = 0; m > 1; ++depth) {
+        for (uint32_t depth = depth0; m > 1; ++depth) {
             ++rounds;
             if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] depth %u%s: m = %u of n = %u\n", depth, packed ? " (packed)" : "", m, n);
             const uint32_t gb = (m + 255) / 256;
             uint64_t *keys = b.key_a, *keys_alt = b.key_b;
             uint32_t *vals = b.val_a, *vals_alt = b.val_b;
             const uint32_t *order_in = (first && identity) ? nullptr : b.order;
-            if (packed) hipLaunchKernelGGL(k_sort_keys_packed, dim3(std::min<uint32_t>(gb, 4096u)), dim3(256), 0, s, uniq_key, uniq_len, m, *pk, keys, vals, d_big + 4);
+            if (packed) hipLaunchKernelGGL(k_sort_keys_packed, dim3(std::min<uint32_t>(gb, 4096u)), dim3(256), 0, s, uniq_key, uniq_len, m, *pk, keys, vals, d_big + 4,
+                                           order_in, order_in ? active + off : (const uint32_t *)nullptr);
             else hipLaunchKernelGGL(k_sort_keys, dim3(gb), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, order_in, active + off, m, depth, keys, vals, uniq_key);
             radix_sort_pairs(&keys, &vals, &keys_alt, &vals_alt, nullptr, m, 0, packed ? (pk->rest_bits + 10 + 7) & ~7u : 64u, b.hist, b.scan_tmp, s);
             if (!first && max_label > 1) {
@@ -810,6 +827,18 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
                 if (!nbig) break;
                 if (res[2] <= res[1] || res[2] > m) return (int)hipErrorUnknown;
                 off = res[1]; m = res[2] - res[1]; max_label = 1;
+                // The one long run (the benchmark's table: 1.67 M date-times that all begin "2024-01-"): its strings lie side by side in
+                // `order`, are tied over their first 8 (depth + 1) bytes and are of one kind -- a packed round of their own may cover
+                // all that is left of them (sort_any).
+                const uint32_t next = depth + (packed ? depth_after - depth : 1u);
+                if (uniq_key && next < 3 && !test_hook("ZDW_SORT_NO_PACK") && (m >= (1u << 20) || test_hook("ZDW_SORT_PACK"))) {
+                    uint32_t pos0 = 0;
+                    HIPCHK(hipMemcpyAsync(&pos0, active + off, 4, hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                    if ((uint64_t)pos0 + m > n) return (int)hipErrorUnknown;      // (cannot happen)
+                    hipLaunchKernelGGL(k_sort_init_range, dim3((m + 255) / 256), dim3(256), 0, s, b.active_a, b.group, pos0, m);
+                    return sort_any(pos0, m, false, next);
+                }
             }
             if (depth > max_len / 8 + 2) return (int)hipErrorUnknown;   // cannot happen: two distinct strings differ within max_len bytes
             if (packed) { depth = depth_after - 1u; packed = false; }   // on behind the characters every first byte's packed key covered
@@ -818,58 +847,61 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
         return 0;
     };
 
-    // a packed first round?  (dictionaries of millions: the sample and its verdict cost ~0.1 ms)
-    PackPlan pl;
+    // A list of positions [pos0, pos0 + m0) of `order` (identity: all ids from the start, holes included; otherwise a run of strings
+    // tied over their first 8 * depth0 bytes), sorted: with a packed round where the sample says it pays -- the packed round, the
+    // rounds the conforming strings still need, the exceptions sorted apart, the two lists merged -- or by ordinary rounds.
+    // (whole dictionaries: from 8 M strings on -- the sample and its verdict cost 0.1-0.3 ms; a long run: from 1 M)
     const bool force = test_hook("ZDW_SORT_PACK") != nullptr;
-    if (uniq_key && n > 1 && !test_hook("ZDW_SORT_NO_PACK") && (force || n >= (8u << 20))) {
-        const uint32_t S = std::min(n, SORT_SAMPLE);
-        std::vector<uint64_t> sample(4 * (size_t)S);
-        hipLaunchKernelGGL(k_sort_sample, dim3((S + 255) / 256), dim3(256), 0, s, uniq_key, uniq_len, n, S, d_sample);
-        HIPCHK(hipMemcpyAsync(sample.data(), d_sample, sample.size() * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        plan_packed_round(sample.data(), S, force, pl);
-        if (experiment("ZDW_SORT_DEBUG"))
-            fprintf(stderr, "[sort] packed first round: %s (%u characters in %u + 9 bits, %.2f %% of the sample left out, the next round at byte %u)\n",
-                    pl.use ? "yes" : "no", pl.chars, pl.P, 100.0 * pl.exceptions, 8 * pl.depth_after);
-    }
-    if (!pl.use) {
-        const int e = sort_region(0, n, true, nullptr, 0);
+    sort_any = [&](uint32_t pos0, uint32_t m0, bool identity, uint32_t depth0) -> int {
+        PackPlan pl;
+        const uint32_t p0 = 8 * depth0;
+        if (uniq_key && m0 > 1 && p0 < 24 && !test_hook("ZDW_SORT_NO_PACK") && (force || m0 >= (identity ? (8u << 20) : (1u << 20)))) {
+            const uint32_t S = std::min(m0, identity ? SORT_SAMPLE : SORT_SAMPLE / 4);
+            std::vector<uint64_t> sample(4 * (size_t)S);
+            hipLaunchKernelGGL(k_sort_sample, dim3((S + 255) / 256), dim3(256), 0, s, uniq_key, uniq_len, m0, S, d_sample,
+                               identity ? (const uint32_t *)nullptr : b.order + pos0);
+            HIPCHK(hipMemcpyAsync(sample.data(), d_sample, sample.size() * 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            plan_packed_round(sample.data(), S, force, p0, pl);
+            if (experiment("ZDW_SORT_DEBUG"))
+                fprintf(stderr, "[sort] packed round at byte %u over %u strings: %s (up to byte %u in %u + 9 bits, %.2f %% of the sample left out, the next round at byte %u)\n",
+                        p0, m0, pl.use ? "yes" : "no", pl.chars, pl.P, 100.0 * pl.exceptions, 8 * pl.depth_after);
+        }
+        if (!pl.use) return sort_region(pos0, m0, identity, nullptr, 0, depth0);
+        uint32_t *d_counts = d_big + 4;
+        uint32_t counts[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(d_table, pl.table.data(), 256 * sizeof(PackedBucket), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemsetAsync(d_counts, 0, 12, s));
+        HIPCHK(hipStreamSynchronize(s));                            // (pl.table has been read)
+        const PackedKeySpec ps{d_table, pl.P, p0};
+        int e = sort_region(pos0, m0, identity, &ps, pl.depth_after, depth0);
         if (e) return e;
-        if (rounds_out) *rounds_out = rounds;
-        return 0;
-    }
-    // the packed round over all ids, then the rounds the conforming strings still need
-    uint32_t *d_counts = d_big + 4;
-    uint32_t counts[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(d_table, pl.table.data(), 256 * sizeof(PackedBucket), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(d_counts, 0, 12, s));
-    HIPCHK(hipStreamSynchronize(s));                                // (pl.table has been read)
-    const PackedKeySpec ps{d_table, pl.P};
-    int e = sort_region(0, n, true, &ps, pl.depth_after);
-    if (e) return e;
-    HIPCHK(hipMemcpyAsync(counts, d_counts, 12, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const uint32_t nh = counts[0], na = counts[1], nx = counts[2];
-    if ((uint64_t)nh + na + nx != n) return (int)hipErrorUnknown;   // (cannot happen)
-    if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] %u holes, %u conforming strings, %u exceptions\n", nh, na, nx);
-    if (nx) {
-        if (nx > 1 && nx <= SORT_TINY && uniq_key) {
-            hipLaunchKernelGGL(k_sort_tiny, dim3(1), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order + nh + na, nx, tmp);
-            HIPCHK(hipMemcpyAsync(b.order + nh + na, tmp, (size_t)nx * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(counts, d_counts, 12, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const uint32_t nh = counts[0], na = counts[1], nx = counts[2];
+        if ((uint64_t)nh + na + nx != m0) return (int)hipErrorUnknown;      // (cannot happen)
+        if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] %u holes, %u conforming strings, %u exceptions\n", nh, na, nx);
+        if (!nx) return 0;
+        uint32_t *A = b.order + pos0 + nh, *B = A + na;
+        if (nx > 1 && nx <= SORT_TINY) {
+            hipLaunchKernelGGL(k_sort_tiny, dim3(1), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, B, nx, tmp);
+            HIPCHK(hipMemcpyAsync(B, tmp, (size_t)nx * 4, hipMemcpyDeviceToDevice, s));
             ++rounds;
-        } else {
-            hipLaunchKernelGGL(k_sort_init_range, dim3((nx + 255) / 256), dim3(256), 0, s, b.active_a, b.group, nh + na, nx);
-            e = sort_region(nh + na, nx, false, nullptr, 0);
+        } else if (nx > 1) {
+            hipLaunchKernelGGL(k_sort_init_range, dim3((nx + 255) / 256), dim3(256), 0, s, b.active_a, b.group, pos0 + nh + na, nx);
+            e = sort_region(pos0 + nh + na, nx, false, nullptr, 0, depth0);
             if (e) return e;
         }
         if (na) {
             uint32_t *rank = still;
-            hipLaunchKernelGGL(k_merge_ranks, dim3((nx + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, b.order + nh, na,
-                               b.order + nh + na, nx, rank);
-            hipLaunchKernelGGL(k_merge_place, dim3((na + nx + 255) / 256), dim3(256), 0, s, b.order + nh, na, b.order + nh + na, nx, rank, tmp);
-            HIPCHK(hipMemcpyAsync(b.order + nh, tmp, (size_t)(na + nx) * 4, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(k_merge_ranks, dim3((nx + 255) / 256), dim3(256), 0, s, in, in_bytes, extra, uniq_pos, uniq_len, uniq_key, A, na, B, nx, rank);
+            hipLaunchKernelGGL(k_merge_place, dim3((na + nx + 255) / 256), dim3(256), 0, s, A, na, B, nx, rank, tmp);
+            HIPCHK(hipMemcpyAsync(A, tmp, (size_t)(na + nx) * 4, hipMemcpyDeviceToDevice, s));
         }
-    }
+        return 0;
+    };
+    const int e = sort_any(0, n, true, 0);
+    if (e) return e;
     if (rounds_out) *rounds_out = rounds;
     return 0;
 }
