@@ -277,16 +277,18 @@ __global__ __launch_bounds__(256) void k_sort_init(uint32_t *order, uint32_t *ac
 // holds the strings of all text columns, so this is looked at per FIRST BYTE, on a sample of the strings (plan_packed_round, on the
 // host): for each first byte and each of the places 1..23 kept by id (Pass1Args.uniq_key) the narrowest block that holds 98 % of the
 // sample's bytes.  A string CONFORMS when every one of its places lies in its first byte's blocks (exact, on the device, for every
-// string: k_sort_classes); the others -- names among 67 M date-times, a date-time cut short -- are EXCEPTIONS.  Then
-//   * the ids are grouped: holes, conforming strings, exceptions (one radix pass on the class);
-//   * the conforming strings' first round sorts by  1 | first byte (8 bits) | the low w bits of places 1 .. nchars - 1 (P bits):
-//     16 or 24 characters in one round instead of 8, on ceil((P + 9) / 8) radix passes instead of 8.  (The reference's movie_tickets
-//     table times 128: the date-times' 23 places take 39 bits -- one round of 6 passes instead of three rounds of 8 and their
-//     tie-group passes.)  Order-preserving: strings with different first bytes differ above bit P; two conforming strings of one
-//     first byte that first differ at place i agree in that place's dropped bits and in every bit before.  What is still tied goes
-//     on in ordinary rounds behind the characters every first byte's key covered;
-//   * the exceptions (few, or the plan is dropped) are sorted by ordinary rounds;
+// string: k_sort_keys_packed); the others -- names among 67 M date-times, a date-time cut short -- are EXCEPTIONS.  Then
+//   * the packed round sorts all the list's ids by one key: 0 for a hole,  1 | first byte (8 bits) | the low w bits of places
+//     1 .. nchars - 1 (P bits)  for a conforming string, 2^(P+9) for an exception -- 16 or 24 characters in one round instead of 8,
+//     on ceil((P + 10) / 8) radix passes instead of 8 -- and leaves holes | conforming strings in order | exceptions.  (The reference's
+//     movie_tickets table times 128: the date-times' 23 places take 33 bits -- one round of 6 passes instead of three rounds of 8
+//     and their tie-group passes.)  Order-preserving: strings with different first bytes differ above bit P; two conforming strings
+//     of one first byte that first differ at place i agree in that place's dropped bits and in every bit before.  What is still
+//     tied among the conforming strings goes on in ordinary rounds behind the characters every first byte's key covered;
+//   * the exceptions (few, or the plan is dropped) are sorted by ordinary rounds -- up to 1024 of them by one workgroup;
 //   * the two sorted lists are merged: every exception finds its place among the conforming strings by bisection on whole strings.
+// The same for ONE LONG RUN of strings a round leaves tied over their first p0 = 8 or 16 bytes (dict_sort: sort_any): the byte at
+// place p0 takes the first byte's part, the key holds the places behind it.
 struct PackedBucket {
     uint64_t w[2];          // 4 bits per place 1..23: its width
     uint64_t himask[3];     // per byte of the string's three words: the bits above the width (none for place 0 and places >= nchars)
