@@ -768,7 +768,10 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
     // packed one -- it leaves holes | conforming strings | exceptions (the exceptions in no order yet), the rounds behind it go on
     // with the conforming strings still tied, at byte 8 * depth_after.
     std::function<int(uint32_t, uint32_t, bool, uint32_t)> sort_any;      // (below: a list sorted with a packed round where that pays)
-    auto sort_region = [&](uint32_t off0, uint32_t m0, bool identity, const PackedKeySpec *pk, uint32_t depth_after, uint32_t depth0) -> int {
+    // (counts_out: the packed round's class counts, read back with the round's other figures -- before a long run can start a packed
+    // round of its own, which uses the same words)
+    auto sort_region = [&](uint32_t off0, uint32_t m0, bool identity, const PackedKeySpec *pk, uint32_t depth_after, uint32_t depth0,
+                           uint32_t *counts_out) -> int {
         uint32_t *active = b.active_a, *active_alt = b.active_b;
         uint32_t *group = b.group, *group_next = group_next0;      // tie-group labels per active index
         uint32_t m = m0, off = off0, max_label = 0;   // max_label: the largest tie-group label of the round (0 in the first: one group)
@@ -804,6 +807,7 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
             HIPCHK(hipMemcpyAsync(&m_next, still_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(&max_label, head_scan + m, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(&nbig, d_big, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            if (packed && counts_out) HIPCHK(hipMemcpyAsync(counts_out, d_big + 4, 12, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             uint32_t *t = active; active = active_alt; active_alt = t;
             t = group; group = group_next; group_next = t;
@@ -869,17 +873,15 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
                 fprintf(stderr, "[sort] packed round at byte %u over %u strings: %s (up to byte %u in %u + 9 bits, %.2f %% of the sample left out, the next round at byte %u)\n",
                         p0, m0, pl.use ? "yes" : "no", pl.chars, pl.P, 100.0 * pl.exceptions, 8 * pl.depth_after);
         }
-        if (!pl.use) return sort_region(pos0, m0, identity, nullptr, 0, depth0);
+        if (!pl.use) return sort_region(pos0, m0, identity, nullptr, 0, depth0, nullptr);
         uint32_t *d_counts = d_big + 4;
         uint32_t counts[3] = {0, 0, 0};
         HIPCHK(hipMemcpyAsync(d_table, pl.table.data(), 256 * sizeof(PackedBucket), hipMemcpyHostToDevice, s));
         HIPCHK(hipMemsetAsync(d_counts, 0, 12, s));
         HIPCHK(hipStreamSynchronize(s));                            // (pl.table has been read)
         const PackedKeySpec ps{d_table, pl.P, p0};
-        int e = sort_region(pos0, m0, identity, &ps, pl.depth_after, depth0);
+        int e = sort_region(pos0, m0, identity, &ps, pl.depth_after, depth0, counts);
         if (e) return e;
-        HIPCHK(hipMemcpyAsync(counts, d_counts, 12, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
         const uint32_t nh = counts[0], na = counts[1], nx = counts[2];
         if ((uint64_t)nh + na + nx != m0) return (int)hipErrorUnknown;      // (cannot happen)
         if (experiment("ZDW_SORT_DEBUG")) fprintf(stderr, "[sort] %u holes, %u conforming strings, %u exceptions\n", nh, na, nx);
@@ -891,7 +893,7 @@ int dict_sort(const uint8_t *in, uint64_t in_bytes, const uint8_t *extra, const 
             ++rounds;
         } else if (nx > 1) {
             hipLaunchKernelGGL(k_sort_init_range, dim3((nx + 255) / 256), dim3(256), 0, s, b.active_a, b.group, pos0 + nh + na, nx);
-            e = sort_region(pos0 + nh + na, nx, false, nullptr, 0, depth0);
+            e = sort_region(pos0 + nh + na, nx, false, nullptr, 0, depth0, nullptr);
             if (e) return e;
         }
         if (na) {
